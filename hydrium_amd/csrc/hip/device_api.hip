@@ -1,0 +1,701 @@
+/*
+ * device_api.hip — the thin C-ABI between the C host side and the HIP kernels (include/hydrium_amd.h).
+ *
+ * Memory plan (sized for 288 GB of HBM3E: nothing is ever reallocated on the hot path):
+ *   per LF-group slot   tokens   64 groups x 196608 records x 8 B   = 100.7 MB  (hard worst case)
+ *                       bitbuf   64 groups x 1.13 MB reversed bits  =  72.4 MB  (hard worst case)
+ *                       tables   HydkTables                          =  86 KB
+ *                       dc       3 x 256 x 256 int32                 = 768 KB
+ *                       hist / counts / section bits+offsets         <   8 KB
+ *   per context         in_lut8 (512 B), in_lut16 (128 KB), bias_lut (256 KB)
+ *                       payload  packed HF sections, sized like bitbuf (its hard upper bound)
+ *                       2 x (pinned host + device) staging tiles for the host-pointer path
+ * A 16384x16384 frame (64 slots) therefore pins 15.7 GB; an 8192x8192 frame 3.9 GB.
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../../include/hydrium_amd.h"
+#include "hydk_common.h"
+
+#pragma clang fp contract(off)
+
+namespace hydk {
+hipError_t launch_transform(const HydkLfJob &job, uint32_t *status, hipStream_t stream);
+hipError_t launch_tables(const uint32_t *hist, HydkTables *tab, uint32_t *running_max, int nclusters, hipStream_t stream);
+hipError_t launch_rans(const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tab, uint32_t *bitbuf,
+                       uint32_t *group_bits, int num_groups, uint32_t preset, int preset_bits, hipStream_t stream);
+hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, hipStream_t stream);
+hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
+                       int count, hipStream_t stream);
+hipError_t launch_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, int linear_light, uint32_t *mismatches,
+                               hipStream_t stream);
+} // namespace hydk
+
+/* HYDStatusCode values (include/libhydrium/libhydrium.h) */
+#define ST_OK 0
+#define ST_NOMEM (-13)
+#define ST_API_ERROR (-14)
+#define ST_INTERNAL_ERROR (-15)
+
+static_assert(HYDAMD_MAX_CLUSTERS == HYDK_MAX_CLUSTERS && HYDAMD_ALPHABET == HYDK_ALPHABET &&
+                  HYDAMD_GROUPS_PER_LFG == HYDK_GROUPS_PER_LFG,
+              "public and kernel-side table shapes must agree");
+
+namespace {
+
+constexpr int kStaging = 2;
+constexpr size_t kDbgPlane = (size_t)2048 * 2048;
+
+char g_global_error[256] = "";
+
+struct TimedLaunch {
+    int cls;
+    hipEvent_t start, stop;
+};
+
+} // namespace
+
+struct HydAmdContext {
+    int device = 0;
+    int max_slots = 0;
+    int linear_light = 0;
+    int use_luts = 1;
+    int register_luts_ok = 0;
+    unsigned num_presets = 1;
+    int scheme = 0;
+    int nclusters = 9;
+    int preset_bits = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char error[256] = "";
+
+    /* device memory */
+    uint64_t *tokens = nullptr;     /* [slots][64][TOKENS_PER_GROUP] */
+    uint32_t *bitbuf = nullptr;     /* [slots][64][BITWORDS_PER_GROUP] */
+    HydkTables *tables = nullptr;   /* [slots] */
+    int32_t *dc = nullptr;          /* [slots][3][256][256] */
+    uint32_t *hist = nullptr;       /* [slots][9][128] */
+    uint32_t *sym_count = nullptr;  /* [slots][64] */
+    uint32_t *group_bits = nullptr; /* [slots][64] */
+    uint64_t *offsets = nullptr;    /* [slots][64] */
+    uint64_t *total = nullptr;      /* [1] */
+    uint32_t *status = nullptr;     /* [1] bit 0: non-finite float sample */
+    uint32_t *running_max = nullptr;
+    uint16_t *in_lut8 = nullptr, *in_lut16 = nullptr;
+    float *bias_lut = nullptr;
+    uint8_t *payload = nullptr;
+    size_t payload_cap = 0;
+    float *dbg_xyb = nullptr, *dbg_dct = nullptr;
+    int32_t *dbg_quant = nullptr;
+
+    /* staging for the host-pointer path */
+    void *pinned[kStaging] = {nullptr, nullptr};
+    void *d_in[kStaging] = {nullptr, nullptr};
+    size_t staging_cap = 0;
+    hipEvent_t staged[kStaging] = {nullptr, nullptr};
+    int staging_next = 0;
+
+    /* host mirrors filled by hydamd_sync */
+    uint64_t h_total = 0;
+    uint32_t h_status = 0;
+    int slots_finished = 0;
+    bool results_valid = false;
+    uint64_t *h_total_pinned = nullptr;
+    uint32_t *h_status_pinned = nullptr;
+
+    /* profiling */
+    bool profiling = false;
+    std::vector<TimedLaunch> timed;
+    double prof_ms[HYDAMD_K_COUNT] = {0, 0, 0, 0};
+    uint64_t prof_n[HYDAMD_K_COUNT] = {0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(HydAmdContext *ctx, int code, const char *what, hipError_t e = hipSuccess) {
+    char *dst = ctx ? ctx->error : g_global_error;
+    if (e != hipSuccess)
+        snprintf(dst, 256, "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(dst, 256, "%s", what);
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                          \
+    do {                                                                            \
+        hipError_t e__ = (call);                                                    \
+        if (e__ != hipSuccess)                                                      \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? ST_NOMEM : ST_INTERNAL_ERROR, #call, e__); \
+    } while (0)
+
+/* ---- the three LUTs of the integer pixel path, built on the host exactly as the reference does
+ * (format.c:15-36,58-83); x86-64 without contraction is the canonical arithmetic ---- */
+float host_linearize(float x) {
+    if (x <= 0.0404482362771082f)
+        return 0.07739938080495357f * x;
+    return 0.003094300919832f + x * (-0.009982599f + x * (0.72007737769f + 0.2852804880f * x));
+}
+
+float host_bias(float v) {
+    const float x = v + 0.0037930732552754493f;
+    union {
+        float f;
+        uint32_t u;
+    } z;
+    z.f = x;
+    z.u = 0x548c39cbu - z.u / 3u;
+    z.f *= 1.5015480449f - 0.534850249f * x * z.f * z.f * z.f;
+    z.f *= 1.333333985f - 0.33333333f * x * z.f * z.f * z.f;
+    return 1.0f / z.f - 0.155954f;
+}
+
+void host_input_lut(uint16_t *lut, size_t size, int linear_light) {
+    const float unit = 1.0f / (size - 1.0f);
+    for (size_t i = 0; i < size; i++) {
+        const float f = i * unit;
+        const int32_t y = (int32_t)((linear_light ? f : host_linearize(f)) * 65535.f + 0.5f);
+        lut[i] = (uint16_t)(y < 0 ? 0 : y > 65535 ? 65535 : y);
+    }
+}
+
+size_t sample_size(int fmt) { return fmt == HYDK_FMT_U8 ? 1 : fmt == HYDK_FMT_U16 ? 2 : 4; }
+
+struct ScopedTimer {
+    HydAmdContext *ctx;
+    TimedLaunch tl;
+    bool on;
+    ScopedTimer(HydAmdContext *c, int cls) : ctx(c), on(c->profiling) {
+        if (!on)
+            return;
+        tl.cls = cls;
+        (void)hipEventCreate(&tl.start);
+        (void)hipEventCreate(&tl.stop);
+        (void)hipEventRecord(tl.start, ctx->stream);
+    }
+    ~ScopedTimer() {
+        if (!on)
+            return;
+        (void)hipEventRecord(tl.stop, ctx->stream);
+        ctx->timed.push_back(tl);
+    }
+};
+
+void drain_timers(HydAmdContext *ctx) {
+    for (TimedLaunch &tl : ctx->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, tl.start, tl.stop) == hipSuccess) {
+            ctx->prof_ms[tl.cls] += ms;
+            ctx->prof_n[tl.cls]++;
+        }
+        (void)hipEventDestroy(tl.start);
+        (void)hipEventDestroy(tl.stop);
+    }
+    ctx->timed.clear();
+}
+
+int check_slot(HydAmdContext *ctx, int slot) {
+    if (!ctx)
+        return fail(nullptr, ST_API_ERROR, "null context");
+    if (slot < 0 || slot >= ctx->max_slots)
+        return fail(ctx, ST_API_ERROR, "LF-group slot out of range");
+    return ST_OK;
+}
+
+int enqueue_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrdiff_t row_stride, ptrdiff_t pixel_stride,
+                     int fmt, size_t width, size_t height, unsigned preset) {
+    if (width == 0 || height == 0 || width > 2048 || height > 2048)
+        return fail(ctx, ST_API_ERROR, "LF group must be between 1 and 2048 pixels in each direction");
+    if (fmt != HYDK_FMT_U8 && fmt != HYDK_FMT_U16 && fmt != HYDK_FMT_F32)
+        return fail(ctx, ST_API_ERROR, "Invalid Sample Format");
+    if (preset >= ctx->num_presets)
+        return fail(ctx, ST_API_ERROR, "preset out of range for this frame");
+
+    HydkLfJob job;
+    memset(&job, 0, sizeof(job));
+    for (int c = 0; c < 3; c++)
+        job.src[c] = src[c];
+    job.row_stride = row_stride;
+    job.pixel_stride = pixel_stride;
+    job.fmt = fmt;
+    job.linear_light = ctx->linear_light;
+    job.width = (int)width;
+    job.height = (int)height;
+    job.gcols = (int)((width + 255) >> 8);
+    job.grows = (int)((height + 255) >> 8);
+    job.scheme = ctx->scheme;
+    job.use_luts = ctx->use_luts;
+    job.in_lut8 = ctx->in_lut8;
+    job.in_lut16 = ctx->in_lut16;
+    job.bias_lut = ctx->bias_lut;
+    job.tokens = ctx->tokens + (size_t)slot * HYDK_GROUPS_PER_LFG * HYDK_TOKENS_PER_GROUP;
+    job.sym_count = ctx->sym_count + (size_t)slot * HYDK_GROUPS_PER_LFG;
+    job.hist = ctx->hist + (size_t)slot * HYDK_MAX_CLUSTERS * HYDK_ALPHABET;
+    job.dc = ctx->dc + (size_t)slot * 3 * HYDK_DC_PITCH * HYDK_DC_PITCH;
+    job.dbg_xyb = ctx->dbg_xyb;
+    job.dbg_dct = ctx->dbg_dct;
+    job.dbg_quant = ctx->dbg_quant;
+    const int ngroups = job.gcols * job.grows;
+
+    ctx->results_valid = false;
+    {
+        ScopedTimer timer(ctx, HYDAMD_K_TRANSFORM);
+        HIP_TRY(ctx, hydk::launch_transform(job, ctx->status, ctx->stream));
+    }
+    {
+        ScopedTimer timer(ctx, HYDAMD_K_TABLES);
+        HIP_TRY(ctx, hydk::launch_tables(job.hist, ctx->tables + slot, ctx->running_max, ctx->nclusters, ctx->stream));
+    }
+    {
+        ScopedTimer timer(ctx, HYDAMD_K_RANS);
+        HIP_TRY(ctx, hydk::launch_rans(job.tokens, job.sym_count, ctx->tables + slot,
+                                       ctx->bitbuf + (size_t)slot * HYDK_GROUPS_PER_LFG * HYDK_BITWORDS_PER_GROUP,
+                                       ctx->group_bits + (size_t)slot * HYDK_GROUPS_PER_LFG, ngroups, preset,
+                                       ctx->preset_bits, ctx->stream));
+    }
+    return ST_OK;
+}
+
+int ensure_staging(HydAmdContext *ctx, size_t bytes) {
+    if (bytes <= ctx->staging_cap)
+        return ST_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < kStaging; i++) {
+        if (ctx->pinned[i])
+            (void)hipHostFree(ctx->pinned[i]);
+        if (ctx->d_in[i])
+            (void)hipFree(ctx->d_in[i]);
+        ctx->pinned[i] = ctx->d_in[i] = nullptr;
+    }
+    ctx->staging_cap = 0;
+    for (int i = 0; i < kStaging; i++) {
+        HIP_TRY(ctx, hipHostMalloc(&ctx->pinned[i], bytes, hipHostMallocDefault));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_in[i], bytes));
+        if (!ctx->staged[i])
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->staged[i], hipEventDisableTiming));
+    }
+    ctx->staging_cap = bytes;
+    return ST_OK;
+}
+
+/* interleave the caller's (possibly planar / strided / bottom-up) samples as packed RGB */
+template <typename T>
+void gather_packed(T *dst, const void *const src[3], ptrdiff_t row_stride, ptrdiff_t pixel_stride, size_t w, size_t h) {
+    const T *r = (const T *)src[0], *g = (const T *)src[1], *b = (const T *)src[2];
+    const bool interleaved = pixel_stride == 3 && g == r + 1 && b == r + 2;
+    for (size_t y = 0; y < h; y++) {
+        T *d = dst + y * w * 3;
+        const ptrdiff_t yo = (ptrdiff_t)y * row_stride;
+        if (interleaved) {
+            memcpy(d, r + yo, w * 3 * sizeof(T));
+        } else {
+            for (size_t x = 0; x < w; x++) {
+                const ptrdiff_t o = yo + (ptrdiff_t)x * pixel_stride;
+                d[3 * x] = r[o];
+                d[3 * x + 1] = g[o];
+                d[3 * x + 2] = b[o];
+            }
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int hydamd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+const char *hydamd_error(HydAmdContext *ctx) { return ctx ? ctx->error : g_global_error; }
+
+void hydamd_destroy(HydAmdContext *ctx) {
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    drain_timers(ctx);
+    void *dev[] = {ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->hist, ctx->sym_count, ctx->group_bits,
+                   ctx->offsets, ctx->total, ctx->status, ctx->running_max, ctx->in_lut8, ctx->in_lut16,
+                   ctx->bias_lut, ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant};
+    for (void *p : dev)
+        if (p)
+            (void)hipFree(p);
+    for (int i = 0; i < kStaging; i++) {
+        if (ctx->pinned[i])
+            (void)hipHostFree(ctx->pinned[i]);
+        if (ctx->d_in[i])
+            (void)hipFree(ctx->d_in[i]);
+        if (ctx->staged[i])
+            (void)hipEventDestroy(ctx->staged[i]);
+    }
+    if (ctx->h_total_pinned)
+        (void)hipHostFree(ctx->h_total_pinned);
+    if (ctx->h_status_pinned)
+        (void)hipHostFree(ctx->h_status_pinned);
+    if (ctx->own_stream)
+        (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+static int create_impl(HydAmdContext *ctx, int debug_planes) {
+    const size_t slots = (size_t)ctx->max_slots, G = HYDK_GROUPS_PER_LFG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    HIP_TRY(ctx, hipMalloc(&ctx->tokens, slots * G * HYDK_TOKENS_PER_GROUP * sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->bitbuf, slots * G * HYDK_BITWORDS_PER_GROUP * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->tables, slots * sizeof(HydkTables)));
+    HIP_TRY(ctx, hipMalloc(&ctx->dc, slots * 3 * HYDK_DC_PITCH * HYDK_DC_PITCH * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->hist, slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->sym_count, slots * G * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->group_bits, slots * G * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->offsets, slots * G * sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->total, sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->status, sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->running_max, sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->in_lut8, 256 * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->in_lut16, 65536 * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->bias_lut, 65536 * sizeof(float)));
+    /* packed sections can never exceed the reversed bit buffers they are copied from, so sizing
+     * the payload to that bound keeps hydamd_finish_frame free of any host synchronisation */
+    ctx->payload_cap = slots * G * HYDK_BITWORDS_PER_GROUP * sizeof(uint32_t);
+    HIP_TRY(ctx, hipMalloc(&ctx->payload, ctx->payload_cap));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_total_pinned, sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_status_pinned, sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(ctx, hipMemset(ctx->group_bits, 0, slots * G * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemset(ctx->sym_count, 0, slots * G * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemset(ctx->status, 0, sizeof(uint32_t)));
+    if (debug_planes) {
+        HIP_TRY(ctx, hipMalloc(&ctx->dbg_xyb, 3 * kDbgPlane * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(&ctx->dbg_dct, 3 * kDbgPlane * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(&ctx->dbg_quant, 3 * kDbgPlane * sizeof(int32_t)));
+    }
+
+    /* LUTs: built on the host, uploaded, then the register evaluation is checked against them */
+    std::vector<uint16_t> l8(256), l16(65536);
+    std::vector<float> bias(65536);
+    host_input_lut(l8.data(), 256, ctx->linear_light);
+    host_input_lut(l16.data(), 65536, ctx->linear_light);
+    const float unit = 1.0f / (65536 - 1.0f);
+    for (size_t i = 0; i < 65536; i++)
+        bias[i] = host_bias(i * unit);
+    HIP_TRY(ctx, hipMemcpy(ctx->in_lut8, l8.data(), 256 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->in_lut16, l16.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->bias_lut, bias.data(), 65536 * sizeof(float), hipMemcpyHostToDevice));
+
+    uint32_t *mism = nullptr;
+    HIP_TRY(ctx, hipMalloc(&mism, sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemset(mism, 0, sizeof(uint32_t)));
+    HIP_TRY(ctx, hydk::launch_lut_selftest(ctx->in_lut16, ctx->bias_lut, ctx->linear_light, mism, ctx->stream));
+    uint32_t h_mism = 1;
+    HIP_TRY(ctx, hipMemcpyAsync(&h_mism, mism, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(mism);
+    ctx->register_luts_ok = h_mism == 0;
+    ctx->use_luts = !ctx->register_luts_ok;
+    if (const char *env = getenv("HYDAMD_FORCE_LUTS"))
+        ctx->use_luts = atoi(env) != 0 || !ctx->register_luts_ok;
+    return ST_OK;
+}
+
+HydAmdContext *hydamd_create(int device, int max_lf_groups, int linear_light, int debug_planes, int *status) {
+    int st = ST_OK;
+    HydAmdContext *ctx = nullptr;
+    if (max_lf_groups < 1 || max_lf_groups > HYDAMD_MAX_LF_GROUPS) {
+        st = fail(nullptr, ST_API_ERROR, "max_lf_groups must be between 1 and 255");
+    } else if (hydamd_device_count() <= device || device < 0) {
+        st = fail(nullptr, ST_INTERNAL_ERROR, "no usable HIP device (this build has no CPU fallback)");
+    } else {
+        ctx = new (std::nothrow) HydAmdContext();
+        if (!ctx) {
+            st = fail(nullptr, ST_NOMEM, "out of host memory");
+        } else {
+            ctx->device = device;
+            ctx->max_slots = max_lf_groups;
+            ctx->linear_light = linear_light != 0;
+            st = create_impl(ctx, debug_planes);
+            if (st != ST_OK) {
+                snprintf(g_global_error, sizeof(g_global_error), "%s", ctx->error);
+                hydamd_destroy(ctx);
+                ctx = nullptr;
+            }
+        }
+    }
+    if (status)
+        *status = st;
+    return ctx;
+}
+
+int hydamd_set_stream(HydAmdContext *ctx, void *hip_stream) {
+    if (!ctx)
+        return ST_API_ERROR;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ST_OK;
+}
+
+void *hydamd_get_stream(HydAmdContext *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int hydamd_uses_register_luts(HydAmdContext *ctx) { return ctx && !ctx->use_luts; }
+
+int hydamd_force_luts(HydAmdContext *ctx, int use_luts) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (!use_luts && !ctx->register_luts_ok)
+        return fail(ctx, ST_INTERNAL_ERROR, "register LUT evaluation failed its self-test on this device");
+    ctx->use_luts = use_luts != 0;
+    return ST_OK;
+}
+
+int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
+    if (!ctx)
+        return ST_API_ERROR;
+    /* 128 or 256 presets would need 256 clusters, which the reference cannot code (entropy.c:99) */
+    if (num_presets < 1 || num_presets > HYDAMD_MAX_LF_GROUPS || num_presets == 128)
+        return fail(ctx, ST_API_ERROR, "unsupported number of LF groups per frame (1..255 except 128)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->num_presets = num_presets;
+    /* clustering scheme by preset count (encoder.c:862-901) */
+    if (num_presets * 9 <= 256) {
+        ctx->scheme = 0;
+        ctx->nclusters = 9;
+    } else if (num_presets * 3 <= 256) {
+        ctx->scheme = 1;
+        ctx->nclusters = 3;
+    } else if (num_presets * 2 <= 256) {
+        ctx->scheme = 2;
+        ctx->nclusters = 2;
+    } else {
+        ctx->scheme = 3;
+        ctx->nclusters = 1;
+    }
+    int bits = 0;
+    while ((1u << bits) < num_presets)
+        bits++;
+    ctx->preset_bits = bits; /* hyd_cllog2(num_presets), encoder.c:940 */
+    ctx->results_valid = false;
+    ctx->slots_finished = 0;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->hist, 0,
+                                (size_t)ctx->max_slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->running_max, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->status, 0, sizeof(uint32_t), ctx->stream));
+    return ST_OK;
+}
+
+int hydamd_encode_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrdiff_t row_stride,
+                           ptrdiff_t pixel_stride, int sample_fmt, size_t width, size_t height, unsigned preset) {
+    int st = check_slot(ctx, slot);
+    if (st != ST_OK)
+        return st;
+    if (!src || !src[0] || !src[1] || !src[2])
+        return fail(ctx, ST_API_ERROR, "null pixel pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return enqueue_lf_group(ctx, slot, src, row_stride, pixel_stride, sample_fmt, width, height, preset);
+}
+
+int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, const void *const src[3], ptrdiff_t row_stride,
+                                ptrdiff_t pixel_stride, int sample_fmt, size_t width, size_t height, unsigned preset) {
+    int st = check_slot(ctx, slot);
+    if (st != ST_OK)
+        return st;
+    if (!src || !src[0] || !src[1] || !src[2])
+        return fail(ctx, ST_API_ERROR, "null pixel pointer");
+    if (width == 0 || height == 0 || width > 2048 || height > 2048)
+        return fail(ctx, ST_API_ERROR, "LF group must be between 1 and 2048 pixels in each direction");
+    if (sample_fmt != HYDK_FMT_U8 && sample_fmt != HYDK_FMT_U16 && sample_fmt != HYDK_FMT_F32)
+        return fail(ctx, ST_API_ERROR, "Invalid Sample Format");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t ss = sample_size(sample_fmt);
+    const size_t bytes = width * height * 3 * ss;
+    /* size for a full 2048x2048 tile of this sample type so that later tiles never reallocate */
+    st = ensure_staging(ctx, (size_t)2048 * 2048 * 3 * ss);
+    if (st != ST_OK)
+        return st;
+    const int k = ctx->staging_next;
+    ctx->staging_next = (k + 1) % kStaging;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->staged[k])); /* previous upload from this pinned tile has left */
+    if (sample_fmt == HYDK_FMT_U8)
+        gather_packed((uint8_t *)ctx->pinned[k], src, row_stride, pixel_stride, width, height);
+    else if (sample_fmt == HYDK_FMT_U16)
+        gather_packed((uint16_t *)ctx->pinned[k], src, row_stride, pixel_stride, width, height);
+    else
+        gather_packed((float *)ctx->pinned[k], src, row_stride, pixel_stride, width, height);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in[k], ctx->pinned[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->staged[k], ctx->stream));
+    const char *base = (const char *)ctx->d_in[k];
+    const void *dsrc[3] = {base, base + ss, base + 2 * ss};
+    return enqueue_lf_group(ctx, slot, dsrc, (ptrdiff_t)(3 * width), 3, sample_fmt, width, height, preset);
+}
+
+int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (num_slots < 1 || num_slots > ctx->max_slots)
+        return fail(ctx, ST_API_ERROR, "slot count out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int count = num_slots * HYDK_GROUPS_PER_LFG;
+    ctx->results_valid = false;
+    {
+        ScopedTimer timer(ctx, HYDAMD_K_PACK);
+        HIP_TRY(ctx, hydk::launch_scan(ctx->group_bits, count, ctx->offsets, ctx->total, ctx->stream));
+    }
+    {
+        ScopedTimer timer(ctx, HYDAMD_K_PACK);
+        HIP_TRY(ctx, hydk::launch_pack(ctx->bitbuf, ctx->group_bits, ctx->offsets, ctx->payload, count, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_total_pinned, ctx->total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status_pinned, ctx->status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->slots_finished = num_slots;
+    return ST_OK;
+}
+
+int hydamd_sync(HydAmdContext *ctx) {
+    if (!ctx)
+        return ST_API_ERROR;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_timers(ctx);
+    ctx->h_total = *ctx->h_total_pinned;
+    ctx->h_status = *ctx->h_status_pinned;
+    if (ctx->h_status & 1u)
+        return fail(ctx, ST_API_ERROR, "Invalid NaN Float");
+    ctx->results_valid = true;
+    return ST_OK;
+}
+
+size_t hydamd_payload_size(HydAmdContext *ctx) { return ctx && ctx->results_valid ? (size_t)ctx->h_total : 0; }
+
+const uint8_t *hydamd_payload_device(HydAmdContext *ctx) { return ctx ? ctx->payload : nullptr; }
+
+int hydamd_read_payload(HydAmdContext *ctx, uint8_t *dst, size_t capacity) {
+    if (!ctx || !ctx->results_valid)
+        return fail(ctx, ST_API_ERROR, "results not ready: call hydamd_finish_frame and hydamd_sync first");
+    if (capacity < ctx->h_total)
+        return fail(ctx, ST_API_ERROR, "payload buffer too small");
+    if (ctx->h_total)
+        HIP_TRY(ctx, hipMemcpy(dst, ctx->payload, ctx->h_total, hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int hydamd_read_sections(HydAmdContext *ctx, int slot, uint32_t bits[HYDAMD_GROUPS_PER_LFG],
+                         uint64_t offsets[HYDAMD_GROUPS_PER_LFG]) {
+    int st = check_slot(ctx, slot);
+    if (st != ST_OK)
+        return st;
+    HIP_TRY(ctx, hipMemcpy(bits, ctx->group_bits + (size_t)slot * HYDK_GROUPS_PER_LFG,
+                           HYDK_GROUPS_PER_LFG * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (offsets)
+        HIP_TRY(ctx, hipMemcpy(offsets, ctx->offsets + (size_t)slot * HYDK_GROUPS_PER_LFG,
+                               HYDK_GROUPS_PER_LFG * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int hydamd_read_tables(HydAmdContext *ctx, int slot, uint32_t freq[HYDAMD_MAX_CLUSTERS][HYDAMD_ALPHABET],
+                       uint32_t alphabet[HYDAMD_MAX_CLUSTERS], uint32_t *log_alphabet_size,
+                       uint32_t *running_max_alphabet) {
+    int st = check_slot(ctx, slot);
+    if (st != ST_OK)
+        return st;
+    const HydkTables *t = ctx->tables + slot;
+    struct {
+        uint32_t alphabet[HYDK_MAX_CLUSTERS];
+        uint32_t log_alphabet_size, running_max_alphabet, error, pad;
+    } tail;
+    HIP_TRY(ctx, hipMemcpy(freq, t->freq, sizeof(t->freq), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&tail, t->alphabet, sizeof(tail), hipMemcpyDeviceToHost));
+    memcpy(alphabet, tail.alphabet, sizeof(tail.alphabet));
+    if (log_alphabet_size)
+        *log_alphabet_size = tail.log_alphabet_size;
+    if (running_max_alphabet)
+        *running_max_alphabet = tail.running_max_alphabet;
+    if (tail.error)
+        return fail(ctx, ST_INTERNAL_ERROR, "ANS table construction failed on the device");
+    return ST_OK;
+}
+
+int hydamd_read_dc(HydAmdContext *ctx, int slot, int32_t *dst, size_t vbw, size_t vbh) {
+    int st = check_slot(ctx, slot);
+    if (st != ST_OK)
+        return st;
+    if (vbw > HYDK_DC_PITCH || vbh > HYDK_DC_PITCH)
+        return fail(ctx, ST_API_ERROR, "DC plane larger than an LF group");
+    const int32_t *src = ctx->dc + (size_t)slot * 3 * HYDK_DC_PITCH * HYDK_DC_PITCH;
+    for (int c = 0; c < 3; c++)
+        HIP_TRY(ctx, hipMemcpy2D(dst + (size_t)c * vbw * vbh, vbw * sizeof(int32_t),
+                                 src + (size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH, HYDK_DC_PITCH * sizeof(int32_t),
+                                 vbw * sizeof(int32_t), vbh, hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int hydamd_read_symbol_counts(HydAmdContext *ctx, int slot, uint32_t counts[HYDAMD_GROUPS_PER_LFG]) {
+    int st = check_slot(ctx, slot);
+    if (st != ST_OK)
+        return st;
+    HIP_TRY(ctx, hipMemcpy(counts, ctx->sym_count + (size_t)slot * HYDK_GROUPS_PER_LFG,
+                           HYDK_GROUPS_PER_LFG * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int hydamd_read_tokens(HydAmdContext *ctx, int slot, int group, uint64_t *dst, size_t capacity) {
+    int st = check_slot(ctx, slot);
+    if (st != ST_OK)
+        return st;
+    if (group < 0 || group >= HYDK_GROUPS_PER_LFG || capacity > HYDK_TOKENS_PER_GROUP)
+        return fail(ctx, ST_API_ERROR, "group or capacity out of range");
+    const uint64_t *src = ctx->tokens + ((size_t)slot * HYDK_GROUPS_PER_LFG + group) * HYDK_TOKENS_PER_GROUP;
+    HIP_TRY(ctx, hipMemcpy(dst, src, capacity * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int hydamd_read_debug_plane(HydAmdContext *ctx, int which, void *dst, size_t pitch, size_t rows) {
+    if (!ctx)
+        return ST_API_ERROR;
+    const void *src = which == 0 ? (const void *)ctx->dbg_xyb : which == 1 ? (const void *)ctx->dbg_dct
+                                                                           : (const void *)ctx->dbg_quant;
+    if (!src)
+        return fail(ctx, ST_API_ERROR, "context was created without debug planes");
+    if (pitch > 2048 || rows > 2048)
+        return fail(ctx, ST_API_ERROR, "debug plane request too large");
+    for (int c = 0; c < 3; c++)
+        HIP_TRY(ctx, hipMemcpy2D((char *)dst + (size_t)c * pitch * rows * 4, pitch * 4,
+                                 (const char *)src + (size_t)c * kDbgPlane * 4, 2048 * 4, pitch * 4, rows,
+                                 hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int hydamd_profile(HydAmdContext *ctx, int enable) {
+    if (!ctx)
+        return ST_API_ERROR;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_timers(ctx);
+    ctx->profiling = enable != 0;
+    return ST_OK;
+}
+
+int hydamd_profile_read(HydAmdContext *ctx, double ms[HYDAMD_K_COUNT], uint64_t launches[HYDAMD_K_COUNT]) {
+    if (!ctx)
+        return ST_API_ERROR;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_timers(ctx);
+    for (int i = 0; i < HYDAMD_K_COUNT; i++) {
+        ms[i] = ctx->prof_ms[i];
+        launches[i] = ctx->prof_n[i];
+        ctx->prof_ms[i] = 0;
+        ctx->prof_n[i] = 0;
+    }
+    return ST_OK;
+}
+
+} /* extern "C" */

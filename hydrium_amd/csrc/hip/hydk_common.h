@@ -1,0 +1,68 @@
+/*
+ * hydk_common.h — shapes and device-side structs shared by the HIP kernels and their launcher.
+ *
+ * Vocabulary (JPEG XL / hydrium): an image is cut into LF groups of 2048x2048 px; an LF group into
+ * <= 64 groups of 256x256 px; a group into <= 1024 varblocks of 8x8 px.  Each group's HF
+ * coefficients are coded as one rANS chain into one "HF section" of the codestream.
+ */
+#ifndef HYDK_COMMON_H_
+#define HYDK_COMMON_H_
+
+#include <stdint.h>
+
+#define HYDK_FMT_U8 0
+#define HYDK_FMT_U16 1
+#define HYDK_FMT_F32 2
+
+#define HYDK_GROUPS_PER_LFG 64        /* 8 x 8 groups of 256 px in a 2048 px LF group */
+#define HYDK_BLOCKS_PER_GROUP 1024    /* 32 x 32 varblocks */
+#define HYDK_TOKENS_PER_GROUP 196608  /* hard maximum: 1024 blocks x 3 channels x (1 + 63) symbols */
+#define HYDK_MAX_CLUSTERS 9           /* clusters one preset owns (scheme 0); fewer in the coarser schemes */
+#define HYDK_ALPHABET 128             /* >= largest token + 1 (71 + 1) of the (4,1,0) hybrid-uint config */
+#define HYDK_ANS_SLOTS 4096           /* 12-bit ANS precision */
+#define HYDK_DC_PITCH 256             /* varblocks per row of an LF group's DC plane */
+/* Reversed per-group bit buffer, in 32-bit words.  Worst case per symbol is one 16-bit refill plus
+ * a 30-bit residue; 196608 * 46 bits = 1.13 MB, plus the 32-bit final state and preset bits. */
+#define HYDK_BITWORDS_PER_GROUP ((HYDK_TOKENS_PER_GROUP * 46 + 64 + 31) / 32 + 1)
+
+/* Token record (8 bytes) written by the transform kernel and read by the rANS kernel:
+ *   lo: bits 0-7 token, 8-11 preset-local cluster, 16-21 residue bit count;  hi: residue bits. */
+#define HYDK_REC_LO(token, cluster, rbits) ((uint32_t)(token) | ((uint32_t)(cluster) << 8) | ((uint32_t)(rbits) << 16))
+
+/* Per-LF-group ANS coding tables produced by the table kernel, consumed by the rANS kernel. */
+typedef struct HydkTables {
+    uint32_t freq[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];   /* normalised 12-bit frequencies (also read back by the host) */
+    uint32_t fb[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];     /* freq | (cumulative base << 16) */
+    uint32_t magic[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];  /* floor(2^32 / freq) (0xFFFFFFFF for freq 1) */
+    uint16_t inv[HYDK_MAX_CLUSTERS][HYDK_ANS_SLOTS];   /* (symbol, offset) -> alias-table slot, at base+offset */
+    uint32_t alphabet[HYDK_MAX_CLUSTERS];              /* largest token + 1 seen per cluster */
+    uint32_t log_alphabet_size;                        /* max(5, ceil log2 of the running max alphabet) */
+    uint32_t running_max_alphabet;                     /* after this LF group, in send order */
+    uint32_t error;                                    /* non-zero: table construction failed */
+    uint32_t pad;
+} HydkTables;
+
+/* Everything the transform kernel needs to know about one LF group. */
+typedef struct HydkLfJob {
+    const void *src[3];      /* R, G, B sample pointers of the LF group's first pixel (device memory) */
+    long long row_stride;    /* in samples */
+    long long pixel_stride;  /* in samples */
+    int fmt;                 /* HYDK_FMT_* */
+    int linear_light;
+    int width, height;       /* LF group size in pixels */
+    int gcols, grows;        /* groups across / down */
+    int scheme;              /* HF clustering scheme 0..3 = 9 / 3 / 2 / 1 clusters per preset */
+    int use_luts;            /* 1: gather from the uploaded LUTs instead of evaluating them in registers */
+    const uint16_t *in_lut8;   /* 256 entries   */
+    const uint16_t *in_lut16;  /* 65536 entries */
+    const float *bias_lut;     /* 65536 entries */
+    uint64_t *tokens;        /* [groups][HYDK_TOKENS_PER_GROUP] */
+    uint32_t *sym_count;     /* [groups] */
+    uint32_t *hist;          /* [HYDK_MAX_CLUSTERS][HYDK_ALPHABET], zeroed before launch */
+    int32_t *dc;             /* [3][HYDK_DC_PITCH][HYDK_DC_PITCH] LF ints */
+    float *dbg_xyb;          /* optional [3][2048][2048] dumps for parity tests, else NULL */
+    float *dbg_dct;
+    int32_t *dbg_quant;
+} HydkLfJob;
+
+#endif /* HYDK_COMMON_H_ */

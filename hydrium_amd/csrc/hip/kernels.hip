@@ -1,0 +1,930 @@
+/*
+ * kernels.hip — hand-written CDNA4 (gfx950) kernels for hydrium's per-group encode hot path.
+ *
+ *   k_transform_tokenize  one 256x256 group per workgroup, strip-sequential (8 px rows at a time):
+ *                         RGB -> XYB (reference format.c:15-56,85-140), 8x8 forward DCT
+ *                         (encoder.c:631-668), HF quantisation + LF ints (encoder.c:573-582,
+ *                         783-823), tokenisation into hybrid-uint symbols (encoder.c:689-750,
+ *                         entropy.c:427-444) and the per-preset token histogram (entropy.c:526-544).
+ *   k_build_tables        histogram -> 12-bit frequencies -> alias table -> inverse slot table
+ *                         (entropy.c:184-301, 943-978).
+ *   k_rans_encode         one lane per group: the serial reverse rANS chain + bit emission
+ *                         (entropy.c:1064-1159), written back-to-front so no second pass is needed.
+ *   k_scan_sections / k_pack_sections   byte sizes, offsets and packing of the HF sections.
+ *
+ * Arithmetic contract: IEEE binary32, source operation order, NO fused multiply-add — the
+ * reference's canonical bytes are the non-contracted ones.  This file is
+ * compiled with -ffp-contract=off and additionally pins the pragma below.  The 8-point DCT is an
+ * ordered 8-term accumulation, so it runs on the VALU (MFMA would fuse and re-associate).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hydk_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kS0Block = 72;            /* floats per block in the row-pass buffer: 64 + 8 pad -> conflict-free column reads */
+constexpr int kS0Chan = 32 * kS0Block;  /* floats per channel */
+constexpr int kQPitch = 65;             /* ints per (block, channel) row of the quantised buffer */
+constexpr int kDbgPitch = 2048;
+
+/* |cos| magnitudes of the scaled DCT-II as the reference spells them (encoder.c:32-40):
+ * double literals narrowed to float at compile time. */
+constexpr float kA = (float)0.17338, kB = (float)0.146984, kC = (float)0.0982119, kD = (float)0.0344874;
+constexpr float kE = (float)0.16332, kF = (float)0.0676495, kG = (float)0.125;
+
+constexpr float kDct[7][8] = {
+    {kA, kB, kC, kD, -kD, -kC, -kB, -kA},
+    {kE, kF, -kF, -kE, -kE, -kF, kF, kE},
+    {kB, -kD, -kA, -kC, kC, kA, kD, -kB},
+    {kG, -kG, -kG, kG, kG, -kG, -kG, kG},
+    {kC, -kA, kD, kB, -kB, -kD, kA, -kC},
+    {kF, -kE, kE, -kF, -kF, kE, -kE, kF},
+    {kD, -kC, kB, -kA, kA, -kB, kC, -kD},
+};
+
+/* zig-zag index of the coefficient with vertical frequency kv and horizontal frequency kh: the
+ * reference's natural_order[j] = {x = kv, y = kh} (encoder.c:42-51 with the transposed store of
+ * encoder.c:660-664). */
+__device__ const uint8_t kZigzag[8][8] = {
+    /* kv = 0 */ {0, 2, 3, 9, 10, 20, 21, 35},
+    /* kv = 1 */ {1, 4, 8, 11, 19, 22, 34, 36},
+    /* kv = 2 */ {5, 7, 12, 18, 23, 33, 37, 48},
+    /* kv = 3 */ {6, 13, 17, 24, 32, 38, 47, 49},
+    /* kv = 4 */ {14, 16, 25, 31, 39, 46, 50, 57},
+    /* kv = 5 */ {15, 26, 30, 40, 45, 51, 56, 58},
+    /* kv = 6 */ {27, 29, 41, 44, 52, 55, 59, 62},
+    /* kv = 7 */ {28, 42, 43, 53, 54, 60, 61, 63},
+};
+
+/* HF quantisation weights, channel X / Y / B, zig-zag order (encoder.c:74-93) */
+__device__ const int16_t kQuantWeight[3][64] = {
+    {1969, 1969, 1969, 1962, 1969, 1962, 1655, 1885, 1885, 1655, 1397, 1610, 1704, 1610, 1397, 1178,
+     1368, 1494, 1494, 1368, 1178, 994,  1159, 1289, 1340, 1289, 1159, 994,  839,  980,  1104, 1178,
+     1178, 1104, 980,  839,  829,  941,  1023, 1054, 1023, 941,  829,  800,  881,  928,  928,  881,
+     800,  755,  809,  829,  809,  755,  663,  731,  731,  663,  491,  524,  491,  349,  349,  239},
+    {280, 280, 280, 279, 280, 279, 245, 271, 271, 245, 214, 239, 250, 239, 214, 188,
+     211, 226, 226, 211, 188, 164, 185, 201, 207, 201, 185, 164, 144, 163, 178, 188,
+     188, 178, 163, 144, 143, 157, 168, 172, 168, 157, 143, 139, 150, 156, 156, 150,
+     139, 133, 140, 143, 140, 133, 125, 129, 129, 125, 116, 118, 116, 107, 107, 98},
+    {256, 147, 147, 85, 117, 85, 60, 78, 78, 60, 43, 56, 63, 56, 43, 43,
+     43,  48,  48,  43, 43,  42, 43, 43, 43, 43, 43, 42, 29, 41, 43, 43,
+     43,  43,  41,  29, 29,  37, 43, 43, 43, 37, 29, 27, 33, 36, 36, 33,
+     27,  24,  27,  29, 27,  24, 20, 22, 22, 20, 15, 16, 15, 10, 10, 7},
+};
+
+/* coefficient-count context offsets (encoder.c:60-66); all values fit a byte */
+__device__ const uint8_t kNnzCtx[64] = {
+    0,   0,   31,  62,  62,  93,  93,  93,  93,  123, 123, 123, 123, 152, 152, 152, 152, 152, 152, 152, 152, 180,
+    180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206,
+    206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206,
+};
+
+constexpr float kLfShift[3] = {8192.f, 1024.f, 512.f}; /* encoder.c:573 */
+
+/* ------------------------------------------------------------------------------------------
+ * pixel front-end
+ * ---------------------------------------------------------------------------------------- */
+
+constexpr float kUnit16 = 1.0f / (65536 - 1.0f); /* format.c:64,79: 1.0f / (size - 1.0f) */
+
+__device__ __forceinline__ float linearize(float x) { /* format.c:15-19 */
+    if (x <= 0.0404482362771082f)
+        return 0.07739938080495357f * x;
+    return 0.003094300919832f + x * (-0.009982599f + x * (0.72007737769f + 0.2852804880f * x));
+}
+
+__device__ __forceinline__ float bias_curve(float v) { /* format.c:21-31 */
+    const float x = v + 0.0037930732552754493f;
+    float z = __uint_as_float(0x548c39cbu - __float_as_uint(x) / 3u);
+    z *= 1.5015480449f - 0.534850249f * x * z * z * z;
+    z *= 1.333333985f - 0.33333333f * x * z * z * z;
+    return 1.0f / z - 0.155954f; /* correctly rounded division (hipcc default) */
+}
+
+__device__ __forceinline__ uint32_t to_u16(float x) { /* format.c:33-36 */
+    const int y = (int)(x * 65535.f + 0.5f);
+    return (uint32_t)(y < 0 ? 0 : y > 65535 ? 65535 : y);
+}
+
+/* the 65536-entry LUTs of format.c:58-83, evaluated in registers */
+__device__ __forceinline__ uint32_t input_lut16_eval(uint32_t i, int linear_light) {
+    const float f = (float)i * kUnit16;
+    return to_u16(linear_light ? f : linearize(f));
+}
+__device__ __forceinline__ float bias_lut_eval(uint32_t i) { return bias_curve((float)i * kUnit16); }
+
+template <bool LUTS>
+__device__ __forceinline__ void lms_mix_u16(uint32_t r, uint32_t g, uint32_t b, const float *bias_lut, float &X,
+                                            float &Y, float &B) {
+    /* format.c:48-56: 16.16 fixed-point LMS mix, high half indexes the bias LUT */
+    const uint32_t il = (19661u * r + 40761u * g + 5112u * b) >> 16;
+    const uint32_t im = (15073u * r + 45350u * g + 5112u * b) >> 16;
+    const uint32_t is = (15953u * r + 13419u * g + 36163u * b) >> 16;
+    float l, m, s;
+    if (LUTS) {
+        l = bias_lut[il];
+        m = bias_lut[im];
+        s = bias_lut[is];
+    } else {
+        l = bias_lut_eval(il);
+        m = bias_lut_eval(im);
+        s = bias_lut_eval(is);
+    }
+    Y = (l + m) * 0.5f;
+    X = Y - m;
+    B = s - Y;
+}
+
+__device__ __forceinline__ bool lms_mix_f32(float r, float g, float b, int linear_light, float &X, float &Y,
+                                            float &B) {
+    /* format.c:111-140, 38-46 */
+    const bool finite = ((__float_as_uint(r) & 0x7f800000u) != 0x7f800000u) &&
+                        ((__float_as_uint(g) & 0x7f800000u) != 0x7f800000u) &&
+                        ((__float_as_uint(b) & 0x7f800000u) != 0x7f800000u);
+    if (!linear_light) {
+        r = linearize(r);
+        g = linearize(g);
+        b = linearize(b);
+    }
+    const float l = bias_curve(0.3f * r + 0.622f * g + 0.078f * b);
+    const float m = bias_curve(0.23f * r + 0.692f * g + 0.078f * b);
+    const float s = bias_curve(0.243423f * r + 0.204767f * g + 0.55181f * b);
+    Y = (l + m) * 0.5f;
+    X = Y - m;
+    B = s - Y;
+    return finite;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * 8-point DCT in the reference's summation order (encoder.c:639-658)
+ * ---------------------------------------------------------------------------------------- */
+__device__ __forceinline__ void dct8(const float (&x)[8], float (&o)[8]) {
+    float dc = x[0];
+#pragma unroll
+    for (int n = 1; n < 8; n++)
+        dc += x[n];
+    o[0] = dc * 0.125f;
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        /* the reference starts from +0.0f; 0.0f + p differs from p only in the sign of a zero,
+         * which no later stage can observe (every consumer multiplies and truncates to int) */
+        float acc = x[0] * kDct[k - 1][0];
+#pragma unroll
+        for (int n = 1; n < 8; n++)
+            acc += x[n] * kDct[k - 1][n];
+        o[k] = acc;
+    }
+}
+
+__device__ __forceinline__ uint32_t pack_signed(int v) { /* math-functions.h:68-71 */
+    const uint32_t w = (uint32_t)v;
+    return (w << 1) ^ (0u - (w >> 31));
+}
+
+template <int FMT>
+struct SampleOf;
+template <>
+struct SampleOf<HYDK_FMT_U8> {
+    typedef uint8_t type;
+};
+template <>
+struct SampleOf<HYDK_FMT_U16> {
+    typedef uint16_t type;
+};
+template <>
+struct SampleOf<HYDK_FMT_F32> {
+    typedef float type;
+};
+
+} /* namespace */
+
+/* ==========================================================================================
+ * K1: fused transform + tokenise.  grid = groups of the LF group, block = 256 threads (4 waves).
+ * ======================================================================================== */
+template <int FMT, bool LUTS>
+__global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob job, uint32_t *status) {
+    typedef typename SampleOf<FMT>::type sample_t;
+
+    __shared__ float s_rowpass[3 * kS0Chan];          /* [c][block][y][kh], 27.0 KiB */
+    __shared__ int32_t s_quant[96 * kQPitch];         /* [block*3 + c][zig-zag j], 24.4 KiB */
+    __shared__ unsigned long long s_mask[96];         /* non-zero bitmap per (block, c), bit j */
+    __shared__ uint32_t s_off[97];                    /* exclusive symbol offsets per emission slot + total */
+    __shared__ uint32_t s_hist[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
+    __shared__ uint16_t s_lut8[256];
+    __shared__ uint8_t s_nnz[64];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int g = blockIdx.x;
+    const int gx = g % job.gcols, gy = g / job.gcols;
+    const int px0 = gx << 8, py0 = gy << 8;
+    const int gw = min(256, job.width - px0), gh = min(256, job.height - py0);
+    const int gbw = (gw + 7) >> 3, gbh = (gh + 7) >> 3;
+
+    for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads)
+        s_hist[i] = 0;
+    if (FMT == HYDK_FMT_U8)
+        s_lut8[t] = job.in_lut8[t];
+    if (t < 64)
+        s_nnz[t] = kNnzCtx[t];
+
+    /* per-thread constants of the column pass: thread (block cb, horizontal frequency kh) */
+    const int cb = t >> 3, kh = t & 7;
+    int zz[8];
+    float wq[3][8];
+#pragma unroll
+    for (int kv = 0; kv < 8; kv++) {
+        zz[kv] = kZigzag[kv][kh];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            wq[c][kv] = (float)kQuantWeight[c][zz[kv]];
+    }
+    /* per-lane constant of the token phase: frequency context of coefficient j = lane (encoder.c:53-58) */
+    const int freq_ctx = lane < 2 ? 0 : lane < 16 ? lane - 1 : lane < 32 ? 15 + ((lane - 16) >> 1) : 23 + ((lane - 32) >> 2);
+
+    /* clusters holding coefficient contexts, by scheme (encoder.c:862-901) */
+    const int coef_cl_lo = job.scheme == 0 ? 3 : job.scheme == 3 ? 0 : 1;
+    const int coef_cl_hi = job.scheme == 0 ? 8 : job.scheme == 1 ? 2 : job.scheme == 2 ? 1 : 0;
+
+    const bool packed = job.pixel_stride == 3 &&
+                        (const char *)job.src[1] == (const char *)job.src[0] + sizeof(sample_t) &&
+                        (const char *)job.src[2] == (const char *)job.src[0] + 2 * sizeof(sample_t) &&
+                        (((uintptr_t)job.src[0] | (uintptr_t)(job.row_stride * (long long)sizeof(sample_t))) & 3) == 0 &&
+                        FMT != HYDK_FMT_F32;
+
+    uint64_t *const tok = job.tokens + (size_t)g * HYDK_TOKENS_PER_GROUP;
+    uint32_t goff = 0;
+    bool bad_sample = false;
+    __syncthreads();
+
+    for (int s = 0; s < gbh; s++) {
+        /* ---------------- phase A: load 8 px of one block row, XYB, row DCT ---------------- */
+        {
+            const int r = t >> 5, b = t & 31;
+            if (b < gbw) {
+                float xv[8], yv[8], bv[8];
+                const int y = py0 + s * 8 + r;        /* row inside the LF group */
+                const int x0 = px0 + b * 8;
+                const bool row_ok = s * 8 + r < gh;
+                const int nvalid = row_ok ? min(8, gw - b * 8) : 0;
+                if (nvalid == 8 && packed) {
+                    /* 24 interleaved samples = 6 (u8) or 12 (u16) aligned dwords */
+                    constexpr int kWords = FMT == HYDK_FMT_U8 ? 6 : 12;
+                    const uint32_t *p = (const uint32_t *)((const char *)job.src[0] +
+                                                           ((long long)y * job.row_stride + (long long)x0 * 3) *
+                                                               (long long)sizeof(sample_t));
+                    uint32_t w[kWords];
+#pragma unroll
+                    for (int k = 0; k < kWords; k++)
+                        w[k] = p[k];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        uint32_t rgb[3];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            const int si = i * 3 + ch;
+                            if (FMT == HYDK_FMT_U8)
+                                rgb[ch] = s_lut8[(w[si >> 2] >> (8 * (si & 3))) & 0xFF];
+                            else {
+                                const uint32_t v = (w[si >> 1] >> (16 * (si & 1))) & 0xFFFF;
+                                rgb[ch] = LUTS ? job.in_lut16[v] : input_lut16_eval(v, job.linear_light);
+                            }
+                        }
+                        lms_mix_u16<LUTS>(rgb[0], rgb[1], rgb[2], job.bias_lut, xv[i], yv[i], bv[i]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        xv[i] = yv[i] = bv[i] = 0.0f; /* edge padding is XYB = 0 (format.c:182-191) */
+                        if (i < nvalid) {
+                            const long long off = (long long)y * job.row_stride + (long long)(x0 + i) * job.pixel_stride;
+                            const sample_t sr = ((const sample_t *)job.src[0])[off];
+                            const sample_t sg = ((const sample_t *)job.src[1])[off];
+                            const sample_t sb = ((const sample_t *)job.src[2])[off];
+                            if (FMT == HYDK_FMT_F32) {
+                                if (!lms_mix_f32((float)sr, (float)sg, (float)sb, job.linear_light, xv[i], yv[i], bv[i]))
+                                    bad_sample = true;
+                            } else {
+                                uint32_t rgb[3] = {(uint32_t)sr, (uint32_t)sg, (uint32_t)sb};
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++) {
+                                    if (FMT == HYDK_FMT_U8)
+                                        rgb[ch] = s_lut8[rgb[ch]];
+                                    else
+                                        rgb[ch] = LUTS ? job.in_lut16[rgb[ch]] : input_lut16_eval(rgb[ch], job.linear_light);
+                                }
+                                lms_mix_u16<LUTS>(rgb[0], rgb[1], rgb[2], job.bias_lut, xv[i], yv[i], bv[i]);
+                            }
+                        }
+                    }
+                }
+                if (job.dbg_xyb) {
+                    float *d = job.dbg_xyb + (size_t)y * kDbgPitch + x0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        d[i] = xv[i];
+                        d[(size_t)kDbgPitch * kDbgPitch + i] = yv[i];
+                        d[(size_t)2 * kDbgPitch * kDbgPitch + i] = bv[i];
+                    }
+                }
+                float o[8];
+                float *dst = s_rowpass + b * kS0Block + r * 8;
+                dct8(xv, o);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    dst[k] = o[k];
+                dct8(yv, o);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    dst[kS0Chan + k] = o[k];
+                dct8(bv, o);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    dst[2 * kS0Chan + k] = o[k];
+            }
+        }
+        __syncthreads();
+
+        /* ---------------- phase B: column DCT, quantise, LF ints, non-zero bitmap ---------------- */
+        if (cb < gbw) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float col[8], v[8];
+                const float *src = s_rowpass + c * kS0Chan + cb * kS0Block + kh;
+#pragma unroll
+                for (int n = 0; n < 8; n++)
+                    col[n] = src[n * 8];
+                dct8(col, v);
+                /* v[kv] = coefficient with vertical frequency kv, horizontal frequency kh; the
+                 * reference leaves it at block row kh, column kv (encoder.c:660-664) */
+                if (job.dbg_dct) {
+                    float *d = job.dbg_dct + (size_t)c * kDbgPitch * kDbgPitch +
+                               (size_t)(py0 + s * 8 + kh) * kDbgPitch + px0 + cb * 8;
+#pragma unroll
+                    for (int kv = 0; kv < 8; kv++)
+                        d[kv] = v[kv];
+                }
+                unsigned long long m = 0;
+                int32_t *qrow = s_quant + (cb * 3 + c) * kQPitch;
+                int qv[8];
+#pragma unroll
+                for (int kv = 0; kv < 8; kv++) {
+                    /* encoder.c:808-811: trunc((coef * weight) * 5); +-1 is the dead zone */
+                    int q = (int)(v[kv] * wq[c][kv] * 5.0f);
+                    if (q > -2 && q < 2)
+                        q = 0;
+                    if (kv == 0 && kh == 0)
+                        q = 0; /* the DC slot is coded by the LF path */
+                    qv[kv] = q;
+                    qrow[zz[kv]] = q;
+                    m |= (unsigned long long)(q != 0) << zz[kv];
+                }
+                if (job.dbg_quant) {
+                    int32_t *d = job.dbg_quant + (size_t)c * kDbgPitch * kDbgPitch +
+                                 (size_t)(py0 + s * 8 + kh) * kDbgPitch + px0 + cb * 8;
+#pragma unroll
+                    for (int kv = 0; kv < 8; kv++)
+                        d[kv] = qv[kv];
+                }
+                m |= __shfl_xor(m, 1);
+                m |= __shfl_xor(m, 2);
+                m |= __shfl_xor(m, 4);
+                if (kh == 0) {
+                    s_mask[cb * 3 + c] = m;
+                    /* LF int: trunc(dc * shift[c]) (encoder.c:573,582) */
+                    job.dc[(size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH + (size_t)((py0 >> 3) + s) * HYDK_DC_PITCH +
+                           (px0 >> 3) + cb] = (int32_t)(v[0] * kLfShift[c]);
+                }
+            }
+        }
+        __syncthreads();
+
+        /* ---------------- phase C1: symbols per (block, visit) and their offsets ---------------- */
+        if (wave == 0) {
+            /* emission slot e = 3*block + visit, visit order Y, X, B (encoder.c:712) */
+            uint32_t cnt[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int e = lane + 64 * h;
+                cnt[h] = 0;
+                if (e < 3 * gbw) {
+                    const int b = e / 3, visit = e - 3 * b;
+                    const int c = visit < 2 ? 1 - visit : 2;
+                    const unsigned long long m = s_mask[b * 3 + c];
+                    cnt[h] = 1 + (m ? 63 - __clzll(m) : 0); /* count symbol + coefficients up to the last non-zero */
+                }
+            }
+            uint32_t inc0 = cnt[0], inc1 = cnt[1];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t a = __shfl_up(inc0, d), b2 = __shfl_up(inc1, d);
+                if (lane >= d) {
+                    inc0 += a;
+                    inc1 += b2;
+                }
+            }
+            const uint32_t total0 = __shfl(inc0, 63);
+            s_off[lane] = inc0 - cnt[0];
+            if (lane < 32)
+                s_off[64 + lane] = total0 + inc1 - cnt[1];
+            if (lane == 31)
+                s_off[96] = total0 + inc1;
+        }
+        __syncthreads();
+
+        /* ---------------- phase C2: one wave per (block, visit), lane j = zig-zag coefficient j ---------------- */
+        for (int e = wave; e < 3 * gbw; e += 4) {
+            const int b = e / 3, visit = e - 3 * b;
+            const int c = visit < 2 ? 1 - visit : 2;
+            const unsigned long long m = s_mask[b * 3 + c];
+            const int nz_total = __popcll(m);
+            const int jlast = m ? 63 - __clzll(m) : 0;
+            const int j = lane;
+            const bool active = j <= jlast;
+            uint32_t value;
+            int cluster;
+            if (j == 0) {
+                /* non-zero count; its context only matters through the cluster, which depends on
+                 * the visit index alone in every scheme (encoder.c:715,865-869,882,895,900) */
+                value = (uint32_t)nz_total;
+                cluster = job.scheme == 0 ? visit : 0;
+            } else {
+                const int q = active ? s_quant[(b * 3 + c) * kQPitch + j] : 0;
+                value = pack_signed(q);
+                /* non-zeros still to come before this coefficient (encoder.c:732,738) */
+                const int remaining = nz_total - __popcll(m & ((1ull << j) - 1ull));
+                const int prev = j == 1 ? (nz_total <= 4) : (int)((m >> (j - 1)) & 1ull);
+                /* context - 111 = 458*visit + prev + 2*(nnz_ctx[remaining] + freq_ctx[j]) (encoder.c:724,731-732) */
+                const int x = 458 * visit + prev + 2 * ((int)s_nnz[remaining & 63] + freq_ctx);
+                cluster = job.scheme == 0 ? 3 + x % 6 : job.scheme == 1 ? 1 + (x & 1) : job.scheme == 2 ? 1 : 0;
+            }
+            /* hybrid-uint split, config (4,1,0) (entropy.c:427-444) */
+            uint32_t token, rbits, residue;
+            if (value < 16) {
+                token = value;
+                rbits = 0;
+                residue = 0;
+            } else {
+                const int n = 30 - __clz((int)value); /* floor(log2) - 1 */
+                rbits = (uint32_t)n;
+                residue = value & ((1u << n) - 1u);
+                token = 16u + (((uint32_t)(n - 3) << 1) | ((value >> n) & 1u));
+            }
+            if (active)
+                tok[goff + s_off[e] + j] = ((uint64_t)residue << 32) | HYDK_REC_LO(token, cluster, rbits);
+
+            /* histogram: zero tokens of coefficient lanes are counted per cluster with one ballot
+             * each (they dominate and would serialise as same-address LDS atomics) */
+            const bool zero_coef = active && j > 0 && token == 0;
+            for (int cl = coef_cl_lo; cl <= coef_cl_hi; cl++) {
+                const unsigned long long bm = __ballot(zero_coef && cluster == cl);
+                if (lane == 0 && bm)
+                    atomicAdd(&s_hist[cl * HYDK_ALPHABET], (uint32_t)__popcll(bm));
+            }
+            if (active && !zero_coef)
+                atomicAdd(&s_hist[cluster * HYDK_ALPHABET + token], 1u);
+        }
+        goff += s_off[96];
+        __syncthreads();
+    }
+
+    for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads) {
+        const uint32_t v = s_hist[i];
+        if (v)
+            atomicAdd(&job.hist[i], v);
+    }
+    if (t == 0)
+        job.sym_count[g] = goff;
+    if (FMT == HYDK_FMT_F32 && bad_sample)
+        atomicOr(status, 1u);
+}
+
+/* ==========================================================================================
+ * K2: per-LF-group ANS tables.  grid = 1, block = 256.
+ * ======================================================================================== */
+__global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist, HydkTables *tab, uint32_t *running_max,
+                                                           int nclusters) {
+    __shared__ uint32_t s_freq[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
+    __shared__ uint32_t s_cutoff[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
+    __shared__ uint32_t s_other[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
+    __shared__ uint32_t s_shift[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
+    __shared__ uint32_t s_base[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
+    __shared__ uint8_t s_under[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
+    __shared__ uint8_t s_over[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
+    __shared__ uint32_t s_alpha[HYDK_MAX_CLUSTERS];
+    __shared__ uint32_t s_log_alpha, s_err;
+
+    const int t = threadIdx.x;
+    for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads) {
+        (&s_freq[0][0])[i] = hist[i];
+        (&s_cutoff[0][0])[i] = 0;
+        (&s_other[0][0])[i] = 0;
+        (&s_shift[0][0])[i] = 0;
+        (&s_base[0][0])[i] = 0;
+    }
+    if (t == 0)
+        s_err = 0;
+    __syncthreads();
+
+    if (t < HYDK_MAX_CLUSTERS) {
+        uint32_t a = 0;
+        if (t < nclusters)
+            for (int k = 0; k < HYDK_ALPHABET; k++)
+                if (s_freq[t][k])
+                    a = k + 1;
+        s_alpha[t] = a;
+    }
+    __syncthreads();
+    if (t == 0) {
+        /* the stream-wide alphabet maximum is never reset between LF groups (entropy.c:459-460,952) */
+        uint32_t mx = *running_max;
+        for (int c = 0; c < nclusters; c++)
+            mx = max(mx, s_alpha[c]);
+        *running_max = mx;
+        uint32_t lg = mx > 1 ? 32 - __clz((int)(mx - 1)) : 0; /* ceil(log2(mx)) */
+        s_log_alpha = max(lg, 5u);
+        tab->running_max_alphabet = mx;
+    }
+    __syncthreads();
+    const int log_alpha = (int)s_log_alpha;
+    const int log_bucket = 12 - log_alpha;
+    const uint32_t bucket = 1u << log_bucket, table_size = 1u << log_alpha;
+
+    if (t < nclusters && s_alpha[t]) {
+        uint32_t *f = s_freq[t];
+        const uint32_t n = s_alpha[t];
+        /* ---- 12-bit normalisation (entropy.c:267-301) ---- */
+        unsigned long long total = 0;
+        for (uint32_t k = 0; k < n; k++)
+            total += f[k];
+        unsigned long long scaled = 0;
+        for (uint32_t k = 0; k < n; k++) {
+            if (!f[k])
+                continue;
+            uint32_t v = (uint32_t)((((unsigned long long)f[k] << 12) / total) & 0xFFFFu);
+            if (!v)
+                v = 1;
+            f[k] = v;
+            scaled += v;
+        }
+        int j = (int)n - 1;
+        while (scaled > 4096 && j >= 0) {
+            const unsigned long long excess = scaled - 4096;
+            if (excess < f[j]) {
+                f[j] -= (uint32_t)excess;
+                scaled -= excess;
+                break;
+            } else if (f[j] > 1) {
+                scaled -= f[j] - 1;
+                f[j] = 1;
+            }
+            j--;
+        }
+        f[0] += (uint32_t)(4096 - scaled);
+        const bool unique = f[n - 1] == 4096;
+
+        /* ---- alias table (entropy.c:184-242) ---- */
+        uint32_t *cutoff = s_cutoff[t], *other = s_other[t], *shift = s_shift[t];
+        if (unique) {
+            for (uint32_t i = 0; i < table_size; i++) {
+                other[i] = n - 1;
+                shift[i] = i * bucket;
+            }
+        } else {
+            uint8_t *under = s_under[t], *over = s_over[t];
+            uint32_t nu = 0, no = 0;
+            for (uint32_t sidx = 0; sidx < n; sidx++) {
+                cutoff[sidx] = f[sidx];
+                if (f[sidx] < bucket)
+                    under[nu++] = (uint8_t)sidx;
+                else if (f[sidx] > bucket)
+                    over[no++] = (uint8_t)sidx;
+            }
+            for (uint32_t sidx = n; sidx < table_size; sidx++)
+                under[nu++] = (uint8_t)sidx;
+            while (no) {
+                if (!nu) {
+                    s_err = 1;
+                    break;
+                }
+                const uint32_t u = under[--nu], o = over[--no];
+                const uint32_t moved = bucket - cutoff[u];
+                cutoff[o] -= moved;
+                shift[u] = cutoff[o];
+                other[u] = o;
+                if (cutoff[o] < bucket)
+                    under[nu++] = (uint8_t)o;
+                else if (cutoff[o] > bucket)
+                    over[no++] = (uint8_t)o;
+            }
+            for (uint32_t i = 0; i < table_size; i++) {
+                if (cutoff[i] == bucket) {
+                    other[i] = i;
+                    cutoff[i] = shift[i] = 0;
+                } else {
+                    shift[i] -= cutoff[i];
+                }
+            }
+        }
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < HYDK_ALPHABET; k++) {
+            s_base[t][k] = run;
+            run += k < n ? f[k] : 0;
+        }
+    }
+    __syncthreads();
+
+    /* ---- inverse slot table: evaluate the decoder-direction alias map for every slot; it is a
+     * bijection onto (symbol, offset < freq), which is what the reference's per-symbol search
+     * (entropy.c:1104-1113) inverts ---- */
+    for (int idx = t; idx < nclusters * HYDK_ANS_SLOTS; idx += kThreads) {
+        const int c = idx >> 12;
+        const uint32_t slot = idx & (HYDK_ANS_SLOTS - 1);
+        if (!s_alpha[c])
+            continue;
+        const uint32_t i = slot >> log_bucket, pos = slot & (bucket - 1);
+        uint32_t sym, off;
+        if (pos >= s_cutoff[c][i]) {
+            sym = s_other[c][i];
+            off = s_shift[c][i] + pos;
+        } else {
+            sym = i;
+            off = pos;
+        }
+        if (sym >= HYDK_ALPHABET || off >= s_freq[c][sym]) {
+            s_err = 2;
+            continue;
+        }
+        tab->inv[c][s_base[c][sym] + off] = (uint16_t)slot;
+    }
+    for (int idx = t; idx < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; idx += kThreads) {
+        const int c = idx / HYDK_ALPHABET, k = idx % HYDK_ALPHABET;
+        const bool live = c < nclusters && s_alpha[c] != 0;
+        const uint32_t f = live ? s_freq[c][k] : 0;
+        tab->freq[c][k] = f;
+        tab->fb[c][k] = f | (s_base[c][k] << 16);
+        tab->magic[c][k] = f <= 1 ? 0xFFFFFFFFu : (uint32_t)(0x100000000ull / f);
+    }
+    __syncthreads();
+    if (t < HYDK_MAX_CLUSTERS)
+        tab->alphabet[t] = s_alpha[t];
+    if (t == 0) {
+        tab->log_alphabet_size = s_log_alpha;
+        tab->error = s_err;
+    }
+}
+
+/* ==========================================================================================
+ * K3a: reverse rANS, one lane per group (<= 64 groups of an LF group share one preset's tables).
+ * The chain state -> state is strictly serial per group (entropy.c:1092-1119); lanes run 64
+ * chains in lock-step.  Bits are prepended into a per-group buffer filled from its end, so the
+ * forward order [state][refill_p][residue_p]... of entropy.c:1127-1147 falls out of the reverse
+ * walk with no replay pass.
+ * ======================================================================================== */
+__global__ __launch_bounds__(64) void k_rans_encode(const uint64_t *tokens, const uint32_t *sym_count,
+                                                    const HydkTables *tab, uint32_t *bitbuf, uint32_t *group_bits,
+                                                    int num_groups, uint32_t preset, int preset_bits) {
+    __shared__ uint16_t s_inv[HYDK_MAX_CLUSTERS * HYDK_ANS_SLOTS];   /* 72 KiB */
+    __shared__ uint32_t s_fb[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
+    __shared__ uint32_t s_magic[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
+
+    const int lane = threadIdx.x;
+    {
+        const uint32_t *src = (const uint32_t *)&tab->inv[0][0];
+        uint32_t *dst = (uint32_t *)s_inv;
+        for (int i = lane; i < HYDK_MAX_CLUSTERS * HYDK_ANS_SLOTS / 2; i += 64)
+            dst[i] = src[i];
+        for (int i = lane; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += 64) {
+            s_fb[i] = (&tab->fb[0][0])[i];
+            s_magic[i] = (&tab->magic[0][0])[i];
+        }
+    }
+    __syncthreads();
+
+    const bool live = lane < num_groups;
+    const int n = live ? (int)sym_count[lane] : 0;
+    const uint64_t *tok = tokens + (size_t)lane * HYDK_TOKENS_PER_GROUP;
+    uint32_t *W = bitbuf + (size_t)lane * HYDK_BITWORDS_PER_GROUP;
+    int widx = HYDK_BITWORDS_PER_GROUP; /* next word goes to W[--widx] */
+    unsigned long long acc = 0;         /* pending bits, bit 0 = earliest stream position */
+    int nb = 0;
+    uint32_t state = 0x130000u;
+
+    int nmax = n;
+#pragma unroll
+    for (int d = 32; d; d >>= 1)
+        nmax = max(nmax, __shfl_xor(nmax, d));
+
+#define HYDK_PREPEND(val, nbits)                                   \
+    do {                                                           \
+        acc = (acc << (nbits)) | (unsigned long long)(val);        \
+        nb += (nbits);                                             \
+        if (nb >= 32) {                                            \
+            nb -= 32;                                              \
+            W[--widx] = (uint32_t)(acc >> nb);                     \
+            acc &= (1ull << nb) - 1ull;                            \
+        }                                                          \
+    } while (0)
+
+    constexpr int kChunk = 8;
+    uint64_t cur[kChunk];
+#pragma unroll
+    for (int k = 0; k < kChunk; k++) {
+        const int p = n - 1 - k;
+        cur[k] = p >= 0 ? tok[p] : 0;
+    }
+    for (int i0 = 0; i0 < nmax; i0 += kChunk) {
+        uint64_t nxt[kChunk];
+        uint32_t fb[kChunk], mg[kChunk];
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) {
+            const int p = n - 1 - (i0 + kChunk + k);
+            nxt[k] = p >= 0 ? tok[p] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) {
+            const uint32_t lo = (uint32_t)cur[k];
+            const uint32_t e = ((lo >> 8) & 0xF) * HYDK_ALPHABET + (lo & 0xFF);
+            fb[k] = s_fb[e];
+            mg[k] = s_magic[e];
+        }
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) {
+            if (i0 + k < n) {
+                const uint32_t lo = (uint32_t)cur[k];
+                const uint32_t residue = (uint32_t)(cur[k] >> 32);
+                const int rbits = (int)((lo >> 16) & 0x3F);
+                const uint32_t f = fb[k] & 0xFFFF, base = fb[k] >> 16;
+                const uint32_t cl = (lo >> 8) & 0xF;
+                /* residue p sits after refill p in the stream, so it is prepended first */
+                if (rbits)
+                    HYDK_PREPEND(residue, rbits);
+                uint32_t x = state;
+                if ((state >> 20) >= f) {
+                    HYDK_PREPEND(state & 0xFFFFu, 16);
+                    x = state >> 16;
+                }
+                /* exact x / f: q' = mulhi(x, floor(2^32/f)) is q or q-1 for x < 2^32 */
+                uint32_t q = __umulhi(x, mg[k]);
+                uint32_t r = x - q * f;
+                if (r >= f) {
+                    r -= f;
+                    q += 1;
+                }
+                const uint32_t slot = s_inv[cl * HYDK_ANS_SLOTS + base + r];
+                state = (q << 12) | slot;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kChunk; k++)
+            cur[k] = nxt[k];
+    }
+
+    if (live) {
+        if (n > 0)
+            HYDK_PREPEND(state, 32); /* low half first, then high half (entropy.c:1127-1130) */
+        if (preset_bits)
+            HYDK_PREPEND(preset, preset_bits); /* encoder.c:945 */
+        uint32_t total = (uint32_t)(HYDK_BITWORDS_PER_GROUP - widx) * 32u + (uint32_t)nb;
+        if (nb)
+            W[--widx] = (uint32_t)(acc << (32 - nb));
+        group_bits[lane] = total;
+    } else {
+        group_bits[lane] = 0;
+    }
+#undef HYDK_PREPEND
+}
+
+/* ==========================================================================================
+ * K3b: section sizes -> offsets (single block), then pack each section to its byte offset.
+ * Sections are byte-padded with zeros, as hyd_bitwriter_flush does (bitwriter.c:144-150).
+ * ======================================================================================== */
+__global__ __launch_bounds__(1024) void k_scan_sections(const uint32_t *group_bits, int count, uint64_t *offsets,
+                                                        uint64_t *total) {
+    __shared__ uint64_t s_part[1024];
+    const int t = threadIdx.x;
+    const int per = (count + 1023) / 1024;
+    uint64_t sum = 0;
+    for (int i = t * per; i < min(count, (t + 1) * per); i++)
+        sum += (group_bits[i] + 7u) >> 3;
+    s_part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint64_t v = t >= d ? s_part[t - d] : 0;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = s_part[t] - sum;
+    for (int i = t * per; i < min(count, (t + 1) * per); i++) {
+        offsets[i] = run;
+        run += (group_bits[i] + 7u) >> 3;
+    }
+    if (t == 1023)
+        *total = s_part[1023];
+}
+
+__global__ __launch_bounds__(kThreads) void k_pack_sections(const uint32_t *bitbuf, const uint32_t *group_bits,
+                                                            const uint64_t *offsets, uint8_t *payload) {
+    const int G = blockIdx.x;
+    const uint32_t bits = group_bits[G];
+    if (!bits)
+        return;
+    const uint32_t nbytes = (bits + 7u) >> 3;
+    const uint32_t *W = bitbuf + (size_t)G * HYDK_BITWORDS_PER_GROUP;
+    const uint32_t start = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u - bits;
+    const uint32_t sw = start >> 5, sh = start & 31u;
+    uint8_t *dst = payload + offsets[G];
+    for (uint32_t k = threadIdx.x; k * 4u < nbytes; k += kThreads) {
+        const uint32_t w0 = W[sw + k];
+        const uint32_t w1 = sw + k + 1 < (uint32_t)HYDK_BITWORDS_PER_GROUP ? W[sw + k + 1] : 0u;
+        const uint32_t v = sh ? (w0 >> sh) | (w1 << (32u - sh)) : w0;
+        const uint32_t lim = min(4u, nbytes - k * 4u);
+        for (uint32_t bidx = 0; bidx < lim; bidx++)
+            dst[k * 4u + bidx] = (uint8_t)(v >> (8u * bidx));
+    }
+}
+
+/* ==========================================================================================
+ * Self-test: do the register evaluations of the format.c LUTs reproduce the host-built tables
+ * bit for bit?  (If not, the launcher keeps the exact LUT-gather variant of K1.)
+ * ======================================================================================== */
+__global__ void k_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, int linear_light, uint32_t *mismatches) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 65536)
+        return;
+    uint32_t bad = 0;
+    if (input_lut16_eval(i, linear_light) != in_lut16[i])
+        bad++;
+    if (__float_as_uint(bias_lut_eval(i)) != __float_as_uint(bias_lut[i]))
+        bad++;
+    if (bad)
+        atomicAdd(mismatches, bad);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * launch helpers (C++ linkage, used by device_api.hip)
+ * ---------------------------------------------------------------------------------------- */
+namespace hydk {
+
+hipError_t launch_transform(const HydkLfJob &job, uint32_t *status, hipStream_t stream) {
+    const dim3 grid(job.gcols * job.grows), block(kThreads);
+    const bool luts = job.use_luts != 0;
+    switch (job.fmt) {
+    case HYDK_FMT_U8:
+        if (luts)
+            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U8, true>), grid, block, 0, stream, job, status);
+        else
+            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U8, false>), grid, block, 0, stream, job, status);
+        break;
+    case HYDK_FMT_U16:
+        if (luts)
+            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U16, true>), grid, block, 0, stream, job, status);
+        else
+            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U16, false>), grid, block, 0, stream, job, status);
+        break;
+    case HYDK_FMT_F32:
+        hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_F32, false>), grid, block, 0, stream, job, status);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_tables(const uint32_t *hist, HydkTables *tab, uint32_t *running_max, int nclusters, hipStream_t stream) {
+    hipLaunchKernelGGL(k_build_tables, dim3(1), dim3(kThreads), 0, stream, hist, tab, running_max, nclusters);
+    return hipGetLastError();
+}
+
+hipError_t launch_rans(const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tab, uint32_t *bitbuf,
+                       uint32_t *group_bits, int num_groups, uint32_t preset, int preset_bits, hipStream_t stream) {
+    hipLaunchKernelGGL(k_rans_encode, dim3(1), dim3(64), 0, stream, tokens, sym_count, tab, bitbuf, group_bits,
+                       num_groups, preset, preset_bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, hipStream_t stream) {
+    hipLaunchKernelGGL(k_scan_sections, dim3(1), dim3(1024), 0, stream, group_bits, count, offsets, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
+                       int count, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pack_sections, dim3(count), dim3(kThreads), 0, stream, bitbuf, group_bits, offsets, payload);
+    return hipGetLastError();
+}
+
+hipError_t launch_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, int linear_light, uint32_t *mismatches,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(k_lut_selftest, dim3(256), dim3(256), 0, stream, in_lut16, bias_lut, linear_light, mismatches);
+    return hipGetLastError();
+}
+
+} /* namespace hydk */

@@ -1,0 +1,232 @@
+"""ctypes binding of the additive device-level C-ABI (include/hydrium_amd.h).
+
+This is plumbing for tests, ``bench.py`` and the multi-GPU driver: it hands raw device pointers
+(from torch tensors) to the HIP hot path and reads results back.  There is no CPU fallback — if the
+library or a GPU is missing, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import api
+
+MAX_CLUSTERS = 9
+ALPHABET = 128
+GROUPS_PER_LFG = 64
+K_NAMES = ("transform_tokenize", "build_tables", "rans_encode", "pack_sections")
+
+FMT_OF_DTYPE = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.float32): 2}
+
+
+class DeviceError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"hydamd error {code}: {msg}")
+        self.code = code
+        self.message = msg
+
+
+_dll = None
+
+
+def dll(path: Optional[str] = None):
+    global _dll
+    if _dll is None or path is not None:
+        p = path or api.DEFAULT_LIB
+        if not os.path.exists(p):
+            raise FileNotFoundError(f"{p} missing: the HIP extension is not built (there is no CPU fallback)")
+        d = C.CDLL(p)
+        vp, i, u, sz = C.c_void_p, C.c_int, C.c_uint, C.c_size_t
+        d.hydamd_device_count.restype = i
+        d.hydamd_create.restype = vp
+        d.hydamd_create.argtypes = [i, i, i, i, C.POINTER(i)]
+        d.hydamd_destroy.argtypes = [vp]
+        d.hydamd_error.restype = C.c_char_p
+        d.hydamd_error.argtypes = [vp]
+        d.hydamd_set_stream.argtypes = [vp, vp]
+        d.hydamd_get_stream.restype = vp
+        d.hydamd_get_stream.argtypes = [vp]
+        d.hydamd_uses_register_luts.argtypes = [vp]
+        d.hydamd_force_luts.argtypes = [vp, i]
+        d.hydamd_begin_frame.argtypes = [vp, u]
+        lf_args = [vp, i, C.POINTER(vp), C.c_ssize_t, C.c_ssize_t, i, sz, sz, u]
+        d.hydamd_encode_lf_group.argtypes = lf_args
+        d.hydamd_encode_lf_group_host.argtypes = lf_args
+        d.hydamd_finish_frame.argtypes = [vp, i]
+        d.hydamd_sync.argtypes = [vp]
+        d.hydamd_payload_size.restype = sz
+        d.hydamd_payload_size.argtypes = [vp]
+        d.hydamd_payload_device.restype = vp
+        d.hydamd_payload_device.argtypes = [vp]
+        d.hydamd_read_payload.argtypes = [vp, vp, sz]
+        d.hydamd_read_sections.argtypes = [vp, i, vp, vp]
+        d.hydamd_read_tables.argtypes = [vp, i, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        d.hydamd_read_dc.argtypes = [vp, i, vp, sz, sz]
+        d.hydamd_read_symbol_counts.argtypes = [vp, i, vp]
+        d.hydamd_read_tokens.argtypes = [vp, i, i, vp, sz]
+        d.hydamd_read_debug_plane.argtypes = [vp, i, vp, sz, sz]
+        d.hydamd_profile.argtypes = [vp, i]
+        d.hydamd_profile_read.argtypes = [vp, vp, vp]
+        if path is not None:
+            return d
+        _dll = d
+    return _dll
+
+
+class DeviceContext:
+    """One HydAmdContext: one GPU, one stream, ``max_lf_groups`` LF-group slots."""
+
+    def __init__(self, device: int = 0, max_lf_groups: int = 1, linear_light: int = 0, debug_planes: bool = False):
+        self.d = dll()
+        st = C.c_int(0)
+        self.h = self.d.hydamd_create(device, max_lf_groups, linear_light, int(debug_planes), C.byref(st))
+        if not self.h:
+            raise DeviceError(st.value, (self.d.hydamd_error(None) or b"").decode())
+        self.max_lf_groups = max_lf_groups
+
+    def close(self):
+        if self.h:
+            self.d.hydamd_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, code: int) -> int:
+        if code != 0:
+            raise DeviceError(code, (self.d.hydamd_error(self.h) or b"").decode())
+        return code
+
+    # -- control ---------------------------------------------------------------------------------
+    def set_stream(self, stream_ptr: Optional[int]):
+        self._ck(self.d.hydamd_set_stream(self.h, stream_ptr))
+
+    def get_stream(self) -> int:
+        return self.d.hydamd_get_stream(self.h) or 0
+
+    def uses_register_luts(self) -> bool:
+        return bool(self.d.hydamd_uses_register_luts(self.h))
+
+    def force_luts(self, use_luts: bool):
+        self._ck(self.d.hydamd_force_luts(self.h, int(use_luts)))
+
+    def begin_frame(self, num_presets: int):
+        self._ck(self.d.hydamd_begin_frame(self.h, num_presets))
+
+    def encode_lf_group(self, slot: int, ptrs: Sequence[int], row_stride: int, pixel_stride: int, fmt: int,
+                        width: int, height: int, preset: int, host: bool = False):
+        arr = (C.c_void_p * 3)(*ptrs)
+        fn = self.d.hydamd_encode_lf_group_host if host else self.d.hydamd_encode_lf_group
+        self._ck(fn(self.h, slot, arr, row_stride, pixel_stride, fmt, width, height, preset))
+
+    def finish_frame(self, num_slots: int):
+        self._ck(self.d.hydamd_finish_frame(self.h, num_slots))
+
+    def sync(self):
+        self._ck(self.d.hydamd_sync(self.h))
+
+    # -- whole-image helpers -----------------------------------------------------------------------
+    def encode_image_tensor(self, img, num_slots_check: bool = True):
+        """Enqueue the hot path for every LF group of an interleaved (H, W, 3) torch CUDA tensor."""
+        h, w, _ = img.shape
+        isz = img.element_size()
+        fmt = {1: 0, 2: 1, 4: 2}[isz]
+        lfx, lfy = -(-w // 2048), -(-h // 2048)
+        n = lfx * lfy
+        if num_slots_check and n > self.max_lf_groups:
+            raise ValueError("context has too few LF-group slots for this image")
+        self.begin_frame(n)
+        base = img.data_ptr()
+        for ty in range(lfy):
+            for tx in range(lfx):
+                x0, y0 = tx * 2048, ty * 2048
+                p = base + (y0 * w + x0) * 3 * isz
+                self.encode_lf_group(ty * lfx + tx, [p, p + isz, p + 2 * isz], 3 * w, 3, fmt,
+                                     min(2048, w - x0), min(2048, h - y0), ty * lfx + tx)
+        self.finish_frame(n)
+        return n
+
+    def encode_image_host(self, img: np.ndarray):
+        """Same from a host numpy image, through the pinned staging path."""
+        h, w, _ = img.shape
+        isz = img.dtype.itemsize
+        fmt = FMT_OF_DTYPE[img.dtype]
+        lfx, lfy = -(-w // 2048), -(-h // 2048)
+        n = lfx * lfy
+        self.begin_frame(n)
+        base = img.ctypes.data
+        for ty in range(lfy):
+            for tx in range(lfx):
+                x0, y0 = tx * 2048, ty * 2048
+                p = base + (y0 * w + x0) * 3 * isz
+                self.encode_lf_group(ty * lfx + tx, [p, p + isz, p + 2 * isz], 3 * w, 3, fmt,
+                                     min(2048, w - x0), min(2048, h - y0), ty * lfx + tx, host=True)
+        self.finish_frame(n)
+        return n
+
+    # -- results -----------------------------------------------------------------------------------
+    def payload_size(self) -> int:
+        return self.d.hydamd_payload_size(self.h)
+
+    def payload_device_ptr(self) -> int:
+        return self.d.hydamd_payload_device(self.h) or 0
+
+    def read_payload(self) -> bytes:
+        n = self.payload_size()
+        buf = np.zeros(max(n, 1), np.uint8)
+        self._ck(self.d.hydamd_read_payload(self.h, buf.ctypes.data, n))
+        return buf[:n].tobytes()
+
+    def read_sections(self, slot: int):
+        bits = np.zeros(GROUPS_PER_LFG, np.uint32)
+        offs = np.zeros(GROUPS_PER_LFG, np.uint64)
+        self._ck(self.d.hydamd_read_sections(self.h, slot, bits.ctypes.data, offs.ctypes.data))
+        return bits.astype(np.int64), offs.astype(np.int64)
+
+    def read_tables(self, slot: int):
+        freq = np.zeros((MAX_CLUSTERS, ALPHABET), np.uint32)
+        alpha = np.zeros(MAX_CLUSTERS, np.uint32)
+        la, rm = C.c_uint32(0), C.c_uint32(0)
+        self._ck(self.d.hydamd_read_tables(self.h, slot, freq.ctypes.data, alpha.ctypes.data, C.byref(la), C.byref(rm)))
+        return freq, alpha.astype(np.int64), la.value, rm.value
+
+    def read_dc(self, slot: int, vbw: int, vbh: int) -> np.ndarray:
+        out = np.zeros((3, vbh, vbw), np.int32)
+        self._ck(self.d.hydamd_read_dc(self.h, slot, out.ctypes.data, vbw, vbh))
+        return out
+
+    def read_symbol_counts(self, slot: int) -> np.ndarray:
+        out = np.zeros(GROUPS_PER_LFG, np.uint32)
+        self._ck(self.d.hydamd_read_symbol_counts(self.h, slot, out.ctypes.data))
+        return out.astype(np.int64)
+
+    def read_tokens(self, slot: int, group: int, count: int) -> np.ndarray:
+        out = np.zeros(max(count, 1), np.uint64)
+        self._ck(self.d.hydamd_read_tokens(self.h, slot, group, out.ctypes.data, count))
+        return out[:count]
+
+    def read_debug_plane(self, which: int, pitch: int, rows: int) -> np.ndarray:
+        out = np.zeros((3, rows, pitch), np.int32 if which == 2 else np.float32)
+        self._ck(self.d.hydamd_read_debug_plane(self.h, which, out.ctypes.data, pitch, rows))
+        return out
+
+    def profile(self, enable: bool):
+        self._ck(self.d.hydamd_profile(self.h, int(enable)))
+
+    def profile_read(self):
+        ms = (C.c_double * 4)()
+        n = (C.c_uint64 * 4)()
+        self._ck(self.d.hydamd_profile_read(self.h, ms, n))
+        return {K_NAMES[i]: (ms[i], n[i]) for i in range(4)}
+
+
+def decode_token_records(rec: np.ndarray):
+    """Split device token records into (token, local cluster, residue_bits, residue) arrays."""
+    lo = (rec & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    return lo & 0xFF, (lo >> 8) & 0xF, (lo >> 16) & 0x3F, (rec >> np.uint64(32)).astype(np.uint32)

@@ -1,0 +1,127 @@
+/*
+ * hydrium_amd.h — additive C-ABI of the MI355X build of libhydrium (not present in the reference).
+ *
+ * The drop-in boundary is include/libhydrium/libhydrium.h (the reference's nine hyd_* functions).
+ * The functions below expose the layer underneath it — the HIP hot path of one LF group at a
+ * time — so that callers which already hold pixels in HBM (bench.py, multi-GPU sharding, a video
+ * pipeline) can skip the host-pointer API the reference's hyd_send_tile imposes
+ * (reference src/include/libhydrium/libhydrium.h:260-262, SURVEY.md §8b "additive extension").
+ *
+ * One HydAmdContext drives one GPU through one HIP stream.  All calls are asynchronous with
+ * respect to the GPU unless stated; hydamd_sync() is the only blocking point.  Plain pointers and
+ * sizes only: no C++ or torch types cross this boundary.
+ *
+ * What each call replaces in the reference (file:line relative to /root/reference/src/libhydrium/):
+ *   hydamd_encode_lf_group*   hyd_populate_xyb_buffer (format.c:142), forward_dct (encoder.c:631),
+ *                             the HF quantiser (encoder.c:783-823), the LF ints of write_lf_group
+ *                             (encoder.c:573,582), initialize_hf_coeffs (encoder.c:689),
+ *                             hyd_ans_prepare_frequencies (entropy.c:943) and the per-group
+ *                             hyd_ans_write_stream_symbols loop (encoder.c:940-950, entropy.c:1064)
+ *   hydamd_finish_frame       the byte-padding + concatenation of encoder.c:973-981
+ */
+#ifndef HYDRIUM_AMD_H_
+#define HYDRIUM_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__) || defined(__clang__)
+#define HYDAMD_EXPORT __attribute__((visibility("default")))
+#else
+#define HYDAMD_EXPORT
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HYDAMD_MAX_CLUSTERS 9      /* clusters owned by one preset */
+#define HYDAMD_ALPHABET 128        /* row pitch of the frequency tables */
+#define HYDAMD_GROUPS_PER_LFG 64   /* group slots per LF group (8 x 8) */
+#define HYDAMD_MAX_LF_GROUPS 255   /* the reference cannot code 256 presets (entropy.c:99) */
+
+typedef struct HydAmdContext HydAmdContext;
+
+/* Kernel classes timed by the optional profiler. */
+enum { HYDAMD_K_TRANSFORM = 0, HYDAMD_K_TABLES = 1, HYDAMD_K_RANS = 2, HYDAMD_K_PACK = 3, HYDAMD_K_COUNT = 4 };
+
+/* Number of usable HIP devices (0 when there is none; never fails). */
+HYDAMD_EXPORT int hydamd_device_count(void);
+
+/*
+ * Create a context on `device` with room for `max_lf_groups` LF groups in flight (one frame's
+ * worth: every LF group of a one-frame image, or 1 for tile mode).  `linear_light` selects the
+ * input transfer LUTs (HYDImageMetadata.linear_light).  `debug_planes` != 0 additionally
+ * allocates the XYB / DCT / quantised dump planes used by the parity tests.
+ * Returns NULL on failure; *status (if non-NULL) receives a HYDStatusCode-compatible value and
+ * hydamd_error(NULL) a description.
+ */
+HYDAMD_EXPORT HydAmdContext *hydamd_create(int device, int max_lf_groups, int linear_light, int debug_planes, int *status);
+HYDAMD_EXPORT void hydamd_destroy(HydAmdContext *ctx);
+HYDAMD_EXPORT const char *hydamd_error(HydAmdContext *ctx);
+
+/* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the context's own. */
+HYDAMD_EXPORT int hydamd_set_stream(HydAmdContext *ctx, void *hip_stream);
+HYDAMD_EXPORT void *hydamd_get_stream(HydAmdContext *ctx);
+
+/* 1 if K1 evaluates the format.c LUTs in registers (verified bit-exact at creation), 0 if it gathers from them. */
+HYDAMD_EXPORT int hydamd_uses_register_luts(HydAmdContext *ctx);
+/* Force the LUT-gather (1) or register (0) variant; for A/B measurements. */
+HYDAMD_EXPORT int hydamd_force_luts(HydAmdContext *ctx, int use_luts);
+
+/* Start a frame of `num_presets` presets (= LF groups, at most 255): clears histograms and the running alphabet. */
+HYDAMD_EXPORT int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets);
+
+/*
+ * Enqueue the whole hot path for the LF group stored in `slot` (0 <= slot < max_lf_groups; slots
+ * are coded into the frame in the order they are submitted).  src/strides/fmt mean exactly what
+ * hyd_send_tile's buffer/row_stride/pixel_stride/sample_fmt mean (strides in samples, src[c]
+ * pointing at the LF group's first pixel), except that the pointers are DEVICE pointers.
+ */
+HYDAMD_EXPORT int hydamd_encode_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrdiff_t row_stride,
+                                         ptrdiff_t pixel_stride, int sample_fmt, size_t width, size_t height,
+                                         unsigned preset);
+
+/* Same, from HOST pointers: the samples are gathered into pinned staging (the caller's buffers may
+ * be reused as soon as this returns, as after hyd_send_tile) and copied to the GPU on the stream. */
+HYDAMD_EXPORT int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, const void *const src[3],
+                                              ptrdiff_t row_stride, ptrdiff_t pixel_stride, int sample_fmt,
+                                              size_t width, size_t height, unsigned preset);
+
+/* Enqueue section sizing + packing for slots [0, num_slots): byte-padded HF sections, slot-major, raster inside a slot. */
+HYDAMD_EXPORT int hydamd_finish_frame(HydAmdContext *ctx, int num_slots);
+
+/* Block until everything enqueued so far has run; reports device-side failures (non-finite float
+ * sample -> HYD_API_ERROR, table construction failure -> HYD_INTERNAL_ERROR). */
+HYDAMD_EXPORT int hydamd_sync(HydAmdContext *ctx);
+
+/* ---- results; valid after hydamd_sync() ---- */
+HYDAMD_EXPORT size_t hydamd_payload_size(HydAmdContext *ctx);
+HYDAMD_EXPORT const uint8_t *hydamd_payload_device(HydAmdContext *ctx);
+HYDAMD_EXPORT int hydamd_read_payload(HydAmdContext *ctx, uint8_t *dst, size_t capacity);
+/* bits[g] = exact bit length of group g's section (0 for absent groups), offsets[g] = byte offset in the payload */
+HYDAMD_EXPORT int hydamd_read_sections(HydAmdContext *ctx, int slot, uint32_t bits[HYDAMD_GROUPS_PER_LFG],
+                                       uint64_t offsets[HYDAMD_GROUPS_PER_LFG]);
+HYDAMD_EXPORT int hydamd_read_tables(HydAmdContext *ctx, int slot, uint32_t freq[HYDAMD_MAX_CLUSTERS][HYDAMD_ALPHABET],
+                                     uint32_t alphabet[HYDAMD_MAX_CLUSTERS], uint32_t *log_alphabet_size,
+                                     uint32_t *running_max_alphabet);
+/* LF ints, dst[c][by][bx] with row pitch vbw, channel order X, Y, B */
+HYDAMD_EXPORT int hydamd_read_dc(HydAmdContext *ctx, int slot, int32_t *dst, size_t vbw, size_t vbh);
+
+/* ---- parity / debug read-backs ---- */
+HYDAMD_EXPORT int hydamd_read_symbol_counts(HydAmdContext *ctx, int slot, uint32_t counts[HYDAMD_GROUPS_PER_LFG]);
+/* token records of one group: lo = token | cluster<<8 | residue_bits<<16, hi = residue */
+HYDAMD_EXPORT int hydamd_read_tokens(HydAmdContext *ctx, int slot, int group, uint64_t *dst, size_t capacity);
+/* which: 0 XYB, 1 DCT (float), 2 quantised (int32); dst[c][y][x] with row pitch `pitch` elements */
+HYDAMD_EXPORT int hydamd_read_debug_plane(HydAmdContext *ctx, int which, void *dst, size_t pitch, size_t rows);
+
+/* ---- optional per-kernel timing with HIP events on the context's stream ---- */
+HYDAMD_EXPORT int hydamd_profile(HydAmdContext *ctx, int enable);
+/* accumulated milliseconds and launch counts per kernel class since the last call; resets the counters */
+HYDAMD_EXPORT int hydamd_profile_read(HydAmdContext *ctx, double ms[HYDAMD_K_COUNT], uint64_t launches[HYDAMD_K_COUNT]);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HYDRIUM_AMD_H_ */

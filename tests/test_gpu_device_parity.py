@@ -1,0 +1,159 @@
+"""GPU parity: the HIP hot path (through the hydamd_* C-ABI) against the CPU oracle, stage by stage.
+
+Bar: bit-exact for everything integer (LF ints, quantised coefficients, tokens, frequencies,
+section bytes); the XYB and DCT float intermediates are also required to be bit-identical
+(tolerance 0 ulp; +0.0 and -0.0 compare equal, see kernels.hip dct8).
+"""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+CASES = [
+    ("photo", 256, 256, 8),
+    ("photo", 264, 200, 16),
+    ("noise", 64, 48, 8),
+    ("smooth", 517, 259, 8),
+    ("photo", 97, 301, 16),
+    ("ramp", 8, 8, 8),
+    ("black", 40, 24, 8),
+    ("white", 33, 9, 16),
+    ("noise", 256, 256, 16),
+    ("photo", 1000, 700, 8),
+]
+
+
+def _torch_image(img):
+    import torch
+
+    if img.dtype == np.uint16:
+        return torch.from_numpy(img.view(np.int16).copy()).cuda()
+    return torch.from_numpy(np.ascontiguousarray(img)).cuda()
+
+
+def _check_lf_group(ctx, slot, res, scheme_local_offset, check_planes, pitch_rows=None):
+    from hydrium_amd import device
+
+    counts = ctx.read_symbol_counts(slot)
+    assert np.array_equal(counts[:res.num_groups], res.group_symbols)
+    first = 0
+    for g in range(res.num_groups):
+        n = int(res.group_symbols[g])
+        tok, cl, rb, resid = device.decode_token_records(ctx.read_tokens(slot, g, n))
+        ref = res.symbols[first:first + n]
+        assert np.array_equal(tok, ref["token"]), f"group {g} tokens"
+        assert np.array_equal(cl + scheme_local_offset, ref["cluster"]), f"group {g} clusters"
+        assert np.array_equal(rb, ref["residue_bits"]), f"group {g} residue bits"
+        assert np.array_equal(resid, ref["residue"]), f"group {g} residues"
+        first += n
+    freq, alpha, log_alpha, run_max = ctx.read_tables(slot)
+    ncl = res.cluster_to - res.cluster_from
+    assert np.array_equal(alpha[:ncl], res.alphabet_size[res.cluster_from:res.cluster_to])
+    assert np.array_equal(freq[:ncl], res.freqs[res.cluster_from:res.cluster_to])
+    assert (log_alpha, run_max) == (res.log_alphabet_size, res.max_alphabet_size)
+    assert np.array_equal(ctx.read_dc(slot, res.vbw, res.vbh), res.dc)
+
+
+@pytest.mark.parametrize("use_luts", [False, True])
+@pytest.mark.parametrize("kind,w,h,depth", CASES)
+def test_lf_group_stages_match_oracle(image, kind, w, h, depth, use_luts):
+    from hydrium_amd import device
+    from oracle import binding as orc
+
+    img = image(kind, w, h, depth)
+    res, _ = orc.encode_lf_group(img)
+    timg = _torch_image(img)
+    with device.DeviceContext(0, 1, 0, debug_planes=True) as ctx:
+        assert ctx.uses_register_luts(), "register evaluation of the format.c LUTs failed its bit-exactness self-test"
+        ctx.force_luts(use_luts)
+        ctx.encode_image_tensor(timg)
+        ctx.sync()
+        rows, pitch = res.vbh * 8, res.stride
+        xyb = ctx.read_debug_plane(0, pitch, rows)
+        assert np.array_equal(xyb.view(np.uint32), res.xyb.view(np.uint32)), "XYB planes differ"
+        dct = ctx.read_debug_plane(1, pitch, rows)
+        assert np.array_equal(dct, res.dct), "DCT planes differ"
+        quant = ctx.read_debug_plane(2, pitch, rows)
+        assert np.array_equal(quant, res.quant), "quantised planes differ"
+        _check_lf_group(ctx, 0, res, res.cluster_from, True)
+        bits, offs = ctx.read_sections(0)
+        assert np.array_equal(bits[:res.num_groups], res.group_bits)
+        payload = ctx.read_payload()
+        assert len(payload) == res.stream_bytes
+        assert payload == res.stream
+        assert np.array_equal(offs[:res.num_groups], res.group_offset)
+
+
+def test_f32_input_and_nan_rejection(image):
+    from hydrium_amd import device, synth
+    from oracle import binding as orc
+    import torch
+
+    img = synth.make_image_f32("photo", 300, 270)
+    res, _ = orc.encode_lf_group(img)
+    with device.DeviceContext(0, 1, 0) as ctx:
+        ctx.encode_image_tensor(torch.from_numpy(img).cuda())
+        ctx.sync()
+        assert ctx.read_payload() == res.stream
+        bad = img.copy()
+        bad[7, 9, 2] = np.inf
+        ctx.encode_image_tensor(torch.from_numpy(bad).cuda())
+        with pytest.raises(device.DeviceError) as ei:
+            ctx.sync()
+        assert ei.value.code == -14 and "NaN" in ei.value.message
+
+
+def test_multi_lf_group_frame_host_and_device_paths(image):
+    """2x2 LF groups (ragged right/bottom): presets, running alphabet, host-staged == device-resident."""
+    from hydrium_amd import device
+    from oracle import binding as orc
+
+    img = image("photo", 2048 + 300, 2048 + 120, 8)
+    expected = []
+    mx = 0
+    for ty in range(2):
+        for tx in range(2):
+            res, mx = orc.encode_lf_group(img, tx, ty, max_alphabet_size=mx)
+            expected.append(res)
+    want = b"".join(r.stream for r in expected)
+    with device.DeviceContext(0, 4, 0) as ctx:
+        ctx.encode_image_tensor(_torch_image(img))
+        ctx.sync()
+        got_dev = ctx.read_payload()
+        for slot, res in enumerate(expected):
+            _check_lf_group(ctx, slot, res, res.cluster_from, False)
+        ctx.encode_image_host(img)
+        ctx.sync()
+        got_host = ctx.read_payload()
+    assert got_dev == want
+    assert got_host == want
+
+
+def test_planar_and_strided_inputs(image):
+    """Generic (non-packed) addressing: planar channels and RGBA-style pixel stride 4."""
+    import torch
+    from hydrium_amd import device
+    from oracle import binding as orc
+
+    img = image("photo", 200, 136, 8)
+    res, _ = orc.encode_lf_group(img)
+    h, w, _ = img.shape
+    with device.DeviceContext(0, 1, 0) as ctx:
+        planes = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))).cuda()
+        ctx.begin_frame(1)
+        p = planes.data_ptr()
+        ctx.encode_lf_group(0, [p, p + w * h, p + 2 * w * h], w, 1, 0, w, h, 0)
+        ctx.finish_frame(1)
+        ctx.sync()
+        assert ctx.read_payload() == res.stream
+        rgba = np.zeros((h, w, 4), np.uint8)
+        rgba[:, :, :3] = img
+        t = torch.from_numpy(rgba).cuda()
+        ctx.begin_frame(1)
+        p = t.data_ptr()
+        ctx.encode_lf_group(0, [p, p + 1, p + 2], 4 * w, 4, 0, w, h, 0)
+        ctx.finish_frame(1)
+        ctx.sync()
+        assert ctx.read_payload() == res.stream

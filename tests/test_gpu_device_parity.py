@@ -81,7 +81,7 @@ def test_lf_group_stages_match_oracle(image, kind, w, h, depth, use_luts):
         bits, offs = ctx.read_sections(0)
         assert np.array_equal(bits[:res.num_groups], res.group_bits)
         payload = ctx.read_payload()
-        assert len(payload) == res.stream_bytes
+        assert len(payload) == len(res.stream)
         assert payload == res.stream
         assert np.array_equal(offs[:res.num_groups], res.group_offset)
 

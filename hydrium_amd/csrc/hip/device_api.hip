@@ -27,10 +27,12 @@
 #pragma clang fp contract(off)
 
 namespace hydk {
-hipError_t launch_transform(const HydkLfJob &job, uint32_t *status, hipStream_t stream);
-hipError_t launch_tables(const uint32_t *hist, HydkTables *tab, uint32_t *running_max, int nclusters, hipStream_t stream);
-hipError_t launch_rans(const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tab, uint32_t *bitbuf,
-                       uint32_t *group_bits, int num_groups, uint32_t preset, int preset_bits, hipStream_t stream);
+hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, bool luts, uint32_t *status,
+                            hipStream_t stream);
+hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int num_slots,
+                         hipStream_t stream);
+hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
+                       uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, hipStream_t stream);
 hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, hipStream_t stream);
 hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
                        int count, hipStream_t stream);
@@ -87,7 +89,14 @@ struct HydAmdContext {
     uint64_t *offsets = nullptr;    /* [slots][64] */
     uint64_t *total = nullptr;      /* [1] */
     uint32_t *status = nullptr;     /* [1] bit 0: non-finite float sample */
-    uint32_t *running_max = nullptr;
+    uint32_t *alpha_max = nullptr;  /* [slots] largest token + 1 per LF group */
+    HydkLfJob *d_jobs = nullptr;    /* [slots] */
+    HydkLfJob *h_jobs = nullptr;    /* [slots] pinned mirror of the frame being submitted (one of the ring below) */
+    HydkLfJob *h_jobs_ring[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t jobs_uploaded[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned frame_counter = 0;
+    int jobs_idx = 0;
+    unsigned fmt_mask = 0;          /* sample formats present among the submitted LF groups */
     uint16_t *in_lut8 = nullptr, *in_lut16 = nullptr;
     float *bias_lut = nullptr;
     uint8_t *payload = nullptr;
@@ -95,9 +104,10 @@ struct HydAmdContext {
     float *dbg_xyb = nullptr, *dbg_dct = nullptr;
     int32_t *dbg_quant = nullptr;
 
-    /* staging for the host-pointer path */
+    /* staging for the host-pointer path: pinned bounce tiles + one device tile per slot */
     void *pinned[kStaging] = {nullptr, nullptr};
-    void *d_in[kStaging] = {nullptr, nullptr};
+    char *d_arena = nullptr;
+    size_t arena_tile = 0;
     size_t staging_cap = 0;
     hipEvent_t staged[kStaging] = {nullptr, nullptr};
     int staging_next = 0;
@@ -208,8 +218,9 @@ int check_slot(HydAmdContext *ctx, int slot) {
     return ST_OK;
 }
 
-int enqueue_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrdiff_t row_stride, ptrdiff_t pixel_stride,
-                     int fmt, size_t width, size_t height, unsigned preset) {
+/* Record one LF group's job; the kernels run batched over all recorded slots in hydamd_finish_frame. */
+int record_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrdiff_t row_stride, ptrdiff_t pixel_stride,
+                    int fmt, size_t width, size_t height, unsigned preset) {
     if (width == 0 || height == 0 || width > 2048 || height > 2048)
         return fail(ctx, ST_API_ERROR, "LF group must be between 1 and 2048 pixels in each direction");
     if (fmt != HYDK_FMT_U8 && fmt != HYDK_FMT_U16 && fmt != HYDK_FMT_F32)
@@ -217,7 +228,7 @@ int enqueue_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptr
     if (preset >= ctx->num_presets)
         return fail(ctx, ST_API_ERROR, "preset out of range for this frame");
 
-    HydkLfJob job;
+    HydkLfJob &job = ctx->h_jobs[slot];
     memset(&job, 0, sizeof(job));
     for (int c = 0; c < 3; c++)
         job.src[c] = src[c];
@@ -230,57 +241,47 @@ int enqueue_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptr
     job.gcols = (int)((width + 255) >> 8);
     job.grows = (int)((height + 255) >> 8);
     job.scheme = ctx->scheme;
-    job.use_luts = ctx->use_luts;
+    job.use_luts = fmt == HYDK_FMT_F32 ? 0 : ctx->use_luts;
+    job.preset = preset;
     job.in_lut8 = ctx->in_lut8;
     job.in_lut16 = ctx->in_lut16;
     job.bias_lut = ctx->bias_lut;
     job.tokens = ctx->tokens + (size_t)slot * HYDK_GROUPS_PER_LFG * HYDK_TOKENS_PER_GROUP;
     job.sym_count = ctx->sym_count + (size_t)slot * HYDK_GROUPS_PER_LFG;
     job.hist = ctx->hist + (size_t)slot * HYDK_MAX_CLUSTERS * HYDK_ALPHABET;
+    job.alpha_max = ctx->alpha_max + slot;
     job.dc = ctx->dc + (size_t)slot * 3 * HYDK_DC_PITCH * HYDK_DC_PITCH;
-    job.dbg_xyb = ctx->dbg_xyb;
-    job.dbg_dct = ctx->dbg_dct;
-    job.dbg_quant = ctx->dbg_quant;
-    const int ngroups = job.gcols * job.grows;
-
+    if (slot == 0) { /* the dump planes hold one LF group */
+        job.dbg_xyb = ctx->dbg_xyb;
+        job.dbg_dct = ctx->dbg_dct;
+        job.dbg_quant = ctx->dbg_quant;
+    }
+    ctx->fmt_mask |= 1u << fmt;
     ctx->results_valid = false;
-    {
-        ScopedTimer timer(ctx, HYDAMD_K_TRANSFORM);
-        HIP_TRY(ctx, hydk::launch_transform(job, ctx->status, ctx->stream));
-    }
-    {
-        ScopedTimer timer(ctx, HYDAMD_K_TABLES);
-        HIP_TRY(ctx, hydk::launch_tables(job.hist, ctx->tables + slot, ctx->running_max, ctx->nclusters, ctx->stream));
-    }
-    {
-        ScopedTimer timer(ctx, HYDAMD_K_RANS);
-        HIP_TRY(ctx, hydk::launch_rans(job.tokens, job.sym_count, ctx->tables + slot,
-                                       ctx->bitbuf + (size_t)slot * HYDK_GROUPS_PER_LFG * HYDK_BITWORDS_PER_GROUP,
-                                       ctx->group_bits + (size_t)slot * HYDK_GROUPS_PER_LFG, ngroups, preset,
-                                       ctx->preset_bits, ctx->stream));
-    }
     return ST_OK;
 }
 
-int ensure_staging(HydAmdContext *ctx, size_t bytes) {
-    if (bytes <= ctx->staging_cap)
+int ensure_staging(HydAmdContext *ctx, size_t tile_bytes) {
+    if (tile_bytes <= ctx->staging_cap)
         return ST_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < kStaging; i++) {
         if (ctx->pinned[i])
             (void)hipHostFree(ctx->pinned[i]);
-        if (ctx->d_in[i])
-            (void)hipFree(ctx->d_in[i]);
-        ctx->pinned[i] = ctx->d_in[i] = nullptr;
+        ctx->pinned[i] = nullptr;
     }
+    if (ctx->d_arena)
+        (void)hipFree(ctx->d_arena);
+    ctx->d_arena = nullptr;
     ctx->staging_cap = 0;
     for (int i = 0; i < kStaging; i++) {
-        HIP_TRY(ctx, hipHostMalloc(&ctx->pinned[i], bytes, hipHostMallocDefault));
-        HIP_TRY(ctx, hipMalloc(&ctx->d_in[i], bytes));
+        HIP_TRY(ctx, hipHostMalloc(&ctx->pinned[i], tile_bytes, hipHostMallocDefault));
         if (!ctx->staged[i])
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->staged[i], hipEventDisableTiming));
     }
-    ctx->staging_cap = bytes;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_arena, tile_bytes * (size_t)ctx->max_slots));
+    ctx->arena_tile = tile_bytes;
+    ctx->staging_cap = tile_bytes;
     return ST_OK;
 }
 
@@ -326,18 +327,22 @@ void hydamd_destroy(HydAmdContext *ctx) {
         (void)hipStreamSynchronize(ctx->stream);
     drain_timers(ctx);
     void *dev[] = {ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->hist, ctx->sym_count, ctx->group_bits,
-                   ctx->offsets, ctx->total, ctx->status, ctx->running_max, ctx->in_lut8, ctx->in_lut16,
-                   ctx->bias_lut, ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant};
+                   ctx->offsets, ctx->total, ctx->status, ctx->alpha_max, ctx->d_jobs, ctx->in_lut8, ctx->in_lut16,
+                   ctx->bias_lut, ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant, ctx->d_arena};
     for (void *p : dev)
         if (p)
             (void)hipFree(p);
     for (int i = 0; i < kStaging; i++) {
         if (ctx->pinned[i])
             (void)hipHostFree(ctx->pinned[i]);
-        if (ctx->d_in[i])
-            (void)hipFree(ctx->d_in[i]);
         if (ctx->staged[i])
             (void)hipEventDestroy(ctx->staged[i]);
+    }
+    for (int i = 0; i < 4; i++) {
+        if (ctx->h_jobs_ring[i])
+            (void)hipHostFree(ctx->h_jobs_ring[i]);
+        if (ctx->jobs_uploaded[i])
+            (void)hipEventDestroy(ctx->jobs_uploaded[i]);
     }
     if (ctx->h_total_pinned)
         (void)hipHostFree(ctx->h_total_pinned);
@@ -363,7 +368,14 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipMalloc(&ctx->offsets, slots * G * sizeof(uint64_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->total, sizeof(uint64_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->status, sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->running_max, sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->alpha_max, slots * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_jobs, slots * sizeof(HydkLfJob)));
+    for (int i = 0; i < 4; i++) {
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_jobs_ring[i], slots * sizeof(HydkLfJob), hipHostMallocDefault));
+        memset(ctx->h_jobs_ring[i], 0, slots * sizeof(HydkLfJob));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->jobs_uploaded[i], hipEventDisableTiming));
+    }
+    ctx->h_jobs = ctx->h_jobs_ring[0];
     HIP_TRY(ctx, hipMalloc(&ctx->in_lut8, 256 * sizeof(uint16_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->in_lut16, 65536 * sizeof(uint16_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->bias_lut, 65536 * sizeof(float)));
@@ -487,9 +499,16 @@ int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
     ctx->preset_bits = bits; /* hyd_cllog2(num_presets), encoder.c:940 */
     ctx->results_valid = false;
     ctx->slots_finished = 0;
+    /* job descriptors are uploaded asynchronously from a small pinned ring, so up to three frames
+     * can be queued behind the one executing without the host touching a descriptor in flight */
+    ctx->jobs_idx = (int)(ctx->frame_counter++ & 3u);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->jobs_uploaded[ctx->jobs_idx]));
+    ctx->h_jobs = ctx->h_jobs_ring[ctx->jobs_idx];
+    memset(ctx->h_jobs, 0, (size_t)ctx->max_slots * sizeof(HydkLfJob));
     HIP_TRY(ctx, hipMemsetAsync(ctx->hist, 0,
                                 (size_t)ctx->max_slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->running_max, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->alpha_max, 0, (size_t)ctx->max_slots * sizeof(uint32_t), ctx->stream));
+    ctx->fmt_mask = 0;
     HIP_TRY(ctx, hipMemsetAsync(ctx->status, 0, sizeof(uint32_t), ctx->stream));
     return ST_OK;
 }
@@ -501,8 +520,7 @@ int hydamd_encode_lf_group(HydAmdContext *ctx, int slot, const void *const src[3
         return st;
     if (!src || !src[0] || !src[1] || !src[2])
         return fail(ctx, ST_API_ERROR, "null pixel pointer");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return enqueue_lf_group(ctx, slot, src, row_stride, pixel_stride, sample_fmt, width, height, preset);
+    return record_lf_group(ctx, slot, src, row_stride, pixel_stride, sample_fmt, width, height, preset);
 }
 
 int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, const void *const src[3], ptrdiff_t row_stride,
@@ -519,7 +537,7 @@ int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, const void *const 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t ss = sample_size(sample_fmt);
     const size_t bytes = width * height * 3 * ss;
-    /* size for a full 2048x2048 tile of this sample type so that later tiles never reallocate */
+    /* size for full 2048x2048 tiles of this sample type so that later tiles never reallocate */
     st = ensure_staging(ctx, (size_t)2048 * 2048 * 3 * ss);
     if (st != ST_OK)
         return st;
@@ -532,11 +550,11 @@ int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, const void *const 
         gather_packed((uint16_t *)ctx->pinned[k], src, row_stride, pixel_stride, width, height);
     else
         gather_packed((float *)ctx->pinned[k], src, row_stride, pixel_stride, width, height);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in[k], ctx->pinned[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+    char *base = ctx->d_arena + (size_t)slot * ctx->arena_tile;
+    HIP_TRY(ctx, hipMemcpyAsync(base, ctx->pinned[k], bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->staged[k], ctx->stream));
-    const char *base = (const char *)ctx->d_in[k];
     const void *dsrc[3] = {base, base + ss, base + 2 * ss};
-    return enqueue_lf_group(ctx, slot, dsrc, (ptrdiff_t)(3 * width), 3, sample_fmt, width, height, preset);
+    return record_lf_group(ctx, slot, dsrc, (ptrdiff_t)(3 * width), 3, sample_fmt, width, height, preset);
 }
 
 int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
@@ -547,12 +565,29 @@ int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int count = num_slots * HYDK_GROUPS_PER_LFG;
     ctx->results_valid = false;
+    for (int i = 0; i < num_slots; i++)
+        if (ctx->h_jobs[i].width == 0)
+            return fail(ctx, ST_API_ERROR, "an LF-group slot of this frame was never submitted");
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_jobs, ctx->h_jobs, (size_t)num_slots * sizeof(HydkLfJob), hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->jobs_uploaded[ctx->jobs_idx], ctx->stream));
     {
-        ScopedTimer timer(ctx, HYDAMD_K_PACK);
-        HIP_TRY(ctx, hydk::launch_scan(ctx->group_bits, count, ctx->offsets, ctx->total, ctx->stream));
+        ScopedTimer timer(ctx, HYDAMD_K_TRANSFORM);
+        HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs, num_slots, ctx->fmt_mask, ctx->use_luts != 0, ctx->status,
+                                            ctx->stream));
+    }
+    {
+        ScopedTimer timer(ctx, HYDAMD_K_TABLES);
+        HIP_TRY(ctx, hydk::launch_tables(ctx->hist, ctx->tables, ctx->alpha_max, ctx->nclusters, num_slots, ctx->stream));
+    }
+    {
+        ScopedTimer timer(ctx, HYDAMD_K_RANS);
+        HIP_TRY(ctx, hydk::launch_rans(ctx->d_jobs, ctx->tokens, ctx->sym_count, ctx->tables, ctx->bitbuf,
+                                       ctx->group_bits, ctx->preset_bits, num_slots, ctx->stream));
     }
     {
         ScopedTimer timer(ctx, HYDAMD_K_PACK);
+        HIP_TRY(ctx, hydk::launch_scan(ctx->group_bits, count, ctx->offsets, ctx->total, ctx->stream));
         HIP_TRY(ctx, hydk::launch_pack(ctx->bitbuf, ctx->group_bits, ctx->offsets, ctx->payload, count, ctx->stream));
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_total_pinned, ctx->total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));

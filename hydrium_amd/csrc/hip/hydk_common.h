@@ -42,7 +42,7 @@ typedef struct HydkTables {
     uint32_t pad;
 } HydkTables;
 
-/* Everything the transform kernel needs to know about one LF group. */
+/* Everything the kernels need to know about one LF group (one entry per slot, in send order). */
 typedef struct HydkLfJob {
     const void *src[3];      /* R, G, B sample pointers of the LF group's first pixel (device memory) */
     long long row_stride;    /* in samples */
@@ -53,12 +53,15 @@ typedef struct HydkLfJob {
     int gcols, grows;        /* groups across / down */
     int scheme;              /* HF clustering scheme 0..3 = 9 / 3 / 2 / 1 clusters per preset */
     int use_luts;            /* 1: gather from the uploaded LUTs instead of evaluating them in registers */
+    unsigned preset;         /* HF preset id of this LF group (written in front of each group section) */
+    int pad0;
     const uint16_t *in_lut8;   /* 256 entries   */
     const uint16_t *in_lut16;  /* 65536 entries */
     const float *bias_lut;     /* 65536 entries */
     uint64_t *tokens;        /* [groups][HYDK_TOKENS_PER_GROUP] */
     uint32_t *sym_count;     /* [groups] */
     uint32_t *hist;          /* [HYDK_MAX_CLUSTERS][HYDK_ALPHABET], zeroed before launch */
+    uint32_t *alpha_max;     /* [1] largest token + 1 over this LF group's symbols, zeroed before launch */
     int32_t *dc;             /* [3][HYDK_DC_PITCH][HYDK_DC_PITCH] LF ints */
     float *dbg_xyb;          /* optional [3][2048][2048] dumps for parity tests, else NULL */
     float *dbg_dct;

@@ -8,8 +8,9 @@
  *                         entropy.c:427-444) and the per-preset token histogram (entropy.c:526-544).
  *   k_build_tables        histogram -> 12-bit frequencies -> alias table -> inverse slot table
  *                         (entropy.c:184-301, 943-978).
- *   k_rans_encode         one lane per group: the serial reverse rANS chain + bit emission
- *                         (entropy.c:1064-1159), written back-to-front so no second pass is needed.
+ *   k_rans_encode         one wave per group: the serial reverse rANS chain (entropy.c:1064-1159)
+ *                         with wave-parallel bit emission, written back-to-front so that no
+ *                         replay pass is needed.
  *   k_scan_sections / k_pack_sections   byte sizes, offsets and packing of the HF sections.
  *
  * Arithmetic contract: IEEE binary32, source operation order, NO fused multiply-add — the
@@ -204,11 +205,17 @@ struct SampleOf<HYDK_FMT_F32> {
 } /* namespace */
 
 /* ==========================================================================================
- * K1: fused transform + tokenise.  grid = groups of the LF group, block = 256 threads (4 waves).
+ * K1: fused transform + tokenise.  grid = 64 group slots per LF group x LF groups of the frame,
+ * block = 256 threads (4 waves); one 256x256 group per workgroup.
  * ======================================================================================== */
 template <int FMT, bool LUTS>
-__global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob job, uint32_t *status) {
+__global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
     typedef typename SampleOf<FMT>::type sample_t;
+    const HydkLfJob job = jobs[blockIdx.x >> 6];
+    if (job.fmt != FMT || (job.use_luts != 0) != LUTS)
+        return; /* another template instance of this launch round owns this LF group */
+    if ((int)(blockIdx.x & 63) >= job.gcols * job.grows)
+        return;
 
     __shared__ float s_rowpass[3 * kS0Chan];          /* [c][block][y][kh], 27.0 KiB */
     __shared__ int32_t s_quant[96 * kQPitch];         /* [block*3 + c][zig-zag j], 24.4 KiB */
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
-    const int g = blockIdx.x;
+    const int g = blockIdx.x & 63;
     const int gx = g % job.gcols, gy = g / job.gcols;
     const int px0 = gx << 8, py0 = gy << 8;
     const int gw = min(256, job.width - px0), gh = min(256, job.height - py0);
@@ -494,11 +501,19 @@ __global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob
         __syncthreads();
     }
 
+    uint32_t top_token = 0;
     for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads) {
         const uint32_t v = s_hist[i];
-        if (v)
+        if (v) {
             atomicAdd(&job.hist[i], v);
+            top_token = max(top_token, (uint32_t)(i % HYDK_ALPHABET) + 1u);
+        }
     }
+#pragma unroll
+    for (int d = 32; d; d >>= 1)
+        top_token = max(top_token, (uint32_t)__shfl_xor((int)top_token, d));
+    if (lane == 0 && top_token)
+        atomicMax(job.alpha_max, top_token);
     if (t == 0)
         job.sym_count[g] = goff;
     if (FMT == HYDK_FMT_F32 && bad_sample)
@@ -506,10 +521,12 @@ __global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob
 }
 
 /* ==========================================================================================
- * K2: per-LF-group ANS tables.  grid = 1, block = 256.
+ * K2: per-LF-group ANS tables.  grid = LF groups of the frame (send order), block = 256.
  * ======================================================================================== */
-__global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist, HydkTables *tab, uint32_t *running_max,
-                                                           int nclusters) {
+__global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_all, HydkTables *tabs,
+                                                           const uint32_t *alpha_max_all, int nclusters) {
+    const uint32_t *hist = hist_all + (size_t)blockIdx.x * HYDK_MAX_CLUSTERS * HYDK_ALPHABET;
+    HydkTables *tab = tabs + blockIdx.x;
     __shared__ uint32_t s_freq[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
     __shared__ uint32_t s_cutoff[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
     __shared__ uint32_t s_other[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
@@ -542,11 +559,11 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist,
     }
     __syncthreads();
     if (t == 0) {
-        /* the stream-wide alphabet maximum is never reset between LF groups (entropy.c:459-460,952) */
-        uint32_t mx = *running_max;
-        for (int c = 0; c < nclusters; c++)
-            mx = max(mx, s_alpha[c]);
-        *running_max = mx;
+        /* the stream-wide alphabet maximum is never reset between LF groups (entropy.c:459-460,952):
+         * LF group n codes with the maximum over LF groups 0..n in send order */
+        uint32_t mx = 0;
+        for (unsigned sl = 0; sl <= blockIdx.x; sl++)
+            mx = max(mx, alpha_max_all[sl]);
         uint32_t lg = mx > 1 ? 32 - __clz((int)(mx - 1)) : 0; /* ceil(log2(mx)) */
         s_log_alpha = max(lg, 5u);
         tab->running_max_alphabet = mx;
@@ -681,124 +698,169 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist,
 }
 
 /* ==========================================================================================
- * K3a: reverse rANS, one lane per group (<= 64 groups of an LF group share one preset's tables).
- * The chain state -> state is strictly serial per group (entropy.c:1092-1119); lanes run 64
- * chains in lock-step.  Bits are prepended into a per-group buffer filled from its end, so the
- * forward order [state][refill_p][residue_p]... of entropy.c:1127-1147 falls out of the reverse
- * walk with no replay pass.
+ * K3a: reverse rANS.  One wave per group, 4 groups of one LF group per workgroup (they share the
+ * preset's tables in LDS).  The state -> state recurrence is strictly serial per group
+ * (entropy.c:1092-1119), so the kernel is shaped around it:
+ *   - 64 symbols at a time are loaded coalesced and their (freq, magic, table base) looked up by
+ *     all lanes in parallel;
+ *   - the serial walk then touches only the recurrence: every lane carries the same state
+ *     redundantly (no divergence, LDS reads broadcast), per-symbol operands arrive by
+ *     v_readlane, and lane k keeps the state seen by symbol k;
+ *   - refill decisions and all bit emission are recomputed wave-parallel from those saved states:
+ *     prefix-sum of bit counts, OR into an LDS window, coalesced store.  The group buffer is
+ *     filled from its END so the forward order [state][refill_p][residue_p].. of
+ *     entropy.c:1127-1147 falls out of the reverse walk without a replay pass.
+ * grid = 16 x LF groups, block = 256.
  * ======================================================================================== */
-__global__ __launch_bounds__(64) void k_rans_encode(const uint64_t *tokens, const uint32_t *sym_count,
-                                                    const HydkTables *tab, uint32_t *bitbuf, uint32_t *group_bits,
-                                                    int num_groups, uint32_t preset, int preset_bits) {
+constexpr int kWinWords = 100; /* 64 symbols x 46 bits = 92 words + alignment slack */
+
+__global__ __launch_bounds__(kThreads) void k_rans_encode(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
+                                                          const uint32_t *sym_count_all, const HydkTables *tabs,
+                                                          uint32_t *bitbuf_all, uint32_t *group_bits_all,
+                                                          int preset_bits) {
     __shared__ uint16_t s_inv[HYDK_MAX_CLUSTERS * HYDK_ANS_SLOTS];   /* 72 KiB */
     __shared__ uint32_t s_fb[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
     __shared__ uint32_t s_magic[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
+    __shared__ uint32_t s_win[4][kWinWords];
 
-    const int lane = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int slot = blockIdx.x >> 4;
+    const int g = ((blockIdx.x & 15) << 2) + wave;
+    const int ngroups = jobs[slot].gcols * jobs[slot].grows;
+    if ((int)((blockIdx.x & 15) << 2) >= ngroups) {
+        if (lane == 0)
+            group_bits_all[slot * HYDK_GROUPS_PER_LFG + g] = 0;
+        return; /* whole workgroup beyond the LF group's last group */
+    }
+    const HydkTables *tab = tabs + slot;
     {
-        const uint32_t *src = (const uint32_t *)&tab->inv[0][0];
-        uint32_t *dst = (uint32_t *)s_inv;
-        for (int i = lane; i < HYDK_MAX_CLUSTERS * HYDK_ANS_SLOTS / 2; i += 64)
+        const uint4 *src = (const uint4 *)&tab->inv[0][0];
+        uint4 *dst = (uint4 *)s_inv;
+        for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ANS_SLOTS / 8; i += kThreads)
             dst[i] = src[i];
-        for (int i = lane; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += 64) {
+        for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads) {
             s_fb[i] = (&tab->fb[0][0])[i];
             s_magic[i] = (&tab->magic[0][0])[i];
         }
     }
     __syncthreads();
-
-    const bool live = lane < num_groups;
-    const int n = live ? (int)sym_count[lane] : 0;
-    const uint64_t *tok = tokens + (size_t)lane * HYDK_TOKENS_PER_GROUP;
-    uint32_t *W = bitbuf + (size_t)lane * HYDK_BITWORDS_PER_GROUP;
-    int widx = HYDK_BITWORDS_PER_GROUP; /* next word goes to W[--widx] */
-    unsigned long long acc = 0;         /* pending bits, bit 0 = earliest stream position */
-    int nb = 0;
-    uint32_t state = 0x130000u;
-
-    int nmax = n;
-#pragma unroll
-    for (int d = 32; d; d >>= 1)
-        nmax = max(nmax, __shfl_xor(nmax, d));
-
-#define HYDK_PREPEND(val, nbits)                                   \
-    do {                                                           \
-        acc = (acc << (nbits)) | (unsigned long long)(val);        \
-        nb += (nbits);                                             \
-        if (nb >= 32) {                                            \
-            nb -= 32;                                              \
-            W[--widx] = (uint32_t)(acc >> nb);                     \
-            acc &= (1ull << nb) - 1ull;                            \
-        }                                                          \
-    } while (0)
-
-    constexpr int kChunk = 8;
-    uint64_t cur[kChunk];
-#pragma unroll
-    for (int k = 0; k < kChunk; k++) {
-        const int p = n - 1 - k;
-        cur[k] = p >= 0 ? tok[p] : 0;
-    }
-    for (int i0 = 0; i0 < nmax; i0 += kChunk) {
-        uint64_t nxt[kChunk];
-        uint32_t fb[kChunk], mg[kChunk];
-#pragma unroll
-        for (int k = 0; k < kChunk; k++) {
-            const int p = n - 1 - (i0 + kChunk + k);
-            nxt[k] = p >= 0 ? tok[p] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < kChunk; k++) {
-            const uint32_t lo = (uint32_t)cur[k];
-            const uint32_t e = ((lo >> 8) & 0xF) * HYDK_ALPHABET + (lo & 0xFF);
-            fb[k] = s_fb[e];
-            mg[k] = s_magic[e];
-        }
-#pragma unroll
-        for (int k = 0; k < kChunk; k++) {
-            if (i0 + k < n) {
-                const uint32_t lo = (uint32_t)cur[k];
-                const uint32_t residue = (uint32_t)(cur[k] >> 32);
-                const int rbits = (int)((lo >> 16) & 0x3F);
-                const uint32_t f = fb[k] & 0xFFFF, base = fb[k] >> 16;
-                const uint32_t cl = (lo >> 8) & 0xF;
-                /* residue p sits after refill p in the stream, so it is prepended first */
-                if (rbits)
-                    HYDK_PREPEND(residue, rbits);
-                uint32_t x = state;
-                if ((state >> 20) >= f) {
-                    HYDK_PREPEND(state & 0xFFFFu, 16);
-                    x = state >> 16;
-                }
-                /* exact x / f: q' = mulhi(x, floor(2^32/f)) is q or q-1 for x < 2^32 */
-                uint32_t q = __umulhi(x, mg[k]);
-                uint32_t r = x - q * f;
-                if (r >= f) {
-                    r -= f;
-                    q += 1;
-                }
-                const uint32_t slot = s_inv[cl * HYDK_ANS_SLOTS + base + r];
-                state = (q << 12) | slot;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kChunk; k++)
-            cur[k] = nxt[k];
+    if (g >= ngroups) {
+        if (lane == 0)
+            group_bits_all[slot * HYDK_GROUPS_PER_LFG + g] = 0;
+        return;
     }
 
-    if (live) {
-        if (n > 0)
-            HYDK_PREPEND(state, 32); /* low half first, then high half (entropy.c:1127-1130) */
-        if (preset_bits)
-            HYDK_PREPEND(preset, preset_bits); /* encoder.c:945 */
-        uint32_t total = (uint32_t)(HYDK_BITWORDS_PER_GROUP - widx) * 32u + (uint32_t)nb;
-        if (nb)
-            W[--widx] = (uint32_t)(acc << (32 - nb));
-        group_bits[lane] = total;
-    } else {
-        group_bits[lane] = 0;
+    const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + g;
+    const uint64_t *tok = tokens_all + G * HYDK_TOKENS_PER_GROUP;
+    uint32_t *W = bitbuf_all + G * HYDK_BITWORDS_PER_GROUP;
+    uint32_t *win = s_win[wave];
+    const int n = __builtin_amdgcn_readfirstlane((int)sym_count_all[G]); /* wave-uniform: scalar loop control */
+    const unsigned char *inv_bytes = (const unsigned char *)s_inv;
+
+    uint32_t cur = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u; /* stream start so far (absolute bit position) */
+    uint32_t carry = 0;                                     /* content of the partly filled word at cur>>5 */
+    uint32_t state = 0x130000u + (uint32_t)(lane >> 6);     /* lane>>6 == 0: keeps the chain in vector registers */
+
+    /* wave-parallel emission of one (value, nbits) per lane, lane 0 nearest the already written
+     * bits (= latest in stream order), lane 63 earliest */
+    auto emit = [&](unsigned long long val, uint32_t nbits) {
+        uint32_t inc = nbits;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d);
+            if (lane >= d)
+                inc += o;
+        }
+        const uint32_t total = __shfl(inc, 63);
+        if (!total)
+            return;
+        const uint32_t newcur = cur - total;
+        const uint32_t wlo = newcur >> 5, whi = (cur - 1u) >> 5;
+        const uint32_t nwords = whi - wlo + 1u;
+        for (uint32_t i = lane; i < nwords; i += 64)
+            win[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0 && (cur & 31u))
+            win[whi - wlo] = carry;
+        /* win[] is private to this wave: lock-step execution + in-order LDS make the phases
+         * visible to each other; the wave barriers only pin the compiler's ordering */
+        __builtin_amdgcn_wave_barrier();
+        if (nbits) {
+            const uint32_t pos = cur - inc - wlo * 32u; /* cur - (exclusive prefix) - nbits, window-relative */
+            const uint32_t w = pos >> 5, sh = pos & 31u;
+            const unsigned long long lo = val << sh;
+            const uint32_t hi = sh ? (uint32_t)(val >> (64u - sh)) : 0u;
+            if ((uint32_t)lo)
+                atomicOr(&win[w], (uint32_t)lo);
+            if ((uint32_t)(lo >> 32))
+                atomicOr(&win[w + 1], (uint32_t)(lo >> 32));
+            if (hi)
+                atomicOr(&win[w + 2], hi);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool low_partial = (newcur & 31u) != 0;
+        for (uint32_t i = lane + (low_partial ? 1u : 0u); i < nwords; i += 64)
+            W[wlo + i] = win[i];
+        carry = low_partial ? win[0] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        cur = newcur;
+    };
+
+    for (int hi_p = n - 1; hi_p >= 0; hi_p -= 64) {
+        /* lane l owns symbol p = hi_p - l; the walk visits lanes 0, 1, 2, ... */
+        const int p = hi_p - lane;
+        const bool valid = p >= 0;
+        const uint64_t rec = valid ? tok[p] : 0ull;
+        const uint32_t lo = (uint32_t)rec;
+        const uint32_t e = ((lo >> 8) & 0xF) * HYDK_ALPHABET + (lo & 0xFF);
+        const uint32_t fbv = s_fb[e];
+        const uint32_t f = valid ? (fbv & 0xFFFFu) : 1u;
+        const uint32_t mg = s_magic[e];
+        const uint32_t adr = (((lo >> 8) & 0xF) * HYDK_ANS_SLOTS + (fbv >> 16)) * 2u;
+        /* (state >> 20) >= f  <=>  state > (f << 20) - 1, exact for f up to 4096 (entropy.c:1092) */
+        const uint32_t thr = (uint32_t)(((unsigned long long)f << 20) - 1ull);
+        const int cnt = min(64, hi_p + 1);
+        uint32_t seen = 0;
+        for (int k = 0; k < cnt; k++) {
+            const uint32_t fk = __builtin_amdgcn_readlane(f, k);
+            const uint32_t mk = __builtin_amdgcn_readlane(mg, k);
+            const uint32_t ak = __builtin_amdgcn_readlane(adr, k);
+            const uint32_t tk = __builtin_amdgcn_readlane(thr, k);
+            seen = lane == k ? state : seen;
+            const uint32_t x = state > tk ? state >> 16 : state;
+            /* exact x / f: mulhi(x, floor(2^32/f)) is the quotient or one less for any x < 2^32 */
+            uint32_t q = __umulhi(x, mk);
+            const uint32_t r0 = x - __umul24(q, fk);
+            const uint32_t r = min(r0, r0 - fk);
+            q += r0 >= fk;
+            const uint32_t slot_v = *(const uint16_t *)(inv_bytes + ak + 2u * r);
+            state = (q << 12) | slot_v;
+        }
+        /* refill p is written just before residue p (entropy.c:1134-1147), i.e. prepended after it */
+        const uint32_t rbits = valid ? (lo >> 16) & 0x3Fu : 0u;
+        const bool refill = valid && seen > thr;
+        const unsigned long long residue = rec >> 32;
+        const unsigned long long val = refill ? (residue << 16) | (seen & 0xFFFFu) : residue;
+        emit(val, rbits + (refill ? 16u : 0u));
     }
-#undef HYDK_PREPEND
+    /* [preset id][final state, low half first] precede everything (encoder.c:945, entropy.c:1127-1130) */
+    {
+        unsigned long long val = 0;
+        uint32_t nb = 0;
+        if (lane == 0 && n > 0) {
+            val = state;
+            nb = 32;
+        } else if (lane == 1) {
+            val = jobs[slot].preset;
+            nb = (uint32_t)preset_bits;
+        }
+        emit(val, nb);
+    }
+    if (lane == 0) {
+        if (cur & 31u)
+            W[cur >> 5] = carry;
+        group_bits_all[G] = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u - cur;
+    }
 }
 
 /* ==========================================================================================
@@ -873,40 +935,38 @@ __global__ void k_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, 
  * ---------------------------------------------------------------------------------------- */
 namespace hydk {
 
-hipError_t launch_transform(const HydkLfJob &job, uint32_t *status, hipStream_t stream) {
-    const dim3 grid(job.gcols * job.grows), block(kThreads);
-    const bool luts = job.use_luts != 0;
-    switch (job.fmt) {
-    case HYDK_FMT_U8:
+/* One launch per template instance that owns at least one LF group of this round; an instance
+ * returns at once for the LF groups of another sample format. */
+hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, bool luts, uint32_t *status,
+                            hipStream_t stream) {
+    const dim3 grid(num_slots * HYDK_GROUPS_PER_LFG), block(kThreads);
+    if (fmt_mask & (1u << HYDK_FMT_U8)) {
         if (luts)
-            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U8, true>), grid, block, 0, stream, job, status);
+            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U8, true>), grid, block, 0, stream, d_jobs, status);
         else
-            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U8, false>), grid, block, 0, stream, job, status);
-        break;
-    case HYDK_FMT_U16:
-        if (luts)
-            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U16, true>), grid, block, 0, stream, job, status);
-        else
-            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U16, false>), grid, block, 0, stream, job, status);
-        break;
-    case HYDK_FMT_F32:
-        hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_F32, false>), grid, block, 0, stream, job, status);
-        break;
-    default:
-        return hipErrorInvalidValue;
+            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U8, false>), grid, block, 0, stream, d_jobs, status);
     }
+    if (fmt_mask & (1u << HYDK_FMT_U16)) {
+        if (luts)
+            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U16, true>), grid, block, 0, stream, d_jobs, status);
+        else
+            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U16, false>), grid, block, 0, stream, d_jobs, status);
+    }
+    if (fmt_mask & (1u << HYDK_FMT_F32))
+        hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_F32, false>), grid, block, 0, stream, d_jobs, status);
     return hipGetLastError();
 }
 
-hipError_t launch_tables(const uint32_t *hist, HydkTables *tab, uint32_t *running_max, int nclusters, hipStream_t stream) {
-    hipLaunchKernelGGL(k_build_tables, dim3(1), dim3(kThreads), 0, stream, hist, tab, running_max, nclusters);
+hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int num_slots,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(k_build_tables, dim3(num_slots), dim3(kThreads), 0, stream, hist, tabs, alpha_max, nclusters);
     return hipGetLastError();
 }
 
-hipError_t launch_rans(const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tab, uint32_t *bitbuf,
-                       uint32_t *group_bits, int num_groups, uint32_t preset, int preset_bits, hipStream_t stream) {
-    hipLaunchKernelGGL(k_rans_encode, dim3(1), dim3(64), 0, stream, tokens, sym_count, tab, bitbuf, group_bits,
-                       num_groups, preset, preset_bits);
+hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
+                       uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, hipStream_t stream) {
+    hipLaunchKernelGGL(k_rans_encode, dim3(num_slots * 16), dim3(kThreads), 0, stream, d_jobs, tokens, sym_count, tabs,
+                       bitbuf, group_bits, preset_bits);
     return hipGetLastError();
 }
 

@@ -1,0 +1,585 @@
+/*
+ * encoder.c — HYDEncoder session, the nine public hyd_* entry points and the host tile scheduler.
+ *
+ * This is the drop-in boundary (include/libhydrium/libhydrium.h).  Behaviour, argument meaning,
+ * status codes and error strings follow the reference's libhydrium.c / encoder.c; what is behind
+ * the boundary is new:
+ *
+ *   hyd_send_tile (reference libhydrium.c:172-203)
+ *     -> geometry + "last tile" decision              (encoder.c:437-508 restated in tile_geometry)
+ *     -> hydamd_encode_lf_group_host: the caller's samples are gathered into pinned staging and
+ *        uploaded; the call returns once they have been read (the CLI reuses its row buffer right
+ *        away, reference hydrium.c:416)
+ *     -> on the frame's final tile only: hydamd_finish_frame runs the whole hot path for every
+ *        LF group of the frame in batched launches (transform+tokenise, ANS tables, rANS, packing),
+ *        then the host wraps the HF sections: LFGlobal, LF groups, HFGlobal, TOC (frame.c).
+ *
+ * One-frame mode therefore keeps the GPU fed with uploads while tiles arrive and codes the frame
+ * in one go at the end, exactly when the reference, too, first produces frame bytes
+ * (libhydrium.c:148-149).  There is NO CPU fallback: without a usable HIP device hyd_send_tile
+ * fails with HYD_INTERNAL_ERROR.
+ *
+ * Deliberate deviations from the reference (all on inputs where the reference misbehaves):
+ *   - frames with 128 or more than 255 LF groups are rejected (the reference never returns:
+ *     uint8_t loop counter vs 256 clusters, entropy.c:99);
+ *   - one-frame images must have every tile sent (the reference reads uninitialised state for
+ *     unsent tiles, encoder.c:248-256,973-975);
+ *   - non-finite float samples yield HYD_API_ERROR "Invalid NaN Float" (the reference sets the
+ *     message but drops the status, format.c:172-174) — reported when the frame is finished;
+ *   - output never lands in caller memory beyond the provided length (bitwriter.c:42-51 would
+ *     realloc() the caller's buffer).
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "bitio.h"
+#include "frame.h"
+#include "hydrium_amd.h"
+#include "libhydrium/libhydrium.h"
+
+typedef struct LfgResult {
+    int32_t *dc; /* [3][vbh][vbw] */
+    uint32_t freq[HYD_FRAME_MAX_CLUSTERS][HYD_FRAME_ALPHABET];
+    uint32_t alphabet[HYD_FRAME_MAX_CLUSTERS];
+    uint32_t bits[HYDAMD_GROUPS_PER_LFG];
+} LfgResult;
+
+struct HYDEncoder {
+    HYDImageMetadata metadata;
+    int have_metadata;
+    int one_frame;
+    int level10;
+    size_t lfg_count_x, lfg_count_y, lfg_per_frame;
+    size_t tile_w, tile_h; /* pixels */
+    const char *error;
+
+    uint8_t *out; /* buffer on loan from the caller */
+    size_t out_len, out_pos;
+
+    HydBits stream;    /* codestream bytes produced and not yet handed over start at stream_pos */
+    size_t stream_pos;
+    int wrote_header;
+    int last_tile;
+    int frame_done; /* one-frame: the final tile has been coded */
+    size_t tiles_sent;
+
+    uint8_t *icc; /* mangled profile (libhydrium.c:242-305) */
+    size_t icc_size;
+
+    HydFrameLfg *sent; /* [lfg_per_frame] in send order */
+    HydAmdContext *dev;
+};
+
+#define FAIL(enc, code, msg) ((enc)->error = (msg), (code))
+
+/* ---------------------------------------------------------------------------------------------
+ * frame assembly (shared by the product path and the CPU-only test hook)
+ * ------------------------------------------------------------------------------------------- */
+
+static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgResult *res, unsigned max_alphabet,
+                          const uint8_t *payload, size_t payload_len) {
+    const size_t fg = ((shape->frame_width + 255) >> 8) * ((shape->frame_height + 255) >> 8);
+    const int multi = fg > 1;
+    const size_t toc_n = hyd_toc_entries(shape);
+    const unsigned num_presets = (unsigned)shape->lfg_count;
+    int ret = 0;
+    HydBits body;
+    hb_init(&body);
+    size_t *sizes = calloc(toc_n, sizeof(size_t));
+    uint32_t(*freq)[HYD_FRAME_MAX_CLUSTERS][HYD_FRAME_ALPHABET] = calloc(num_presets, sizeof(*freq));
+    uint32_t(*alpha)[HYD_FRAME_MAX_CLUSTERS] = calloc(num_presets, sizeof(*alpha));
+    if (!sizes || !freq || !alpha) {
+        ret = FAIL(e, HYD_NOMEM, "out of memory");
+        goto done;
+    }
+    size_t k = 0, mark = 0;
+#define CLOSE_SECTION()                    \
+    do {                                   \
+        if (multi) {                       \
+            hb_align(&body);               \
+            sizes[k++] = body.len - mark;  \
+            mark = body.len;               \
+        }                                  \
+    } while (0)
+
+    hyd_write_lf_global(&body);
+    CLOSE_SECTION();
+    for (size_t s = 0; s < shape->lfg_count; s++) {
+        const size_t vbw = (shape->lfg[s].width + 7) >> 3, vbh = (shape->lfg[s].height + 7) >> 3;
+        ret = hyd_write_lf_group(&body, res[s].dc, vbw, vbh, &e->error);
+        if (ret)
+            goto done;
+        CLOSE_SECTION();
+    }
+    /* tables are signalled per preset = raster LF-group id, whatever the send order was */
+    for (size_t s = 0; s < shape->lfg_count; s++) {
+        const size_t p = shape->lfg[s].raster_id;
+        memcpy(freq[p], res[s].freq, sizeof(res[s].freq));
+        memcpy(alpha[p], res[s].alphabet, sizeof(res[s].alphabet));
+    }
+    ret = hyd_write_hf_global(&body, num_presets, fg, (const uint32_t(*)[HYD_FRAME_MAX_CLUSTERS][HYD_FRAME_ALPHABET])freq,
+                              (const uint32_t(*)[HYD_FRAME_MAX_CLUSTERS])alpha, max_alphabet, &e->error);
+    if (ret)
+        goto done;
+    CLOSE_SECTION();
+    if (multi) {
+        /* the device payload already is: byte-padded sections, send order, raster inside an LF group */
+        hb_append_bytes(&body, payload, payload_len);
+        for (size_t s = 0; s < shape->lfg_count; s++) {
+            const size_t ng = ((shape->lfg[s].width + 255) >> 8) * ((shape->lfg[s].height + 255) >> 8);
+            for (size_t g = 0; g < ng; g++)
+                sizes[k++] = (res[s].bits[g] + 7u) >> 3;
+        }
+    } else {
+        /* a single-group frame is one bit-contiguous section (encoder.c:837-850,968-981 guards) */
+        hb_append_bits(&body, payload, res[0].bits[0]);
+    }
+    hb_align(&body);
+    if (!multi)
+        sizes[k++] = body.len;
+    if (k != toc_n || body.failed) {
+        ret = FAIL(e, body.failed ? HYD_NOMEM : HYD_INTERNAL_ERROR, "frame assembly inconsistency");
+        goto done;
+    }
+    ret = hyd_write_frame_header(&e->stream, shape, &e->error);
+    if (!ret)
+        ret = hyd_write_toc_sizes(&e->stream, sizes, toc_n);
+    if (ret) {
+        if (!e->error)
+            e->error = "frame header could not be written";
+        goto done;
+    }
+    hb_append_bytes(&e->stream, body.data, body.len);
+    if (e->stream.failed)
+        ret = FAIL(e, HYD_NOMEM, "out of memory");
+done:
+#undef CLOSE_SECTION
+    free(sizes);
+    free(freq);
+    free(alpha);
+    hb_free(&body);
+    return ret;
+}
+
+static int emit_file_header(HYDEncoder *e) {
+    if (e->wrote_header)
+        return 0;
+    int ret = hyd_write_file_header(&e->stream, e->metadata.width, e->metadata.height, e->level10, e->icc, e->icc_size,
+                                    &e->error);
+    if (ret) {
+        if (!e->error)
+            e->error = "file header could not be written";
+        return ret;
+    }
+    e->wrote_header = 1;
+    return 0;
+}
+
+/* move pending codestream bytes into the caller's buffer */
+static void drain(HYDEncoder *e) {
+    if (!e->out)
+        return;
+    size_t n = e->stream.len - e->stream_pos;
+    if (n > e->out_len - e->out_pos)
+        n = e->out_len - e->out_pos;
+    if (n) {
+        memcpy(e->out + e->out_pos, e->stream.data + e->stream_pos, n);
+        e->out_pos += n;
+        e->stream_pos += n;
+    }
+    if (e->stream_pos == e->stream.len) {
+        hb_reset(&e->stream);
+        e->stream_pos = 0;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * public API
+ * ------------------------------------------------------------------------------------------- */
+
+HYDRIUM_EXPORT HYDEncoder *hyd_encoder_new(void) {
+    HYDEncoder *e = calloc(1, sizeof(HYDEncoder));
+    if (e)
+        hb_init(&e->stream);
+    return e;
+}
+
+HYDRIUM_EXPORT HYDStatusCode hyd_encoder_destroy(HYDEncoder *e) {
+    if (!e)
+        return HYD_OK;
+    if (e->dev)
+        hydamd_destroy(e->dev);
+    hb_free(&e->stream);
+    free(e->icc);
+    free(e->sent);
+    free(e);
+    return HYD_OK;
+}
+
+HYDRIUM_EXPORT const char *hyd_error_message_get(HYDEncoder *e) { return e->error; }
+
+HYDRIUM_EXPORT HYDStatusCode hyd_set_metadata(HYDEncoder *e, const HYDImageMetadata *md) {
+    /* validation order and messages: libhydrium.c:46-78 */
+    if (!md->width || !md->height)
+        return FAIL(e, HYD_API_ERROR, "invalid zero-width or zero-height");
+    const uint64_t w = md->width, h = md->height;
+    if (w > UINT64_C(1) << 30 || h > UINT64_C(1) << 30)
+        return FAIL(e, HYD_API_ERROR, "width or height out of bounds");
+    if (w * h > UINT64_C(1) << 40)
+        return FAIL(e, HYD_API_ERROR, "width times height out of bounds");
+    e->metadata = *md;
+    if (w > (1 << 20) || h > (1 << 20) || w * h > (1 << 28))
+        e->level10 = 1;
+    if (md->tile_size_shift_x < -1 || md->tile_size_shift_x > 3)
+        return FAIL(e, HYD_API_ERROR, "tile_size_shift_y must be between -1 and 3"); /* sic, libhydrium.c:70-72 */
+    if (md->tile_size_shift_y < -1 || md->tile_size_shift_y > 3)
+        return FAIL(e, HYD_API_ERROR, "tile_size_shift_y must be between -1 and 3");
+    e->one_frame = md->tile_size_shift_x < 0 || md->tile_size_shift_y < 0;
+    e->lfg_count_y = (md->height + 2047) >> 11;
+    e->lfg_count_x = (md->width + 2047) >> 11;
+    e->lfg_per_frame = e->one_frame ? e->lfg_count_x * e->lfg_count_y : 1;
+    e->tile_w = e->one_frame ? 2048 : (size_t)256 << md->tile_size_shift_x;
+    e->tile_h = e->one_frame ? 2048 : (size_t)256 << md->tile_size_shift_y;
+    if (e->lfg_per_frame > HYDAMD_MAX_LF_GROUPS || e->lfg_per_frame == 128)
+        return FAIL(e, HYD_API_ERROR, "one frame cannot hold 128 or more than 255 LF groups; use tile mode");
+    free(e->sent);
+    e->sent = calloc(e->lfg_per_frame, sizeof(HydFrameLfg));
+    if (!e->sent)
+        return FAIL(e, HYD_NOMEM, "out of memory");
+    if (e->dev) { /* metadata changed: the device context is rebuilt lazily */
+        hydamd_destroy(e->dev);
+        e->dev = NULL;
+    }
+    e->have_metadata = 1;
+    e->tiles_sent = 0;
+    e->frame_done = 0;
+    return HYD_OK;
+}
+
+HYDRIUM_EXPORT HYDStatusCode hyd_provide_output_buffer(HYDEncoder *e, uint8_t *buffer, size_t buffer_len) {
+    if (buffer_len < 64)
+        return FAIL(e, HYD_API_ERROR, "provided buffer must be at least 64 bytes long");
+    if (e->out)
+        return FAIL(e, HYD_API_ERROR, "buffer was already provided");
+    if (!buffer)
+        return FAIL(e, HYD_API_ERROR, "buffer may not be null");
+    e->out = buffer;
+    e->out_len = buffer_len;
+    e->out_pos = 0;
+    return HYD_OK;
+}
+
+HYDRIUM_EXPORT HYDStatusCode hyd_release_output_buffer(HYDEncoder *e, size_t *written) {
+    if (!e->out)
+        return FAIL(e, HYD_API_ERROR, "buffer was never provided");
+    *written = e->out_pos;
+    e->out = NULL;
+    return HYD_OK;
+}
+
+HYDRIUM_EXPORT HYDStatusCode hyd_flush(HYDEncoder *e) {
+    if (e->one_frame && !e->last_tile)
+        return HYD_OK; /* libhydrium.c:148-149 */
+    if (!e->out)
+        return FAIL(e, HYD_API_ERROR, "buffer was never provided");
+    drain(e);
+    return e->stream_pos < e->stream.len ? HYD_NEED_MORE_OUTPUT : HYD_OK;
+}
+
+static int device_fail(HYDEncoder *e, int code) {
+    /* hydamd status codes are HYDStatusCode values; keep a static string for the message */
+    static const char *const generic = "GPU encode failed (see hydamd_error)";
+    const char *m = hydamd_error(e->dev);
+    if (m && strstr(m, "NaN"))
+        e->error = "Invalid NaN Float";
+    else if (m && strstr(m, "no usable HIP device"))
+        e->error = "no usable HIP device (this build has no CPU fallback)";
+    else if (code == HYD_NOMEM)
+        e->error = "out of device memory";
+    else
+        e->error = generic;
+    return code;
+}
+
+/* read back everything the frame assembler needs and write the frame */
+static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
+    const size_t n = shape->lfg_count;
+    int ret = hydamd_finish_frame(e->dev, (int)n);
+    if (!ret)
+        ret = hydamd_sync(e->dev);
+    if (ret)
+        return device_fail(e, ret);
+    LfgResult *res = calloc(n, sizeof(LfgResult));
+    uint8_t *payload = NULL;
+    if (!res)
+        return FAIL(e, HYD_NOMEM, "out of memory");
+    unsigned max_alphabet = 0;
+    const size_t payload_len = hydamd_payload_size(e->dev);
+    payload = malloc(payload_len ? payload_len : 1);
+    if (!payload) {
+        ret = FAIL(e, HYD_NOMEM, "out of memory");
+        goto done;
+    }
+    ret = hydamd_read_payload(e->dev, payload, payload_len);
+    for (size_t s = 0; s < n && !ret; s++) {
+        const size_t vbw = (shape->lfg[s].width + 7) >> 3, vbh = (shape->lfg[s].height + 7) >> 3;
+        uint32_t log_alpha = 0, running = 0;
+        res[s].dc = malloc(3 * vbw * vbh * sizeof(int32_t));
+        if (!res[s].dc) {
+            ret = HYD_NOMEM;
+            break;
+        }
+        ret = hydamd_read_dc(e->dev, (int)s, res[s].dc, vbw, vbh);
+        if (!ret)
+            ret = hydamd_read_tables(e->dev, (int)s, res[s].freq, res[s].alphabet, &log_alpha, &running);
+        if (!ret)
+            ret = hydamd_read_sections(e->dev, (int)s, res[s].bits, NULL);
+        if (running > max_alphabet)
+            max_alphabet = running;
+    }
+    if (ret) {
+        ret = device_fail(e, ret);
+        goto done;
+    }
+    ret = assemble_frame(e, shape, res, max_alphabet, payload, payload_len);
+done:
+    for (size_t s = 0; s < n; s++)
+        free(res[s].dc);
+    free(res);
+    free(payload);
+    return ret;
+}
+
+HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buffer[3], uint32_t tile_x, uint32_t tile_y,
+                                           ptrdiff_t row_stride, ptrdiff_t pixel_stride, int is_last,
+                                           HYDSampleFormat sample_fmt) {
+    int ret;
+    if (sample_fmt != HYD_UINT8 && sample_fmt != HYD_UINT16 && sample_fmt != HYD_FLOAT32)
+        return FAIL(e, HYD_API_ERROR, "Invalid Sample Format");
+    if (!e->have_metadata)
+        return FAIL(e, HYD_API_ERROR, "metadata was never set");
+    /* geometry and last-tile rule: encoder.c:437-485 */
+    const size_t W = e->metadata.width, H = e->metadata.height;
+    if (tile_x >= (W + e->tile_w - 1) / e->tile_w || tile_y >= (H + e->tile_h - 1) / e->tile_h)
+        return FAIL(e, HYD_API_ERROR, "tile out of bounds");
+    if (e->one_frame && (e->frame_done || e->tiles_sent >= e->lfg_per_frame))
+        return FAIL(e, HYD_API_ERROR, "the final tile of this image was already sent");
+    const size_t tw = ((size_t)tile_x + 1) * e->tile_w > W ? W - tile_x * e->tile_w : e->tile_w;
+    const size_t th = ((size_t)tile_y + 1) * e->tile_h > H ? H - tile_y * e->tile_h : e->tile_h;
+    e->last_tile = is_last < 0 ? ((size_t)tile_x + 1) * e->tile_w >= W && ((size_t)tile_y + 1) * e->tile_h >= H : !!is_last;
+
+    ret = emit_file_header(e);
+    if (ret)
+        return ret;
+
+    if (!e->dev) {
+        int st = 0;
+        e->dev = hydamd_create(0, (int)e->lfg_per_frame, e->metadata.linear_light, 0, &st);
+        if (!e->dev) {
+            const char *m = hydamd_error(NULL);
+            if (st == HYD_NOMEM)
+                return FAIL(e, HYD_NOMEM, "out of device memory");
+            return FAIL(e, HYD_INTERNAL_ERROR, m && strstr(m, "no usable HIP device")
+                                                   ? "no usable HIP device (this build has no CPU fallback)"
+                                                   : "GPU initialisation failed");
+        }
+    }
+    const size_t slot = e->one_frame ? e->tiles_sent : 0;
+    if (slot == 0) {
+        ret = hydamd_begin_frame(e->dev, (unsigned)e->lfg_per_frame);
+        if (ret)
+            return device_fail(e, ret);
+    }
+    HydFrameLfg *l = &e->sent[slot];
+    l->raster_id = e->one_frame ? (size_t)tile_y * e->lfg_count_x + tile_x : 0;
+    l->x = tile_x;
+    l->y = tile_y;
+    l->width = tw;
+    l->height = th;
+    ret = hydamd_encode_lf_group_host(e->dev, (int)slot, buffer, row_stride, pixel_stride, (int)sample_fmt, tw, th,
+                                      (unsigned)l->raster_id);
+    if (ret)
+        return device_fail(e, ret);
+
+    if (e->one_frame) {
+        e->tiles_sent++;
+        if (!e->last_tile) {
+            drain(e);
+            return HYD_OK;
+        }
+        if (e->tiles_sent != e->lfg_per_frame)
+            return FAIL(e, HYD_API_ERROR, "one-frame mode needs every tile before the final one");
+    }
+
+    HydFrameShape shape;
+    memset(&shape, 0, sizeof(shape));
+    shape.one_frame = e->one_frame;
+    shape.image_width = W;
+    shape.image_height = H;
+    shape.frame_width = e->one_frame ? W : tw;
+    shape.frame_height = e->one_frame ? H : th;
+    shape.tile_count_x = e->tile_w >> 8;
+    shape.tile_count_y = e->tile_h >> 8;
+    shape.lfg_count = e->lfg_per_frame;
+    shape.lfg = e->sent;
+    shape.is_last = e->last_tile;
+    ret = finish_frame(e, &shape);
+    if (ret)
+        return ret;
+    if (e->one_frame)
+        e->frame_done = 1;
+    drain(e);
+    return HYD_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * ICC pre-mangling (libhydrium.c:205-305): the JPEG XL ICC transform with an empty tag list and a
+ * single "copy the rest" command, i.e. header prediction only.
+ * ------------------------------------------------------------------------------------------- */
+
+static uint8_t icc_header_guess(const uint8_t *icc, uint32_t icc_size, unsigned i) {
+    static const char std12[] = "mntrRGB XYZ ";
+    if (i < 4)
+        return (uint8_t)(icc_size >> (8 * (3 - i)));
+    if (i == 8)
+        return 4;
+    if (i >= 12 && i < 24)
+        return (uint8_t)std12[i - 12];
+    if (i >= 36 && i < 40)
+        return (uint8_t)"acsp"[i - 36];
+    if (i >= 41 && i < 44) {
+        if (icc[40] == 'A')
+            return (uint8_t)"PPL"[i - 41];
+        if (icc[40] == 'M')
+            return (uint8_t)"SFT"[i - 41];
+        if (icc[40] == 'S' && icc[41] == 'G')
+            return (uint8_t)"I "[i - 42];
+        if (icc[40] == 'S' && icc[41] == 'U')
+            return (uint8_t)"NW"[i - 42];
+    }
+    switch (i) {
+    case 70:
+        return 246;
+    case 71:
+        return 214;
+    case 73:
+        return 1;
+    case 78:
+        return 211;
+    case 79:
+        return 45;
+    default:
+        break;
+    }
+    if (i >= 80 && i < 84)
+        return icc[i - 76];
+    return 0;
+}
+
+HYDRIUM_EXPORT HYDStatusCode hyd_set_suggested_icc_profile(HYDEncoder *e, const uint8_t *icc_data, size_t icc_size) {
+    if (!icc_data && !icc_size) {
+        free(e->icc);
+        e->icc = NULL;
+        e->icc_size = 0;
+        return HYD_OK;
+    }
+    if (!e->one_frame)
+        return FAIL(e, HYD_API_ERROR, "one-frame mode required to set the suggested ICC profile");
+    if (!icc_size || !icc_data || icc_size > UINT32_MAX)
+        return FAIL(e, HYD_API_ERROR, "invalid ICC size or data buffer");
+    HydBits b;
+    hb_init(&b);
+    const size_t head = icc_size < 128 ? icc_size : 128;
+    const size_t rest = icc_size - head;
+    hb_icc_varint(&b, icc_size);
+    hb_icc_varint(&b, rest ? 3 + (size_t)(63 - __builtin_clzll(rest)) / 7 : 0);
+    if (rest) {
+        hb_icc_varint(&b, 0); /* empty tag list */
+        hb_put(&b, 1, 8);     /* command 1: copy */
+        hb_icc_varint(&b, rest);
+    }
+    hb_align(&b);
+    for (unsigned i = 0; i < head; i++)
+        hb_put(&b, (uint8_t)(icc_data[i] - icc_header_guess(icc_data, (uint32_t)icc_size, i)), 8);
+    hb_align(&b);
+    hb_append_bytes(&b, icc_data + head, rest);
+    if (b.failed) {
+        hb_free(&b);
+        return FAIL(e, HYD_NOMEM, "out of memory");
+    }
+    free(e->icc);
+    e->icc = b.data; /* ownership moves to the encoder */
+    e->icc_size = b.len;
+    return HYD_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * CPU-only test hook: assemble a frame from stage results supplied by the caller (the tests feed
+ * it the oracle's outputs, so the frame glue can be checked against the reference on machines
+ * without a GPU).  Compiled only into libhydrium_hosttest.so.
+ * ------------------------------------------------------------------------------------------- */
+#ifdef HYD_TEST_HOOKS
+#define HYDT_EXPORT __attribute__((visibility("default")))
+
+HYDT_EXPORT int hydt_frame_from_stages(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
+                                       const uint32_t *tile_xy, const int32_t *const *dc, const uint32_t *freq,
+                                       const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
+                                       const uint8_t *payload, size_t payload_len, const uint8_t *icc, size_t icc_size,
+                                       uint8_t **out, size_t *out_len, const char **err) {
+    HYDEncoder *e = hyd_encoder_new();
+    if (!e)
+        return HYD_NOMEM;
+    int ret = hyd_set_metadata(e, md);
+    if (!ret && icc)
+        ret = hyd_set_suggested_icc_profile(e, icc, icc_size);
+    LfgResult *res = calloc(lfg_count, sizeof(LfgResult));
+    if (!ret && !res)
+        ret = HYD_NOMEM;
+    if (!ret && write_header)
+        ret = emit_file_header(e);
+    if (!ret) {
+        const size_t W = md->width, H = md->height;
+        for (size_t s = 0; s < lfg_count; s++) {
+            const size_t tx = tile_xy[2 * s], ty = tile_xy[2 * s + 1];
+            e->sent[s].raster_id = e->one_frame ? ty * e->lfg_count_x + tx : 0;
+            e->sent[s].x = tx;
+            e->sent[s].y = ty;
+            e->sent[s].width = (tx + 1) * e->tile_w > W ? W - tx * e->tile_w : e->tile_w;
+            e->sent[s].height = (ty + 1) * e->tile_h > H ? H - ty * e->tile_h : e->tile_h;
+            res[s].dc = (int32_t *)dc[s];
+            memcpy(res[s].freq, freq + s * HYD_FRAME_MAX_CLUSTERS * HYD_FRAME_ALPHABET, sizeof(res[s].freq));
+            memcpy(res[s].alphabet, alphabet + s * HYD_FRAME_MAX_CLUSTERS, sizeof(res[s].alphabet));
+            memcpy(res[s].bits, group_bits + s * HYDAMD_GROUPS_PER_LFG, sizeof(res[s].bits));
+        }
+        HydFrameShape shape;
+        memset(&shape, 0, sizeof(shape));
+        shape.one_frame = e->one_frame;
+        shape.image_width = W;
+        shape.image_height = H;
+        shape.frame_width = e->one_frame ? W : e->sent[0].width;
+        shape.frame_height = e->one_frame ? H : e->sent[0].height;
+        shape.tile_count_x = e->tile_w >> 8;
+        shape.tile_count_y = e->tile_h >> 8;
+        shape.lfg_count = lfg_count;
+        shape.lfg = e->sent;
+        shape.is_last = is_last;
+        ret = assemble_frame(e, &shape, res, max_alphabet, payload, payload_len);
+    }
+    if (!ret) {
+        *out = malloc(e->stream.len ? e->stream.len : 1);
+        if (*out) {
+            memcpy(*out, e->stream.data, e->stream.len);
+            *out_len = e->stream.len;
+        } else {
+            ret = HYD_NOMEM;
+        }
+    }
+    if (err)
+        *err = e->error;
+    free(res);
+    hyd_encoder_destroy(e);
+    return ret;
+}
+
+HYDT_EXPORT void hydt_free(void *p) { free(p); }
+#endif /* HYD_TEST_HOOKS */

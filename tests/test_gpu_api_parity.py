@@ -1,0 +1,117 @@
+"""GPU, through the drop-in C API (hyd_encoder_new ... hyd_send_tile ... hyd_flush): the bytes that
+come out of hydrium_amd/lib/libhydrium.so.0 must equal the reference's.
+
+Three anchors, strongest available first:
+  * oracle/_ref/libhydrium_ref.so (the real reference, when the prebuilt file travelled),
+  * the committed golden fixtures / MD5 manifest under tests/golden (generated from the reference),
+  * the host glue fed by the CPU oracle (tests/glue.py), itself pinned to the reference on CPU.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from hydrium_amd import api
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return api.Library()
+
+
+def _expected(img, **kw):
+    from oracle import refprobe
+
+    if refprobe.available():
+        return api.encode_image(refprobe.reference_library(), img, **kw), "reference"
+    import glue
+
+    g = {k: v for k, v in kw.items() if k in ("shift_x", "shift_y", "order", "icc", "linear_light")}
+    return glue.encode_with_oracle_stages(img, **g), "oracle+glue"
+
+
+CASES = [
+    ("photo", 256, 256, 8), ("photo", 8, 8, 8), ("noise", 257, 255, 8), ("smooth", 1000, 700, 8),
+    ("photo", 300, 200, 16), ("black", 64, 64, 8), ("white", 40, 520, 16), ("photo", 2049, 130, 8),
+    ("smooth", 2100, 2060, 8), ("photo", 4096, 4096, 8),
+]
+
+
+@pytest.mark.parametrize("kind,w,h,depth", CASES)
+def test_one_frame_files(lib, image, kind, w, h, depth):
+    img = image(kind, w, h, depth)
+    want, _ = _expected(img)
+    got = api.encode_image(lib, img)
+    assert len(got) == len(want)
+    assert got == want
+
+
+@pytest.mark.parametrize("layout", ["planar", "flipped"])
+def test_layouts(lib, image, layout):
+    img = image("photo", 520, 300, 8)
+    want, _ = _expected(img)
+    assert api.encode_image(lib, img, layout=layout) == want
+
+
+@pytest.mark.parametrize("shift", [0, 1, 3])
+def test_tile_mode(lib, image, shift):
+    img = image("photo", 1000, 700, 8)
+    want, _ = _expected(img, shift_x=shift, shift_y=shift)
+    assert api.encode_image(lib, img, shift_x=shift, shift_y=shift) == want
+
+
+def test_out_of_order_tiles(lib, image):
+    img = image("photo", 2048 + 200, 2048 + 100, 8)
+    order = [(1, 0), (0, 1), (0, 0), (1, 1)]
+    want, _ = _expected(img, order=order)
+    assert api.encode_image(lib, img, order=order) == want
+
+
+def test_tiny_output_buffer_streams_the_same_bytes(lib, image):
+    img = image("photo", 300, 200, 8)
+    want, _ = _expected(img)
+    assert api.encode_image(lib, img, out_buf_size=64) == want
+    assert api.encode_image(lib, img, out_buf_size=4099) == want
+
+
+def test_float_linear_and_icc(lib, image):
+    from hydrium_amd import synth
+
+    f = synth.make_image_f32("photo", 264, 136)
+    assert api.encode_image(lib, f) == _expected(f)[0]
+    u16 = image("photo", 120, 72, 16)
+    assert api.encode_image(lib, u16, linear_light=1) == _expected(u16, linear_light=1)[0]
+    icc = bytes(range(256)) * 2
+    img = image("photo", 72, 40, 8)
+    assert api.encode_image(lib, img, icc=icc) == _expected(img, icc=icc)[0]
+
+
+def test_nan_sample_is_an_api_error(lib):
+    img = np.zeros((16, 16, 3), np.float32)
+    img[3, 3, 0] = np.nan
+    with pytest.raises(api.HydriumError) as ei:
+        api.encode_image(lib, img)
+    assert ei.value.code == api.HYD_API_ERROR and ei.value.message == "Invalid NaN Float"
+
+
+def test_golden_manifest(lib, image):
+    """Fixtures generated from the reference by tests/golden/make_golden.py."""
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        manifest = json.load(f)
+    for entry in manifest["files"]:
+        if entry["width"] * entry["height"] > 4096 * 4096:
+            continue
+        img = image(entry["kind"], entry["width"], entry["height"], entry["depth"])
+        got = api.encode_image(lib, img, shift_x=entry["shift"], shift_y=entry["shift"])
+        assert len(got) == entry["size"], entry
+        assert hashlib.md5(got).hexdigest() == entry["md5"], entry
+        if "file" in entry:
+            with open(os.path.join(GOLDEN, entry["file"]), "rb") as fh:
+                assert got == fh.read()

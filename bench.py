@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixel/s of hydrium's per-group encode hot path on MI355X (driver contract).
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): one 8192x8192 RGB16 frame
+per GPU — 16 LF groups, 1024 groups of 256x256 — of the deterministic "photo" content
+(SURVEY.md Appendix C), already resident in HBM when the timed region starts.  One "step" is one
+pass of the whole hot path over that frame: RGB->XYB, 8x8 DCT, quantisation, tokenisation +
+histograms (k_transform_tokenize), ANS tables (k_build_tables), rANS coding of all 1024 group
+sections (k_rans_encode) and their packing (k_scan_sections / k_pack_sections), through the
+additive C-ABI of include/hydrium_amd.h.  Consecutive steps are spread over `--streams`
+independent contexts so that the latency-bound rANS kernel of one frame overlaps the transform
+kernel of the next, as a production encoder serving a queue of frames would.
+
+N > 1 (launched by torch.distributed.run): weak scaling — rank r codes its own 8192x8192 slab
+(a window of one larger synthetic image), then the packed HF sections of all ranks are
+concatenated with one RCCL all-gather of sizes and one of payload bytes per step.
+
+Prints ONE JSON line on rank 0.  `value` is whole-job Mpixel/s over all GPUs.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=8192, help="frame edge in pixels (per GPU)")
+    ap.add_argument("--depth", type=int, default=16, choices=(8, 16))
+    ap.add_argument("--kind", default="photo")
+    ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(host_img):
+    """hydrium's own CPU path (oracle/_ref build, -Os as shipped) on this box's host cores, or the
+    CPU port when the prebuilt reference did not travel.  Reported next to the GPU number."""
+    from hydrium_amd import api
+    from oracle import refprobe
+
+    h, w, _ = host_img.shape
+    if refprobe.available():
+        lib = refprobe.reference_library()
+        t0 = time.perf_counter()
+        data = api.encode_image(lib, host_img)
+        dt = time.perf_counter() - t0
+        return {"value": round(w * h / dt / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "reference",
+                "sample": f"the whole {w}x{h} workload frame once through hyd_send_tile (gcc -Os build of the "
+                          f"reference sources, one-frame mode, {dt:.1f} s)",
+                "bytes": len(data), "md5": hashlib.md5(data).hexdigest()}
+    from oracle import binding as orc
+
+    crop = host_img[:4096, :4096].copy()
+    t0 = time.perf_counter()
+    nbytes, _ = orc.hot_path_image(crop)
+    dt = time.perf_counter() - t0
+    return {"value": round(crop.shape[0] * crop.shape[1] / dt / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+            "sample": f"hot path only (oracle/hyd_oracle.c) on the top-left 4096x4096 of the workload frame, {dt:.1f} s",
+            "bytes": int(nbytes)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP extension has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from hydrium_amd import api, device, sharding, synth
+
+    W = H = args.size
+    # each rank's slab is a window of one big synthetic picture, slabs side by side in raster order
+    gx = sharding.slab_grid(world)[0]
+    img = synth.make_image(args.kind, W, H, args.depth, x0=(rank % gx) * W, y0=(rank // gx) * H,
+                           device=torch.device("cuda", local))
+    torch.cuda.synchronize()
+    lfg = (-(-W // 2048)) * (-(-H // 2048))
+    ctxs = [device.DeviceContext(local, lfg, 0) for _ in range(max(1, args.streams))]
+
+    def step(i):
+        ctx = ctxs[i % len(ctxs)]
+        ctx.encode_image_tensor(img)
+        if world > 1:
+            ctx.sync()
+            sharding.all_gather_sections(ctx.payload_tensor(), dist.group.WORLD)
+        return ctx
+
+    for i in range(args.warmup):
+        step(i)
+    for c in ctxs:
+        c.sync()
+        c.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    for c in ctxs:
+        c.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel durations from HIP events recorded on the kernels' own streams during the timed region
+    kern = {}
+    for c in ctxs:
+        for name, (ms, n) in c.profile_read().items():
+            a = kern.setdefault(name, [0.0, 0])
+            a[0] += ms
+            a[1] += n
+        c.profile(False)
+    payload_bytes = ctxs[0].payload_size()
+    symbols = sum(int(ctxs[0].read_symbol_counts(s).sum()) for s in range(lfg))
+
+    if rank == 0:
+        bytes_in = W * H * 3 * (args.depth // 8)
+        kernels = {k: {"avg_ms": round(v[0] / max(v[1], 1), 4), "launches": v[1],
+                       "algorithmic_GBs": round(bytes_in / (v[0] / max(v[1], 1) * 1e-3) / 1e9, 1) if v[0] else None}
+                   for k, v in kern.items()}
+        dom = max(kern, key=lambda k: kern[k][0])
+        dom_ms = kern[dom][0] / max(kern[dom][1], 1)
+        achieved = bytes_in / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(f"{dom}:{W}x{H}:u{args.depth}:{args.kind}")
+        out = {
+            "metric": "Mpixel/s encode (8K RGB, default q)",
+            "value": round(world * W * H * args.steps / dt / 1e6, 1),
+            "unit": "Mpixel/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} RGB{args.depth} '{args.kind}' frame per GPU (BASELINE configs[2]); "
+                                   "hot path device-resident RGB -> packed HF group sections "
+                                   "(XYB, DCT, quantise, tokenise, ANS tables, rANS, pack)",
+                       "groups": lfg * 64 if W % 2048 == 0 and H % 2048 == 0 else None, "lf_groups": lfg,
+                       "streams": len(ctxs), "parallelism": f"{world} x (one frame per GPU)" +
+                                                            (", RCCL all-gather of sections" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_in, "avg_launch_ms": round(dom_ms, 4)},
+            "kernels": kernels,
+            "symbols_per_pixel": round(symbols / (W * H), 4),
+            "section_bytes": payload_bytes,
+            "hbm_read_roofline_Mpx_s": round(HBM_PEAK_GBS * 1e9 / (3 * args.depth // 8) / 1e6, 0),
+            "frac_of_hbm_read_roofline": round((W * H * args.steps / dt) / (HBM_PEAK_GBS * 1e9 / (3 * args.depth // 8)), 5),
+        }
+        host_img = None
+        if world == 1 and not (args.no_cpu_baseline and args.no_api):
+            arr = img.cpu().numpy()
+            host_img = np.ascontiguousarray(arr.view(np.uint16) if args.depth == 16 else arr)
+        if world == 1 and not args.no_api:
+            # API end-to-end through the drop-in hyd_send_tile (host pixels: includes PCIe, host LF coder, assembly)
+            lib = api.Library()
+            api.encode_image(lib, host_img[:2048, :2048].copy())  # warm the library
+            t1 = time.perf_counter()
+            data = api.encode_image(lib, host_img)
+            t_api = time.perf_counter() - t1
+            out["api_end_to_end"] = {"Mpixel/s": round(W * H / t_api / 1e6, 1), "ms": round(t_api * 1e3, 1),
+                                     "bytes": len(data), "md5": hashlib.md5(data).hexdigest(),
+                                     "note": "host-pointer hyd_send_tile path, one-frame mode; PCIe + host LF coder inclusive"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host_img)
+            if "api_end_to_end" in out and "md5" in out["cpu_baseline"]:
+                out["api_end_to_end"]["identical_to_cpu_reference"] = out["cpu_baseline"]["md5"] == out["api_end_to_end"]["md5"]
+        print(json.dumps(out), flush=True)
+    for c in ctxs:
+        c.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -2,8 +2,8 @@
 
 The binding is deliberately library-agnostic: ``Library(path)`` binds the nine ``hyd_*`` entry
 points of *any* shared object exporting them, so the same driver code runs the MI355X build
-(``hydrium_amd/lib/libhydrium.so.0``) and — in tests only — the reference build under
-``oracle/_ref``.  ``encode_image`` reproduces the reference CLI's call pattern
+(``hydrium_amd/lib/libhydrium.so.0``) and — in tests only — a build of the reference
+itself.  ``encode_image`` reproduces the reference CLI's call pattern
 (reference src/hydrium.c:275-286, 402-479): one-frame mode by default, tiles row-major, a
 fixed-size output buffer cycled through flush / release / provide.
 """

@@ -177,6 +177,18 @@ class DeviceContext:
     def payload_device_ptr(self) -> int:
         return self.d.hydamd_payload_device(self.h) or 0
 
+    def payload_tensor(self):
+        """Zero-copy torch uint8 view of the packed HF sections in HBM (valid until the next frame)."""
+        import torch
+
+        n = self.payload_size()
+        ptr = self.payload_device_ptr()
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (max(n, 1),), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        return torch.as_tensor(_View(), device="cuda")[:n]
+
     def read_payload(self) -> bytes:
         n = self.payload_size()
         buf = np.zeros(max(n, 1), np.uint8)

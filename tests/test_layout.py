@@ -1,0 +1,119 @@
+"""CPU-only structural checks: the C-ABI library loads and exports what include/*.h declare, the
+product never touches oracle/, and error paths of the host API behave like the reference's."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from hydrium_amd import api, build as hbuild
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    hbuild.build()
+    return api.Library()
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hyd_\w+|hydamd_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared("libhydrium/libhydrium.h") + _declared("hydrium_amd.h")
+    assert len([n for n in names if n.startswith("hyd_")]) == 9
+    for n in names:
+        assert hasattr(lib.dll, n), f"{n} declared in include/ but not exported"
+
+
+def test_only_api_symbols_are_exported():
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", hbuild.LIB_PATH], capture_output=True, text=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert syms and all(s.startswith(("hyd_", "hydamd_")) for s in syms), syms
+
+
+def test_product_does_not_reference_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "hydrium_amd")):
+        if "build" in base.split(os.sep) or "lib" in base.split(os.sep):
+            continue
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|oracle/|liboracle|hyd_oracle", text, re.M):
+                    bad.append(os.path.join(base, f))
+    assert not bad, f"product files mention the oracle: {bad}"
+
+
+def test_metadata_validation_matches_reference_messages(lib):
+    cases = [
+        ((0, 10, 0, -1, -1), "invalid zero-width or zero-height"),
+        (((1 << 30) + 1, 10, 0, -1, -1), "width or height out of bounds"),
+        ((1 << 30, 1 << 20, 0, 0, 0), "width times height out of bounds"),
+        ((10, 10, 0, 4, 0), "tile_size_shift_y must be between -1 and 3"),
+        ((10, 10, 0, 0, -2), "tile_size_shift_y must be between -1 and 3"),
+    ]
+    for args, msg in cases:
+        with api.Encoder(lib) as enc:
+            assert enc.set_metadata(*args) == api.HYD_API_ERROR
+            assert enc.error_message() == msg
+    with api.Encoder(lib) as enc:
+        assert enc.set_metadata(2048 * 16, 2048 * 8) == api.HYD_API_ERROR  # 128 LF groups: reference hangs
+        assert enc.set_metadata(2048 * 16, 2048 * 8, 0, 3, 3) == api.HYD_OK  # fine in tile mode
+
+
+def test_output_buffer_protocol_errors(lib):
+    with api.Encoder(lib) as enc:
+        assert enc.set_metadata(64, 64) == api.HYD_OK
+        small = (C.c_uint8 * 63)()
+        assert enc.provide_output(small) == api.HYD_API_ERROR
+        assert enc.error_message() == "provided buffer must be at least 64 bytes long"
+        code, _ = enc.release_output()
+        assert code == api.HYD_API_ERROR and enc.error_message() == "buffer was never provided"
+        buf = (C.c_uint8 * 64)()
+        assert enc.provide_output(buf) == api.HYD_OK
+        assert enc.provide_output(buf) == api.HYD_API_ERROR and enc.error_message() == "buffer was already provided"
+        assert enc.provide_output_raw(None, 64) == api.HYD_API_ERROR
+        assert enc.flush() == api.HYD_OK  # one-frame mode before the last tile: no-op
+        code, n = enc.release_output()
+        assert (code, n) == (api.HYD_OK, 0)
+        assert enc.provide_output_raw(None, 128) == api.HYD_API_ERROR and enc.error_message() == "buffer may not be null"
+
+
+def test_send_tile_argument_errors_need_no_gpu(lib):
+    import numpy as np
+
+    img = np.zeros((8, 8, 3), np.uint8)
+    with api.Encoder(lib) as enc:
+        assert enc.set_metadata(8, 8) == api.HYD_OK
+        p = img.ctypes.data
+        assert enc.send_tile_ptrs([p, p + 1, p + 2], 0, 0, 24, 3, -1, 7) == api.HYD_API_ERROR
+        assert enc.error_message() == "Invalid Sample Format"
+        assert enc.send_tile_ptrs([p, p + 1, p + 2], 1, 0, 24, 3, -1, 0) == api.HYD_API_ERROR
+        assert enc.error_message() == "tile out of bounds"
+
+
+def test_icc_requires_one_frame_mode(lib):
+    with api.Encoder(lib) as enc:
+        assert enc.set_metadata(8, 8, 0, 0, 0) == api.HYD_OK
+        assert enc.set_icc(b"x" * 200) == api.HYD_API_ERROR
+        assert enc.error_message() == "one-frame mode required to set the suggested ICC profile"
+        assert enc.set_icc(None) == api.HYD_OK
+
+
+def test_without_a_gpu_the_product_fails_loudly(lib):
+    import numpy as np
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    img = np.zeros((8, 8, 3), np.uint8)
+    with pytest.raises(api.HydriumError) as ei:
+        api.encode_image(lib, img)
+    assert ei.value.code == api.HYD_INTERNAL_ERROR and "no CPU fallback" in ei.value.message

@@ -53,12 +53,18 @@ def cpu_baseline(host_img):
     h, w, _ = host_img.shape
     if refprobe.available():
         lib = refprobe.reference_library()
+        reps = 4
         t0 = time.perf_counter()
-        data = api.encode_image(lib, host_img)
-        dt = time.perf_counter() - t0
+        for _ in range(reps):
+            data = api.encode_image(lib, host_img)
+        dt = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        api.encode_image(refprobe.reference_library(optimised=True), host_img)
+        dt_o2 = time.perf_counter() - t0
         return {"value": round(w * h / dt / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "reference",
-                "sample": f"the whole {w}x{h} workload frame once through hyd_send_tile (gcc -Os build of the "
-                          f"reference sources, one-frame mode, {dt:.1f} s)",
+                "sample": f"the whole {w}x{h} workload frame, {reps} times through hyd_send_tile in one-frame mode "
+                          f"(reference sources built gcc -Os as shipped, {dt * reps:.1f} s of CPU work)",
+                "value_O2_build": round(w * h / dt_o2 / 1e6, 3),
                 "bytes": len(data), "md5": hashlib.md5(data).hexdigest()}
     from oracle import binding as orc
 

@@ -59,6 +59,9 @@ class Library:
             raise FileNotFoundError(
                 f"{path} not found - build it first (python -c 'import __graft_entry__ as g; g.build()')")
         self.path = path
+        from . import preload_hip_runtime
+
+        preload_hip_runtime()
         self.dll = C.CDLL(path)
         d = self.dll
         d.hyd_encoder_new.restype = C.c_void_p

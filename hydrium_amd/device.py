@@ -38,6 +38,9 @@ def dll(path: Optional[str] = None):
         p = path or api.DEFAULT_LIB
         if not os.path.exists(p):
             raise FileNotFoundError(f"{p} missing: the HIP extension is not built (there is no CPU fallback)")
+        from . import preload_hip_runtime
+
+        preload_hip_runtime()
         d = C.CDLL(p)
         vp, i, u, sz = C.c_void_p, C.c_int, C.c_uint, C.c_size_t
         d.hydamd_device_count.restype = i

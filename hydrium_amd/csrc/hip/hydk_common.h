@@ -34,7 +34,10 @@ typedef struct HydkTables {
     uint32_t freq[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];   /* normalised 12-bit frequencies (also read back by the host) */
     uint32_t fb[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];     /* freq | (cumulative base << 16) */
     uint32_t magic[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];  /* floor(2^32 / freq) (0xFFFFFFFF for freq 1) */
-    uint16_t inv[HYDK_MAX_CLUSTERS][HYDK_ANS_SLOTS];   /* (symbol, offset) -> alias-table slot, at base+offset */
+    /* (symbol, remainder) -> alias-table slot.  Symbol s owns entries [2*base, 2*base + 2*freq):
+     * the first freq hold slot(r); the second freq hold slot(r - freq) + 4096, so that the
+     * one-too-small quotient of the multiply-high division is repaired by the same lookup. */
+    uint16_t inv[HYDK_MAX_CLUSTERS][2 * HYDK_ANS_SLOTS];
     uint32_t alphabet[HYDK_MAX_CLUSTERS];              /* largest token + 1 seen per cluster */
     uint32_t log_alphabet_size;                        /* max(5, ceil log2 of the running max alphabet) */
     uint32_t running_max_alphabet;                     /* after this LF group, in send order */

@@ -678,7 +678,9 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
             s_err = 2;
             continue;
         }
-        tab->inv[c][s_base[c][sym] + off] = (uint16_t)slot;
+        const uint32_t at = 2u * s_base[c][sym] + off, f = s_freq[c][sym];
+        tab->inv[c][at] = (uint16_t)slot;
+        tab->inv[c][at + f] = (uint16_t)(slot + HYDK_ANS_SLOTS);
     }
     for (int idx = t; idx < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; idx += kThreads) {
         const int c = idx / HYDK_ALPHABET, k = idx % HYDK_ALPHABET;
@@ -713,12 +715,31 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
  * grid = 16 x LF groups, block = 256.
  * ======================================================================================== */
 constexpr int kWinWords = 100; /* 64 symbols x 46 bits = 92 words + alignment slack */
+constexpr int kInvEntries = HYDK_MAX_CLUSTERS * 2 * HYDK_ANS_SLOTS;
+
+/* one step of the recurrence for the symbol whose operands sit in lane `src` (wave-uniform) */
+#define HYDK_RANS_STEP(src)                                                                   \
+    do {                                                                                      \
+        const uint32_t fk = __builtin_amdgcn_readlane(f, (src));                              \
+        const uint32_t mk = __builtin_amdgcn_readlane(mg, (src));                             \
+        const uint32_t ak = __builtin_amdgcn_readlane(adr, (src));                            \
+        const uint32_t tk = __builtin_amdgcn_readlane(thr, (src));                            \
+        /* lane 0 <- state, lane l <- trail[l-1]: the states file past, newest in lane 0 */   \
+        trail = (uint32_t)__builtin_amdgcn_update_dpp((int)state, (int)trail, 0x138, 0xF, 0xF, false); \
+        const uint32_t x = state > tk ? state >> 16 : state;                                  \
+        /* q = mulhi(x, floor(2^32/f)) is floor(x/f) or one less, so r = x - q*f < 2f; the   \
+         * doubled table returns slot(r mod f) + 4096*(r >= f), which also repairs q */        \
+        const uint32_t q = __umulhi(x, mk);                                                   \
+        const uint32_t r = x - __umul24(q, fk);                                               \
+        const uint32_t ent = *(const uint16_t *)(inv_bytes + ak + 2u * r);                    \
+        state = (q << 12) + ent;                                                              \
+    } while (0)
 
 __global__ __launch_bounds__(kThreads) void k_rans_encode(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
                                                           const uint32_t *sym_count_all, const HydkTables *tabs,
                                                           uint32_t *bitbuf_all, uint32_t *group_bits_all,
                                                           int preset_bits) {
-    __shared__ uint16_t s_inv[HYDK_MAX_CLUSTERS * HYDK_ANS_SLOTS];   /* 72 KiB */
+    __shared__ uint16_t s_inv[kInvEntries];                          /* 144 KiB */
     __shared__ uint32_t s_fb[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
     __shared__ uint32_t s_magic[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
     __shared__ uint32_t s_win[4][kWinWords];
@@ -736,7 +757,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_encode(const HydkLfJob *__res
     {
         const uint4 *src = (const uint4 *)&tab->inv[0][0];
         uint4 *dst = (uint4 *)s_inv;
-        for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ANS_SLOTS / 8; i += kThreads)
+        for (int i = t; i < kInvEntries / 8; i += kThreads)
             dst[i] = src[i];
         for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads) {
             s_fb[i] = (&tab->fb[0][0])[i];
@@ -759,7 +780,10 @@ __global__ __launch_bounds__(kThreads) void k_rans_encode(const HydkLfJob *__res
 
     uint32_t cur = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u; /* stream start so far (absolute bit position) */
     uint32_t carry = 0;                                     /* content of the partly filled word at cur>>5 */
-    uint32_t state = 0x130000u + (uint32_t)(lane >> 6);     /* lane>>6 == 0: keeps the chain in vector registers */
+    uint32_t state;
+    /* keep the recurrence in vector registers: routed through the scalar unit, every LDS lookup
+     * would cost a v_mov + v_readfirstlane round trip on the critical path */
+    asm volatile("v_mov_b32 %0, 0x130000" : "=v"(state));
 
     /* wave-parallel emission of one (value, nbits) per lane, lane 0 nearest the already written
      * bits (= latest in stream order), lane 63 earliest */
@@ -816,26 +840,23 @@ __global__ __launch_bounds__(kThreads) void k_rans_encode(const HydkLfJob *__res
         const uint32_t fbv = s_fb[e];
         const uint32_t f = valid ? (fbv & 0xFFFFu) : 1u;
         const uint32_t mg = s_magic[e];
-        const uint32_t adr = (((lo >> 8) & 0xF) * HYDK_ANS_SLOTS + (fbv >> 16)) * 2u;
+        const uint32_t adr = (((lo >> 8) & 0xF) * (2u * HYDK_ANS_SLOTS) + 2u * (fbv >> 16)) * 2u;
         /* (state >> 20) >= f  <=>  state > (f << 20) - 1, exact for f up to 4096 (entropy.c:1092) */
         const uint32_t thr = (uint32_t)(((unsigned long long)f << 20) - 1ull);
         const int cnt = min(64, hi_p + 1);
-        uint32_t seen = 0;
-        for (int k = 0; k < cnt; k++) {
-            const uint32_t fk = __builtin_amdgcn_readlane(f, k);
-            const uint32_t mk = __builtin_amdgcn_readlane(mg, k);
-            const uint32_t ak = __builtin_amdgcn_readlane(adr, k);
-            const uint32_t tk = __builtin_amdgcn_readlane(thr, k);
-            seen = lane == k ? state : seen;
-            const uint32_t x = state > tk ? state >> 16 : state;
-            /* exact x / f: mulhi(x, floor(2^32/f)) is the quotient or one less for any x < 2^32 */
-            uint32_t q = __umulhi(x, mk);
-            const uint32_t r0 = x - __umul24(q, fk);
-            const uint32_t r = min(r0, r0 - fk);
-            q += r0 >= fk;
-            const uint32_t slot_v = *(const uint16_t *)(inv_bytes + ak + 2u * r);
-            state = (q << 12) | slot_v;
+        uint32_t trail = 0;
+        if (cnt == 64) {
+            for (int k = 0; k < 64; k += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    HYDK_RANS_STEP(k + u);
+            }
+        } else {
+            for (int k = 0; k < cnt; k++)
+                HYDK_RANS_STEP(k);
         }
+        /* the state seen by step j now sits in lane cnt-1-j; give it back to lane j */
+        const uint32_t seen = (uint32_t)__shfl((int)trail, (cnt - 1 - lane) & 63);
         /* refill p is written just before residue p (entropy.c:1134-1147), i.e. prepended after it */
         const uint32_t rbits = valid ? (lo >> 16) & 0x3Fu : 0u;
         const bool refill = valid && seen > thr;
@@ -862,6 +883,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_encode(const HydkLfJob *__res
         group_bits_all[G] = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u - cur;
     }
 }
+#undef HYDK_RANS_STEP
 
 /* ==========================================================================================
  * K3b: section sizes -> offsets (single block), then pack each section to its byte offset.

@@ -206,11 +206,22 @@ struct SampleOf<HYDK_FMT_F32> {
 
 /* ==========================================================================================
  * K1: fused transform + tokenise.  grid = 64 group slots per LF group x LF groups of the frame,
- * block = 256 threads (4 waves); one 256x256 group per workgroup.
+ * block = 256 threads (4 waves); one 256x256 group per workgroup, walked as 32 strips of 8 rows.
+ *
+ * Per strip (32 varblocks x 3 channels):
+ *   A  thread (row r, block b): 8 pixels -> XYB in registers -> three 8-point row DCTs -> LDS
+ *   B  thread (block cb, horizontal frequency kh): three 8-point column DCTs, quantisation; the
+ *      24 quantised coefficients stay in registers; 8-lane OR gives the block's non-zero bitmap
+ *   C1 one wave prefix-sums the 96 per-(block, channel) symbol counts
+ *   C2 the SAME threads emit the symbols of the coefficients they hold: position inside the
+ *      block's run is the zig-zag index, contexts come from the bitmap by popcount
+ * Token order inside a group is block raster, channels Y, X, B (encoder.c:707-745), which the
+ * strip order + prefix sum reproduces.  The next strip's pixels are in flight during B and C.
  * ======================================================================================== */
 template <int FMT, bool LUTS>
-__global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
+__global__ __launch_bounds__(kThreads, 2) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
     typedef typename SampleOf<FMT>::type sample_t;
+    constexpr int kWords = FMT == HYDK_FMT_U8 ? 6 : 12; /* dwords holding 8 packed RGB pixels */
     const HydkLfJob job = jobs[blockIdx.x >> 6];
     if (job.fmt != FMT || (job.use_luts != 0) != LUTS)
         return; /* another template instance of this launch round owns this LF group */
@@ -218,11 +229,11 @@ __global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob
         return;
 
     __shared__ float s_rowpass[3 * kS0Chan];          /* [c][block][y][kh], 27.0 KiB */
-    __shared__ int32_t s_quant[96 * kQPitch];         /* [block*3 + c][zig-zag j], 24.4 KiB */
-    __shared__ unsigned long long s_mask[96];         /* non-zero bitmap per (block, c), bit j */
-    __shared__ uint32_t s_off[97];                    /* exclusive symbol offsets per emission slot + total */
+    __shared__ uint32_t s_cnt[96];                    /* symbols per emission slot e = 3*block + visit */
+    __shared__ uint32_t s_off[97];                    /* their exclusive prefix sums + strip total */
     __shared__ uint32_t s_hist[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
     __shared__ uint16_t s_lut8[256];
+    __shared__ uint8_t s_nnz3[64];                    /* coefficient-count context offset, mod 3 and in full */
     __shared__ uint8_t s_nnz[64];
 
     const int t = threadIdx.x;
@@ -238,26 +249,30 @@ __global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob
         s_hist[i] = 0;
     if (FMT == HYDK_FMT_U8)
         s_lut8[t] = job.in_lut8[t];
-    if (t < 64)
+    if (t < 64) {
         s_nnz[t] = kNnzCtx[t];
+        s_nnz3[t] = kNnzCtx[t] % 3;
+    }
+    if (t < 96)
+        s_cnt[t] = 0;
 
-    /* per-thread constants of the column pass: thread (block cb, horizontal frequency kh) */
+    /* per-thread constants of the column / token phases: thread (block cb, horizontal frequency kh)
+     * owns the coefficients (kv, kh), kv = 0..7, whose zig-zag indices are zz[kv] */
     const int cb = t >> 3, kh = t & 7;
-    int zz[8];
+    int zz[8], fctx[8];
     float wq[3][8];
 #pragma unroll
     for (int kv = 0; kv < 8; kv++) {
-        zz[kv] = kZigzag[kv][kh];
+        const int j = kZigzag[kv][kh];
+        zz[kv] = j;
+        /* frequency context of zig-zag position j (encoder.c:53-58) */
+        fctx[kv] = j < 2 ? 0 : j < 16 ? j - 1 : j < 32 ? 15 + ((j - 16) >> 1) : 23 + ((j - 32) >> 2);
 #pragma unroll
         for (int c = 0; c < 3; c++)
-            wq[c][kv] = (float)kQuantWeight[c][zz[kv]];
+            wq[c][kv] = (float)kQuantWeight[c][j];
     }
-    /* per-lane constant of the token phase: frequency context of coefficient j = lane (encoder.c:53-58) */
-    const int freq_ctx = lane < 2 ? 0 : lane < 16 ? lane - 1 : lane < 32 ? 15 + ((lane - 16) >> 1) : 23 + ((lane - 32) >> 2);
-
-    /* clusters holding coefficient contexts, by scheme (encoder.c:862-901) */
+    /* first cluster holding coefficient contexts, by scheme (encoder.c:862-901) */
     const int coef_cl_lo = job.scheme == 0 ? 3 : job.scheme == 3 ? 0 : 1;
-    const int coef_cl_hi = job.scheme == 0 ? 8 : job.scheme == 1 ? 2 : job.scheme == 2 ? 1 : 0;
 
     const bool packed = job.pixel_stride == 3 &&
                         (const char *)job.src[1] == (const char *)job.src[0] + sizeof(sample_t) &&
@@ -265,31 +280,45 @@ __global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob
                         (((uintptr_t)job.src[0] | (uintptr_t)(job.row_stride * (long long)sizeof(sample_t))) & 3) == 0 &&
                         FMT != HYDK_FMT_F32;
 
+    /* phase-A role of this thread: row ar of block ab */
+    const int ar = t >> 5, ab = t & 31;
+    const bool fast = packed && ab < gbw && ab * 8 + 8 <= gw; /* whole block row comes as aligned dwords */
+    uint32_t nxt[kWords];
+#pragma unroll
+    for (int k = 0; k < kWords; k++)
+        nxt[k] = 0;
+    auto prefetch = [&](int s) {
+        if (fast && s * 8 + ar < gh) {
+            const uint32_t *p = (const uint32_t *)((const char *)job.src[0] +
+                                                   ((long long)(py0 + s * 8 + ar) * job.row_stride +
+                                                    (long long)(px0 + ab * 8) * 3) * (long long)sizeof(sample_t));
+#pragma unroll
+            for (int k = 0; k < kWords; k++)
+                nxt[k] = p[k];
+        }
+    };
+    prefetch(0);
+
     uint64_t *const tok = job.tokens + (size_t)g * HYDK_TOKENS_PER_GROUP;
     uint32_t goff = 0;
+    unsigned long long zero_tokens = 0; /* six 10-bit counters: zero-valued coefficient tokens per cluster */
     bool bad_sample = false;
     __syncthreads();
 
     for (int s = 0; s < gbh; s++) {
-        /* ---------------- phase A: load 8 px of one block row, XYB, row DCT ---------------- */
-        {
-            const int r = t >> 5, b = t & 31;
-            if (b < gbw) {
-                float xv[8], yv[8], bv[8];
-                const int y = py0 + s * 8 + r;        /* row inside the LF group */
-                const int x0 = px0 + b * 8;
-                const bool row_ok = s * 8 + r < gh;
-                const int nvalid = row_ok ? min(8, gw - b * 8) : 0;
-                if (nvalid == 8 && packed) {
-                    /* 24 interleaved samples = 6 (u8) or 12 (u16) aligned dwords */
-                    constexpr int kWords = FMT == HYDK_FMT_U8 ? 6 : 12;
-                    const uint32_t *p = (const uint32_t *)((const char *)job.src[0] +
-                                                           ((long long)y * job.row_stride + (long long)x0 * 3) *
-                                                               (long long)sizeof(sample_t));
-                    uint32_t w[kWords];
+        /* ---------------- phase A: 8 px of one block row -> XYB -> row DCT ---------------- */
+        if (ab < gbw) {
+            float xv[8], yv[8], bv[8];
+            const int y = py0 + s * 8 + ar; /* row inside the LF group */
+            const int x0 = px0 + ab * 8;
+            const bool row_ok = s * 8 + ar < gh;
+            if (fast) {
+                uint32_t w[kWords];
 #pragma unroll
-                    for (int k = 0; k < kWords; k++)
-                        w[k] = p[k];
+                for (int k = 0; k < kWords; k++)
+                    w[k] = nxt[k];
+                prefetch(s + 1);
+                if (row_ok) {
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         uint32_t rgb[3];
@@ -307,58 +336,65 @@ __global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        xv[i] = yv[i] = bv[i] = 0.0f; /* edge padding is XYB = 0 (format.c:182-191) */
-                        if (i < nvalid) {
-                            const long long off = (long long)y * job.row_stride + (long long)(x0 + i) * job.pixel_stride;
-                            const sample_t sr = ((const sample_t *)job.src[0])[off];
-                            const sample_t sg = ((const sample_t *)job.src[1])[off];
-                            const sample_t sb = ((const sample_t *)job.src[2])[off];
-                            if (FMT == HYDK_FMT_F32) {
-                                if (!lms_mix_f32((float)sr, (float)sg, (float)sb, job.linear_light, xv[i], yv[i], bv[i]))
-                                    bad_sample = true;
-                            } else {
-                                uint32_t rgb[3] = {(uint32_t)sr, (uint32_t)sg, (uint32_t)sb};
+                    for (int i = 0; i < 8; i++)
+                        xv[i] = yv[i] = bv[i] = 0.0f;
+                }
+            } else {
+                const int nvalid = row_ok ? min(8, gw - ab * 8) : 0;
 #pragma unroll
-                                for (int ch = 0; ch < 3; ch++) {
-                                    if (FMT == HYDK_FMT_U8)
-                                        rgb[ch] = s_lut8[rgb[ch]];
-                                    else
-                                        rgb[ch] = LUTS ? job.in_lut16[rgb[ch]] : input_lut16_eval(rgb[ch], job.linear_light);
-                                }
-                                lms_mix_u16<LUTS>(rgb[0], rgb[1], rgb[2], job.bias_lut, xv[i], yv[i], bv[i]);
+                for (int i = 0; i < 8; i++) {
+                    xv[i] = yv[i] = bv[i] = 0.0f; /* edge padding is XYB = 0 (format.c:182-191) */
+                    if (i < nvalid) {
+                        const long long off = (long long)y * job.row_stride + (long long)(x0 + i) * job.pixel_stride;
+                        const sample_t sr = ((const sample_t *)job.src[0])[off];
+                        const sample_t sg = ((const sample_t *)job.src[1])[off];
+                        const sample_t sb = ((const sample_t *)job.src[2])[off];
+                        if (FMT == HYDK_FMT_F32) {
+                            if (!lms_mix_f32((float)sr, (float)sg, (float)sb, job.linear_light, xv[i], yv[i], bv[i]))
+                                bad_sample = true;
+                        } else {
+                            uint32_t rgb[3] = {(uint32_t)sr, (uint32_t)sg, (uint32_t)sb};
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++) {
+                                if (FMT == HYDK_FMT_U8)
+                                    rgb[ch] = s_lut8[rgb[ch]];
+                                else
+                                    rgb[ch] = LUTS ? job.in_lut16[rgb[ch]] : input_lut16_eval(rgb[ch], job.linear_light);
                             }
+                            lms_mix_u16<LUTS>(rgb[0], rgb[1], rgb[2], job.bias_lut, xv[i], yv[i], bv[i]);
                         }
                     }
                 }
-                if (job.dbg_xyb) {
-                    float *d = job.dbg_xyb + (size_t)y * kDbgPitch + x0;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        d[i] = xv[i];
-                        d[(size_t)kDbgPitch * kDbgPitch + i] = yv[i];
-                        d[(size_t)2 * kDbgPitch * kDbgPitch + i] = bv[i];
-                    }
-                }
-                float o[8];
-                float *dst = s_rowpass + b * kS0Block + r * 8;
-                dct8(xv, o);
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    dst[k] = o[k];
-                dct8(yv, o);
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    dst[kS0Chan + k] = o[k];
-                dct8(bv, o);
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    dst[2 * kS0Chan + k] = o[k];
             }
+            if (job.dbg_xyb) {
+                float *d = job.dbg_xyb + (size_t)y * kDbgPitch + x0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    d[i] = xv[i];
+                    d[(size_t)kDbgPitch * kDbgPitch + i] = yv[i];
+                    d[(size_t)2 * kDbgPitch * kDbgPitch + i] = bv[i];
+                }
+            }
+            float o[8];
+            float *dst = s_rowpass + ab * kS0Block + ar * 8;
+            dct8(xv, o);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                dst[k] = o[k];
+            dct8(yv, o);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                dst[kS0Chan + k] = o[k];
+            dct8(bv, o);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                dst[2 * kS0Chan + k] = o[k];
         }
         __syncthreads();
 
-        /* ---------------- phase B: column DCT, quantise, LF ints, non-zero bitmap ---------------- */
+        /* ---------------- phase B: column DCT, quantise, LF ints, non-zero bitmaps ---------------- */
+        int q[3][8];
+        unsigned long long msk[3];
         if (cb < gbw) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -378,32 +414,33 @@ __global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob
                         d[kv] = v[kv];
                 }
                 unsigned long long m = 0;
-                int32_t *qrow = s_quant + (cb * 3 + c) * kQPitch;
-                int qv[8];
 #pragma unroll
                 for (int kv = 0; kv < 8; kv++) {
                     /* encoder.c:808-811: trunc((coef * weight) * 5); +-1 is the dead zone */
-                    int q = (int)(v[kv] * wq[c][kv] * 5.0f);
-                    if (q > -2 && q < 2)
-                        q = 0;
+                    int qq = (int)(v[kv] * wq[c][kv] * 5.0f);
+                    if (qq > -2 && qq < 2)
+                        qq = 0;
                     if (kv == 0 && kh == 0)
-                        q = 0; /* the DC slot is coded by the LF path */
-                    qv[kv] = q;
-                    qrow[zz[kv]] = q;
-                    m |= (unsigned long long)(q != 0) << zz[kv];
+                        qq = 0; /* the DC slot is coded by the LF path */
+                    q[c][kv] = qq;
+                    m |= (unsigned long long)(qq != 0) << zz[kv];
                 }
                 if (job.dbg_quant) {
                     int32_t *d = job.dbg_quant + (size_t)c * kDbgPitch * kDbgPitch +
                                  (size_t)(py0 + s * 8 + kh) * kDbgPitch + px0 + cb * 8;
 #pragma unroll
                     for (int kv = 0; kv < 8; kv++)
-                        d[kv] = qv[kv];
+                        d[kv] = q[c][kv];
                 }
                 m |= __shfl_xor(m, 1);
                 m |= __shfl_xor(m, 2);
                 m |= __shfl_xor(m, 4);
+                msk[c] = m;
                 if (kh == 0) {
-                    s_mask[cb * 3 + c] = m;
+                    /* emission slot: visit order Y, X, B (encoder.c:712); symbols = count symbol +
+                     * coefficients up to the last non-zero one */
+                    const int visit = c == 1 ? 0 : c == 0 ? 1 : 2;
+                    s_cnt[cb * 3 + visit] = 1u + (m ? 63u - (uint32_t)__clzll(m) : 0u);
                     /* LF int: trunc(dc * shift[c]) (encoder.c:573,582) */
                     job.dc[(size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH + (size_t)((py0 >> 3) + s) * HYDK_DC_PITCH +
                            (px0 >> 3) + cb] = (int32_t)(v[0] * kLfShift[c]);
@@ -412,22 +449,10 @@ __global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob
         }
         __syncthreads();
 
-        /* ---------------- phase C1: symbols per (block, visit) and their offsets ---------------- */
+        /* ---------------- phase C1: offsets of the 96 emission slots ---------------- */
         if (wave == 0) {
-            /* emission slot e = 3*block + visit, visit order Y, X, B (encoder.c:712) */
-            uint32_t cnt[2];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int e = lane + 64 * h;
-                cnt[h] = 0;
-                if (e < 3 * gbw) {
-                    const int b = e / 3, visit = e - 3 * b;
-                    const int c = visit < 2 ? 1 - visit : 2;
-                    const unsigned long long m = s_mask[b * 3 + c];
-                    cnt[h] = 1 + (m ? 63 - __clzll(m) : 0); /* count symbol + coefficients up to the last non-zero */
-                }
-            }
-            uint32_t inc0 = cnt[0], inc1 = cnt[1];
+            const uint32_t c0 = s_cnt[lane], c1 = lane < 32 ? s_cnt[64 + lane] : 0u;
+            uint32_t inc0 = c0, inc1 = c1;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t a = __shfl_up(inc0, d), b2 = __shfl_up(inc1, d);
@@ -437,70 +462,82 @@ __global__ __launch_bounds__(kThreads) void k_transform_tokenize(const HydkLfJob
                 }
             }
             const uint32_t total0 = __shfl(inc0, 63);
-            s_off[lane] = inc0 - cnt[0];
+            s_off[lane] = inc0 - c0;
             if (lane < 32)
-                s_off[64 + lane] = total0 + inc1 - cnt[1];
+                s_off[64 + lane] = total0 + inc1 - c1;
             if (lane == 31)
                 s_off[96] = total0 + inc1;
         }
         __syncthreads();
 
-        /* ---------------- phase C2: one wave per (block, visit), lane j = zig-zag coefficient j ---------------- */
-        for (int e = wave; e < 3 * gbw; e += 4) {
-            const int b = e / 3, visit = e - 3 * b;
-            const int c = visit < 2 ? 1 - visit : 2;
-            const unsigned long long m = s_mask[b * 3 + c];
-            const int nz_total = __popcll(m);
-            const int jlast = m ? 63 - __clzll(m) : 0;
-            const int j = lane;
-            const bool active = j <= jlast;
-            uint32_t value;
-            int cluster;
-            if (j == 0) {
-                /* non-zero count; its context only matters through the cluster, which depends on
-                 * the visit index alone in every scheme (encoder.c:715,865-869,882,895,900) */
-                value = (uint32_t)nz_total;
-                cluster = job.scheme == 0 ? visit : 0;
-            } else {
-                const int q = active ? s_quant[(b * 3 + c) * kQPitch + j] : 0;
-                value = pack_signed(q);
-                /* non-zeros still to come before this coefficient (encoder.c:732,738) */
-                const int remaining = nz_total - __popcll(m & ((1ull << j) - 1ull));
-                const int prev = j == 1 ? (nz_total <= 4) : (int)((m >> (j - 1)) & 1ull);
-                /* context - 111 = 458*visit + prev + 2*(nnz_ctx[remaining] + freq_ctx[j]) (encoder.c:724,731-732) */
-                const int x = 458 * visit + prev + 2 * ((int)s_nnz[remaining & 63] + freq_ctx);
-                cluster = job.scheme == 0 ? 3 + x % 6 : job.scheme == 1 ? 1 + (x & 1) : job.scheme == 2 ? 1 : 0;
+        /* ---------------- phase C2: every thread emits the symbols of its own coefficients ---------------- */
+        if (cb < gbw) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int visit = c == 1 ? 0 : c == 0 ? 1 : 2;
+                const unsigned long long m = msk[c];
+                const int nz_total = __popcll(m);
+                const int jlast = m ? 63 - __clzll(m) : 0;
+                uint64_t *const dst = tok + goff + s_off[cb * 3 + visit];
+#pragma unroll
+                for (int kv = 0; kv < 8; kv++) {
+                    const int j = zz[kv];
+                    if (j > jlast)
+                        continue;
+                    uint32_t value;
+                    int cluster;
+                    if (kv == 0 && kh == 0) {
+                        /* j == 0: the non-zero count.  Its context only matters through the cluster, which
+                         * depends on the visit index alone in every scheme (encoder.c:715,865-869,882,895,900) */
+                        value = (uint32_t)nz_total;
+                        cluster = job.scheme == 0 ? visit : 0;
+                    } else {
+                        value = pack_signed(q[c][kv]);
+                        /* non-zeros still to come before this coefficient (encoder.c:732,738) */
+                        const int remaining = nz_total - __popcll(m & ((1ull << j) - 1ull));
+                        const int prev = j == 1 ? (nz_total <= 4) : (int)((m >> (j - 1)) & 1ull);
+                        /* context - 111 = 458*visit + prev + 2*(nnz_ctx[remaining] + freq_ctx[j]) (encoder.c:724,731-732);
+                         * scheme 0 needs it mod 6 = prev + 2*((visit + nnz_ctx + freq_ctx) mod 3), the others mod 2 = prev */
+                        if (job.scheme == 0) {
+                            const int u = visit + (int)s_nnz3[remaining & 63] + fctx[kv] % 3; /* 0..6 */
+                            cluster = 3 + prev + 2 * (u - 3 * ((u * 11) >> 5));
+                        } else {
+                            cluster = job.scheme == 1 ? 1 + prev : job.scheme == 2 ? 1 : 0;
+                        }
+                    }
+                    /* hybrid-uint split, config (4,1,0) (entropy.c:427-444) */
+                    uint32_t token, rbits, residue;
+                    if (value < 16) {
+                        token = value;
+                        rbits = 0;
+                        residue = 0;
+                    } else {
+                        const int n = 30 - __clz((int)value); /* floor(log2) - 1 */
+                        rbits = (uint32_t)n;
+                        residue = value & ((1u << n) - 1u);
+                        token = 16u + (((uint32_t)(n - 3) << 1) | ((value >> n) & 1u));
+                    }
+                    dst[j] = ((uint64_t)residue << 32) | HYDK_REC_LO(token, cluster, rbits);
+                    if (token == 0 && !(kv == 0 && kh == 0))
+                        zero_tokens += 1ull << (10 * (cluster - coef_cl_lo)); /* at most 24 x 32 per thread and group */
+                    else
+                        atomicAdd(&s_hist[cluster * HYDK_ALPHABET + token], 1u);
+                }
             }
-            /* hybrid-uint split, config (4,1,0) (entropy.c:427-444) */
-            uint32_t token, rbits, residue;
-            if (value < 16) {
-                token = value;
-                rbits = 0;
-                residue = 0;
-            } else {
-                const int n = 30 - __clz((int)value); /* floor(log2) - 1 */
-                rbits = (uint32_t)n;
-                residue = value & ((1u << n) - 1u);
-                token = 16u + (((uint32_t)(n - 3) << 1) | ((value >> n) & 1u));
-            }
-            if (active)
-                tok[goff + s_off[e] + j] = ((uint64_t)residue << 32) | HYDK_REC_LO(token, cluster, rbits);
-
-            /* histogram: zero tokens of coefficient lanes are counted per cluster with one ballot
-             * each (they dominate and would serialise as same-address LDS atomics) */
-            const bool zero_coef = active && j > 0 && token == 0;
-            for (int cl = coef_cl_lo; cl <= coef_cl_hi; cl++) {
-                const unsigned long long bm = __ballot(zero_coef && cluster == cl);
-                if (lane == 0 && bm)
-                    atomicAdd(&s_hist[cl * HYDK_ALPHABET], (uint32_t)__popcll(bm));
-            }
-            if (active && !zero_coef)
-                atomicAdd(&s_hist[cluster * HYDK_ALPHABET + token], 1u);
         }
         goff += s_off[96];
-        __syncthreads();
+        /* no barrier here: s_off is rewritten only after the next strip's two barriers, s_cnt
+         * after its first, s_rowpass is last read before this strip's second barrier */
     }
+    __syncthreads();
 
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint32_t n0 = (uint32_t)(zero_tokens >> (10 * k)) & 1023u;
+        if (n0)
+            atomicAdd(&s_hist[(coef_cl_lo + k) * HYDK_ALPHABET], n0);
+    }
+    __syncthreads();
     uint32_t top_token = 0;
     for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads) {
         const uint32_t v = s_hist[i];

@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=16, choices=(8, 16))
     ap.add_argument("--kind", default="photo")
     ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--rans-waves", type=int, default=4, choices=(4, 8, 16))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
     return ap.parse_args()
@@ -101,6 +102,8 @@ def main():
     torch.cuda.synchronize()
     lfg = (-(-W // 2048)) * (-(-H // 2048))
     ctxs = [device.DeviceContext(local, lfg, 0) for _ in range(max(1, args.streams))]
+    for c in ctxs:
+        c.set_rans_waves(args.rans_waves)
 
     def step(i):
         ctx = ctxs[i % len(ctxs)]
@@ -168,7 +171,7 @@ def main():
                                    "hot path device-resident RGB -> packed HF group sections "
                                    "(XYB, DCT, quantise, tokenise, ANS tables, rANS, pack)",
                        "groups": lfg * 64 if W % 2048 == 0 and H % 2048 == 0 else None, "lf_groups": lfg,
-                       "streams": len(ctxs), "parallelism": f"{world} x (one frame per GPU)" +
+                       "streams": len(ctxs), "rans_groups_per_workgroup": args.rans_waves, "parallelism": f"{world} x (one frame per GPU)" +
                                                             (", RCCL all-gather of sections" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

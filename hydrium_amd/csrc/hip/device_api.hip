@@ -32,7 +32,8 @@ hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int num_slots,
                          hipStream_t stream);
 hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
-                       uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, hipStream_t stream);
+                       uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int waves,
+                       hipStream_t stream);
 hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, hipStream_t stream);
 hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
                        int count, hipStream_t stream);
@@ -70,6 +71,7 @@ struct HydAmdContext {
     int linear_light = 0;
     int use_luts = 1;
     int register_luts_ok = 0;
+    int rans_waves = 4;             /* groups per rANS workgroup: 4 (latency) .. 16 (throughput) */
     unsigned num_presets = 1;
     int scheme = 0;
     int nclusters = 9;
@@ -416,6 +418,11 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     (void)hipFree(mism);
     ctx->register_luts_ok = h_mism == 0;
     ctx->use_luts = !ctx->register_luts_ok;
+    if (const char *env = getenv("HYDAMD_RANS_WAVES")) {
+        const int w = atoi(env);
+        if (w == 4 || w == 8 || w == 16)
+            ctx->rans_waves = w;
+    }
     if (const char *env = getenv("HYDAMD_FORCE_LUTS"))
         ctx->use_luts = atoi(env) != 0 || !ctx->register_luts_ok;
     return ST_OK;
@@ -468,6 +475,15 @@ int hydamd_force_luts(HydAmdContext *ctx, int use_luts) {
     if (!use_luts && !ctx->register_luts_ok)
         return fail(ctx, ST_INTERNAL_ERROR, "register LUT evaluation failed its self-test on this device");
     ctx->use_luts = use_luts != 0;
+    return ST_OK;
+}
+
+int hydamd_set_rans_waves(HydAmdContext *ctx, int waves) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (waves != 4 && waves != 8 && waves != 16)
+        return fail(ctx, ST_API_ERROR, "rANS workgroups hold 4, 8 or 16 groups");
+    ctx->rans_waves = waves;
     return ST_OK;
 }
 
@@ -583,7 +599,7 @@ int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
     {
         ScopedTimer timer(ctx, HYDAMD_K_RANS);
         HIP_TRY(ctx, hydk::launch_rans(ctx->d_jobs, ctx->tokens, ctx->sym_count, ctx->tables, ctx->bitbuf,
-                                       ctx->group_bits, ctx->preset_bits, num_slots, ctx->stream));
+                                       ctx->group_bits, ctx->preset_bits, num_slots, ctx->rans_waves, ctx->stream));
     }
     {
         ScopedTimer timer(ctx, HYDAMD_K_PACK);

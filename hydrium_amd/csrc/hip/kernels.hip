@@ -219,7 +219,7 @@ struct SampleOf<HYDK_FMT_F32> {
  * strip order + prefix sum reproduces.  The next strip's pixels are in flight during B and C.
  * ======================================================================================== */
 template <int FMT, bool LUTS>
-__global__ __launch_bounds__(kThreads, 2) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
+__global__ __launch_bounds__(kThreads, 3) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
     typedef typename SampleOf<FMT>::type sample_t;
     constexpr int kWords = FMT == HYDK_FMT_U8 ? 6 : 12; /* dwords holding 8 packed RGB pixels */
     const HydkLfJob job = jobs[blockIdx.x >> 6];
@@ -233,8 +233,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_transform_tokenize(const HydkLf
     __shared__ uint32_t s_off[97];                    /* their exclusive prefix sums + strip total */
     __shared__ uint32_t s_hist[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
     __shared__ uint16_t s_lut8[256];
-    __shared__ uint8_t s_nnz3[64];                    /* coefficient-count context offset, mod 3 and in full */
-    __shared__ uint8_t s_nnz[64];
+    __shared__ uint8_t s_nnz3[64];                    /* coefficient-count context offset (encoder.c:60-66) mod 3 */
+    __shared__ uint8_t s_fc3[64];                     /* frequency context of zig-zag position j (encoder.c:53-58) mod 3 */
+    __shared__ uint8_t s_zz[64];                      /* zig-zag index of coefficient (kv, kh) at [kv*8 + kh] */
+    __shared__ float s_wq[3 * 64];                    /* quantisation weight by channel and zig-zag index */
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -250,27 +252,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_transform_tokenize(const HydkLf
     if (FMT == HYDK_FMT_U8)
         s_lut8[t] = job.in_lut8[t];
     if (t < 64) {
-        s_nnz[t] = kNnzCtx[t];
+        const int j = t;
         s_nnz3[t] = kNnzCtx[t] % 3;
+        s_fc3[t] = (uint8_t)((j < 2 ? 0 : j < 16 ? j - 1 : j < 32 ? 15 + ((j - 16) >> 1) : 23 + ((j - 32) >> 2)) % 3);
+        s_zz[t] = kZigzag[t >> 3][t & 7];
     }
+    if (t < 192)
+        s_wq[t] = (float)kQuantWeight[t >> 6][t & 63];
     if (t < 96)
         s_cnt[t] = 0;
 
-    /* per-thread constants of the column / token phases: thread (block cb, horizontal frequency kh)
-     * owns the coefficients (kv, kh), kv = 0..7, whose zig-zag indices are zz[kv] */
+    /* column / token phases: thread (block cb, horizontal frequency kh) owns the coefficients
+     * (kv, kh), kv = 0..7, whose zig-zag indices are s_zz[kv*8 + kh]; the small per-coefficient
+     * constants live in LDS rather than in 40 registers, which buys a third wave per SIMD */
     const int cb = t >> 3, kh = t & 7;
-    int zz[8], fctx[8];
-    float wq[3][8];
-#pragma unroll
-    for (int kv = 0; kv < 8; kv++) {
-        const int j = kZigzag[kv][kh];
-        zz[kv] = j;
-        /* frequency context of zig-zag position j (encoder.c:53-58) */
-        fctx[kv] = j < 2 ? 0 : j < 16 ? j - 1 : j < 32 ? 15 + ((j - 16) >> 1) : 23 + ((j - 32) >> 2);
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-            wq[c][kv] = (float)kQuantWeight[c][j];
-    }
     /* first cluster holding coefficient contexts, by scheme (encoder.c:862-901) */
     const int coef_cl_lo = job.scheme == 0 ? 3 : job.scheme == 3 ? 0 : 1;
 
@@ -416,14 +411,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_transform_tokenize(const HydkLf
                 unsigned long long m = 0;
 #pragma unroll
                 for (int kv = 0; kv < 8; kv++) {
+                    const int j = s_zz[kv * 8 + kh];
                     /* encoder.c:808-811: trunc((coef * weight) * 5); +-1 is the dead zone */
-                    int qq = (int)(v[kv] * wq[c][kv] * 5.0f);
+                    int qq = (int)(v[kv] * s_wq[c * 64 + j] * 5.0f);
                     if (qq > -2 && qq < 2)
                         qq = 0;
                     if (kv == 0 && kh == 0)
                         qq = 0; /* the DC slot is coded by the LF path */
                     q[c][kv] = qq;
-                    m |= (unsigned long long)(qq != 0) << zz[kv];
+                    m |= (unsigned long long)(qq != 0) << j;
                 }
                 if (job.dbg_quant) {
                     int32_t *d = job.dbg_quant + (size_t)c * kDbgPitch * kDbgPitch +
@@ -481,7 +477,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_transform_tokenize(const HydkLf
                 uint64_t *const dst = tok + goff + s_off[cb * 3 + visit];
 #pragma unroll
                 for (int kv = 0; kv < 8; kv++) {
-                    const int j = zz[kv];
+                    const int j = s_zz[kv * 8 + kh];
                     if (j > jlast)
                         continue;
                     uint32_t value;
@@ -499,7 +495,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_transform_tokenize(const HydkLf
                         /* context - 111 = 458*visit + prev + 2*(nnz_ctx[remaining] + freq_ctx[j]) (encoder.c:724,731-732);
                          * scheme 0 needs it mod 6 = prev + 2*((visit + nnz_ctx + freq_ctx) mod 3), the others mod 2 = prev */
                         if (job.scheme == 0) {
-                            const int u = visit + (int)s_nnz3[remaining & 63] + fctx[kv] % 3; /* 0..6 */
+                            const int u = visit + (int)s_nnz3[remaining & 63] + (int)s_fc3[j]; /* 0..6 */
                             cluster = 3 + prev + 2 * (u - 3 * ((u * 11) >> 5));
                         } else {
                             cluster = job.scheme == 1 ? 1 + prev : job.scheme == 2 ? 1 : 0;
@@ -757,7 +753,7 @@ constexpr int kInvEntries = HYDK_MAX_CLUSTERS * 2 * HYDK_ANS_SLOTS;
 /* one step of the recurrence for the symbol whose operands sit in lane `src` (wave-uniform) */
 #define HYDK_RANS_STEP(src)                                                                   \
     do {                                                                                      \
-        const uint32_t fk = __builtin_amdgcn_readlane(f, (src));                              \
+        const int n2 = __builtin_amdgcn_readlane(neg2f, (src));                               \
         const uint32_t mk = __builtin_amdgcn_readlane(mg, (src));                             \
         const uint32_t ak = __builtin_amdgcn_readlane(adr, (src));                            \
         const uint32_t tk = __builtin_amdgcn_readlane(thr, (src));                            \
@@ -765,27 +761,32 @@ constexpr int kInvEntries = HYDK_MAX_CLUSTERS * 2 * HYDK_ANS_SLOTS;
         trail = (uint32_t)__builtin_amdgcn_update_dpp((int)state, (int)trail, 0x138, 0xF, 0xF, false); \
         const uint32_t x = state > tk ? state >> 16 : state;                                  \
         /* q = mulhi(x, floor(2^32/f)) is floor(x/f) or one less, so r = x - q*f < 2f; the   \
-         * doubled table returns slot(r mod f) + 4096*(r >= f), which also repairs q */        \
+         * doubled table returns slot(r mod f) + 4096*(r >= f), which also repairs q.  The    \
+         * byte address adr + 2r is formed as (adr + 2x) + q*(-2f): one op after the mulhi */  \
         const uint32_t q = __umulhi(x, mk);                                                   \
-        const uint32_t r = x - __umul24(q, fk);                                               \
-        const uint32_t ent = *(const uint16_t *)(inv_bytes + ak + 2u * r);                    \
+        const uint32_t at = (uint32_t)__mul24((int)q, n2) + (ak + 2u * x);                    \
+        const uint32_t ent = *(const uint16_t *)(inv_bytes + at);                             \
         state = (q << 12) + ent;                                                              \
     } while (0)
 
-__global__ __launch_bounds__(kThreads) void k_rans_encode(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
-                                                          const uint32_t *sym_count_all, const HydkTables *tabs,
-                                                          uint32_t *bitbuf_all, uint32_t *group_bits_all,
-                                                          int preset_bits) {
+template <int WAVES> /* groups (= waves) per workgroup: 4 for latency, 8 / 16 to pack more chains per CU */
+__global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
+                                                            const uint32_t *sym_count_all, const HydkTables *tabs,
+                                                            uint32_t *bitbuf_all, uint32_t *group_bits_all,
+                                                            int preset_bits) {
+    constexpr int kThreads = 64 * WAVES;                             /* shadows the file-level constant */
+    constexpr int kBlocksPerLfg = HYDK_GROUPS_PER_LFG / WAVES;
     __shared__ uint16_t s_inv[kInvEntries];                          /* 144 KiB */
     __shared__ uint32_t s_fb[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
     __shared__ uint32_t s_magic[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
-    __shared__ uint32_t s_win[4][kWinWords];
+    __shared__ uint32_t s_win[WAVES][kWinWords];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int slot = blockIdx.x >> 4;
-    const int g = ((blockIdx.x & 15) << 2) + wave;
+    const int slot = blockIdx.x / kBlocksPerLfg;
+    const int first_group = (blockIdx.x % kBlocksPerLfg) * WAVES;
+    const int g = first_group + wave;
     const int ngroups = jobs[slot].gcols * jobs[slot].grows;
-    if ((int)((blockIdx.x & 15) << 2) >= ngroups) {
+    if (first_group >= ngroups) {
         if (lane == 0)
             group_bits_all[slot * HYDK_GROUPS_PER_LFG + g] = 0;
         return; /* whole workgroup beyond the LF group's last group */
@@ -876,6 +877,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_encode(const HydkLfJob *__res
         const uint32_t e = ((lo >> 8) & 0xF) * HYDK_ALPHABET + (lo & 0xFF);
         const uint32_t fbv = s_fb[e];
         const uint32_t f = valid ? (fbv & 0xFFFFu) : 1u;
+        const int neg2f = -2 * (int)f;
         const uint32_t mg = s_magic[e];
         const uint32_t adr = (((lo >> 8) & 0xF) * (2u * HYDK_ANS_SLOTS) + 2u * (fbv >> 16)) * 2u;
         /* (state >> 20) >= f  <=>  state > (f << 20) - 1, exact for f up to 4096 (entropy.c:1092) */
@@ -1023,9 +1025,17 @@ hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t 
 }
 
 hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
-                       uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, hipStream_t stream) {
-    hipLaunchKernelGGL(k_rans_encode, dim3(num_slots * 16), dim3(kThreads), 0, stream, d_jobs, tokens, sym_count, tabs,
-                       bitbuf, group_bits, preset_bits);
+                       uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int waves,
+                       hipStream_t stream) {
+    if (waves == 16)
+        hipLaunchKernelGGL(k_rans_encode<16>, dim3(num_slots * 4), dim3(1024), 0, stream, d_jobs, tokens, sym_count, tabs,
+                           bitbuf, group_bits, preset_bits);
+    else if (waves == 8)
+        hipLaunchKernelGGL(k_rans_encode<8>, dim3(num_slots * 8), dim3(512), 0, stream, d_jobs, tokens, sym_count, tabs,
+                           bitbuf, group_bits, preset_bits);
+    else
+        hipLaunchKernelGGL(k_rans_encode<4>, dim3(num_slots * 16), dim3(256), 0, stream, d_jobs, tokens, sym_count, tabs,
+                           bitbuf, group_bits, preset_bits);
     return hipGetLastError();
 }
 

@@ -55,6 +55,7 @@ def dll(path: Optional[str] = None):
         d.hydamd_uses_register_luts.argtypes = [vp]
         d.hydamd_force_luts.argtypes = [vp, i]
         d.hydamd_begin_frame.argtypes = [vp, u]
+        d.hydamd_set_rans_waves.argtypes = [vp, i]
         lf_args = [vp, i, C.POINTER(vp), C.c_ssize_t, C.c_ssize_t, i, sz, sz, u]
         d.hydamd_encode_lf_group.argtypes = lf_args
         d.hydamd_encode_lf_group_host.argtypes = lf_args
@@ -118,6 +119,9 @@ class DeviceContext:
 
     def force_luts(self, use_luts: bool):
         self._ck(self.d.hydamd_force_luts(self.h, int(use_luts)))
+
+    def set_rans_waves(self, waves: int):
+        self._ck(self.d.hydamd_set_rans_waves(self.h, waves))
 
     def begin_frame(self, num_presets: int):
         self._ck(self.d.hydamd_begin_frame(self.h, num_presets))

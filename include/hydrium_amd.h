@@ -69,6 +69,11 @@ HYDAMD_EXPORT int hydamd_uses_register_luts(HydAmdContext *ctx);
 /* Force the LUT-gather (1) or register (0) variant; for A/B measurements. */
 HYDAMD_EXPORT int hydamd_force_luts(HydAmdContext *ctx, int use_luts);
 
+/* Groups (= wavefronts) per rANS workgroup: 4 (default) gives each chain a SIMD of its own and the
+ * lowest single-frame latency; 8 or 16 pack more chains per CU so that several frames queued on
+ * different contexts/streams can run their entropy stage side by side (throughput mode). */
+HYDAMD_EXPORT int hydamd_set_rans_waves(HydAmdContext *ctx, int waves);
+
 /* Start a frame of `num_presets` presets (= LF groups, at most 255): clears histograms and the running alphabet. */
 HYDAMD_EXPORT int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets);
 

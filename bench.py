@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=16, choices=(8, 16))
     ap.add_argument("--kind", default="photo")
     ap.add_argument("--streams", type=int, default=3)
-    ap.add_argument("--rans-waves", type=int, default=4, choices=(4, 8, 16))
+    ap.add_argument("--rans-waves", type=int, default=4, choices=(4, 8, 16, 64))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
     return ap.parse_args()

@@ -34,6 +34,9 @@ hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t 
 hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
                        uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int waves,
                        hipStream_t stream);
+hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
+                             uint32_t *final_state, uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots,
+                             hipStream_t stream);
 hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, hipStream_t stream);
 hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
                        int count, hipStream_t stream);
@@ -72,6 +75,8 @@ struct HydAmdContext {
     int use_luts = 1;
     int register_luts_ok = 0;
     int rans_waves = 4;             /* groups per rANS workgroup: 4 (latency) .. 16 (throughput) */
+    int rans_lanes = 0;             /* 1: lane-per-group chain kernel + parallel emit (throughput form) */
+    uint32_t *final_state = nullptr; /* [slots][64] */
     unsigned num_presets = 1;
     int scheme = 0;
     int nclusters = 9;
@@ -329,7 +334,7 @@ void hydamd_destroy(HydAmdContext *ctx) {
         (void)hipStreamSynchronize(ctx->stream);
     drain_timers(ctx);
     void *dev[] = {ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->hist, ctx->sym_count, ctx->group_bits,
-                   ctx->offsets, ctx->total, ctx->status, ctx->alpha_max, ctx->d_jobs, ctx->in_lut8, ctx->in_lut16,
+                   ctx->offsets, ctx->total, ctx->status, ctx->alpha_max, ctx->final_state, ctx->d_jobs, ctx->in_lut8, ctx->in_lut16,
                    ctx->bias_lut, ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant, ctx->d_arena};
     for (void *p : dev)
         if (p)
@@ -371,6 +376,7 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipMalloc(&ctx->total, sizeof(uint64_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->status, sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->alpha_max, slots * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->final_state, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_jobs, slots * sizeof(HydkLfJob)));
     for (int i = 0; i < 4; i++) {
         HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_jobs_ring[i], slots * sizeof(HydkLfJob), hipHostMallocDefault));
@@ -422,6 +428,8 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
         const int w = atoi(env);
         if (w == 4 || w == 8 || w == 16)
             ctx->rans_waves = w;
+        if (w == 64)
+            ctx->rans_lanes = 1;
     }
     if (const char *env = getenv("HYDAMD_FORCE_LUTS"))
         ctx->use_luts = atoi(env) != 0 || !ctx->register_luts_ok;
@@ -481,9 +489,14 @@ int hydamd_force_luts(HydAmdContext *ctx, int use_luts) {
 int hydamd_set_rans_waves(HydAmdContext *ctx, int waves) {
     if (!ctx)
         return ST_API_ERROR;
+    if (waves == 64) { /* one LANE per group: 64 chains per wave */
+        ctx->rans_lanes = 1;
+        return ST_OK;
+    }
     if (waves != 4 && waves != 8 && waves != 16)
-        return fail(ctx, ST_API_ERROR, "rANS workgroups hold 4, 8 or 16 groups");
+        return fail(ctx, ST_API_ERROR, "rANS workgroups hold 4, 8 or 16 groups (64 selects the lane-per-group form)");
     ctx->rans_waves = waves;
+    ctx->rans_lanes = 0;
     return ST_OK;
 }
 
@@ -598,8 +611,12 @@ int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
     }
     {
         ScopedTimer timer(ctx, HYDAMD_K_RANS);
-        HIP_TRY(ctx, hydk::launch_rans(ctx->d_jobs, ctx->tokens, ctx->sym_count, ctx->tables, ctx->bitbuf,
-                                       ctx->group_bits, ctx->preset_bits, num_slots, ctx->rans_waves, ctx->stream));
+        if (ctx->rans_lanes)
+            HIP_TRY(ctx, hydk::launch_rans_lanes(ctx->d_jobs, ctx->tokens, ctx->sym_count, ctx->tables, ctx->final_state,
+                                                 ctx->bitbuf, ctx->group_bits, ctx->preset_bits, num_slots, ctx->stream));
+        else
+            HIP_TRY(ctx, hydk::launch_rans(ctx->d_jobs, ctx->tokens, ctx->sym_count, ctx->tables, ctx->bitbuf,
+                                           ctx->group_bits, ctx->preset_bits, num_slots, ctx->rans_waves, ctx->stream));
     }
     {
         ScopedTimer timer(ctx, HYDAMD_K_PACK);

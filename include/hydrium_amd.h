@@ -71,7 +71,9 @@ HYDAMD_EXPORT int hydamd_force_luts(HydAmdContext *ctx, int use_luts);
 
 /* Groups (= wavefronts) per rANS workgroup: 4 (default) gives each chain a SIMD of its own and the
  * lowest single-frame latency; 8 or 16 pack more chains per CU so that several frames queued on
- * different contexts/streams can run their entropy stage side by side (throughput mode). */
+ * different contexts/streams can run their entropy stage side by side; 64 selects the
+ * lane-per-group form (64 chains per wavefront + a parallel emit kernel): slightly longer latency
+ * for one frame, but the entropy stage then occupies one CU per LF group only (throughput mode). */
 HYDAMD_EXPORT int hydamd_set_rans_waves(HydAmdContext *ctx, int waves);
 
 /* Start a frame of `num_presets` presets (= LF groups, at most 255): clears histograms and the running alphabet. */

@@ -27,21 +27,24 @@
 #pragma clang fp contract(off)
 
 namespace hydk {
-hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, bool luts, uint32_t *status,
+hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, int xmode, uint32_t *status,
                             hipStream_t stream);
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int num_slots,
                          hipStream_t stream);
 hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
                        uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int waves,
                        hipStream_t stream);
+hipError_t launch_rans_rows(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
+                            uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int whole_lf_group,
+                            hipStream_t stream);
 hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
                              uint32_t *final_state, uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots,
                              hipStream_t stream);
 hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, hipStream_t stream);
 hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
                        int count, hipStream_t stream);
-hipError_t launch_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, int linear_light, uint32_t *mismatches,
-                               hipStream_t stream);
+hipError_t launch_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, int linear_light, int xmode,
+                               uint32_t *mismatches, hipStream_t stream);
 } // namespace hydk
 
 /* HYDStatusCode values (include/libhydrium/libhydrium.h) */
@@ -72,7 +75,8 @@ struct HydAmdContext {
     int device = 0;
     int max_slots = 0;
     int linear_light = 0;
-    int use_luts = 1;
+    int use_luts = 2;               /* XYB mode: 0 registers + fast reciprocal, 1 registers + IEEE division, 2 LUT gathers */
+    int best_register_mode = 2;     /* best mode that passed the bit-exactness self-test */
     int register_luts_ok = 0;
     int rans_waves = 4;             /* groups per rANS workgroup: 4 (latency) .. 16 (throughput) */
     int rans_lanes = 0;             /* 1: lane-per-group chain kernel + parallel emit (throughput form) */
@@ -416,23 +420,33 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
 
     uint32_t *mism = nullptr;
     HIP_TRY(ctx, hipMalloc(&mism, sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMemset(mism, 0, sizeof(uint32_t)));
-    HIP_TRY(ctx, hydk::launch_lut_selftest(ctx->in_lut16, ctx->bias_lut, ctx->linear_light, mism, ctx->stream));
-    uint32_t h_mism = 1;
-    HIP_TRY(ctx, hipMemcpyAsync(&h_mism, mism, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->best_register_mode = 2;
+    for (int mode = 0; mode < 2 && ctx->best_register_mode == 2; mode++) {
+        uint32_t h_mism = 1;
+        HIP_TRY(ctx, hipMemsetAsync(mism, 0, sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hydk::launch_lut_selftest(ctx->in_lut16, ctx->bias_lut, ctx->linear_light, mode, mism, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&h_mism, mism, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (h_mism == 0)
+            ctx->best_register_mode = mode;
+    }
     (void)hipFree(mism);
-    ctx->register_luts_ok = h_mism == 0;
-    ctx->use_luts = !ctx->register_luts_ok;
+    ctx->register_luts_ok = ctx->best_register_mode < 2;
+    ctx->use_luts = ctx->best_register_mode;
     if (const char *env = getenv("HYDAMD_RANS_WAVES")) {
         const int w = atoi(env);
         if (w == 4 || w == 8 || w == 16)
             ctx->rans_waves = w;
         if (w == 64)
             ctx->rans_lanes = 1;
+        if (w >= 1 && w <= 3)
+            ctx->rans_lanes = w + 1;
     }
-    if (const char *env = getenv("HYDAMD_FORCE_LUTS"))
-        ctx->use_luts = atoi(env) != 0 || !ctx->register_luts_ok;
+    if (const char *env = getenv("HYDAMD_XYB_MODE")) { /* 0 / 1 / 2, never faster than what was proven exact */
+        const int m = atoi(env);
+        if (m >= ctx->best_register_mode && m <= 2)
+            ctx->use_luts = m;
+    }
     return ST_OK;
 }
 
@@ -475,14 +489,25 @@ int hydamd_set_stream(HydAmdContext *ctx, void *hip_stream) {
 
 void *hydamd_get_stream(HydAmdContext *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
-int hydamd_uses_register_luts(HydAmdContext *ctx) { return ctx && !ctx->use_luts; }
+int hydamd_uses_register_luts(HydAmdContext *ctx) { return ctx && ctx->use_luts < 2; }
+
+int hydamd_xyb_mode(HydAmdContext *ctx) { return ctx ? ctx->use_luts : -1; }
 
 int hydamd_force_luts(HydAmdContext *ctx, int use_luts) {
     if (!ctx)
         return ST_API_ERROR;
     if (!use_luts && !ctx->register_luts_ok)
         return fail(ctx, ST_INTERNAL_ERROR, "register LUT evaluation failed its self-test on this device");
-    ctx->use_luts = use_luts != 0;
+    ctx->use_luts = use_luts ? 2 : ctx->best_register_mode;
+    return ST_OK;
+}
+
+int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (mode < ctx->best_register_mode || mode > 2)
+        return fail(ctx, ST_API_ERROR, "XYB mode not available (it must have passed the bit-exactness self-test)");
+    ctx->use_luts = mode;
     return ST_OK;
 }
 
@@ -491,6 +516,10 @@ int hydamd_set_rans_waves(HydAmdContext *ctx, int waves) {
         return ST_API_ERROR;
     if (waves == 64) { /* one LANE per group: 64 chains per wave */
         ctx->rans_lanes = 1;
+        return ST_OK;
+    }
+    if (waves >= 1 && waves <= 3) { /* four chains per wave, one per 16-lane row; 2: a whole LF group, 3: half of one, per workgroup */
+        ctx->rans_lanes = waves + 1;
         return ST_OK;
     }
     if (waves != 4 && waves != 8 && waves != 16)
@@ -602,7 +631,7 @@ int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
     HIP_TRY(ctx, hipEventRecord(ctx->jobs_uploaded[ctx->jobs_idx], ctx->stream));
     {
         ScopedTimer timer(ctx, HYDAMD_K_TRANSFORM);
-        HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs, num_slots, ctx->fmt_mask, ctx->use_luts != 0, ctx->status,
+        HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs, num_slots, ctx->fmt_mask, ctx->use_luts, ctx->status,
                                             ctx->stream));
     }
     {
@@ -611,7 +640,11 @@ int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
     }
     {
         ScopedTimer timer(ctx, HYDAMD_K_RANS);
-        if (ctx->rans_lanes)
+        if (ctx->rans_lanes >= 2)
+            HIP_TRY(ctx, hydk::launch_rans_rows(ctx->d_jobs, ctx->tokens, ctx->sym_count, ctx->tables, ctx->bitbuf,
+                                                ctx->group_bits, ctx->preset_bits, num_slots, ctx->rans_lanes - 2,
+                                                ctx->stream));
+        else if (ctx->rans_lanes)
             HIP_TRY(ctx, hydk::launch_rans_lanes(ctx->d_jobs, ctx->tokens, ctx->sym_count, ctx->tables, ctx->final_state,
                                                  ctx->bitbuf, ctx->group_bits, ctx->preset_bits, num_slots, ctx->stream));
         else

@@ -38,6 +38,9 @@ typedef struct HydkTables {
      * the first freq hold slot(r); the second freq hold slot(r - freq) + 4096, so that the
      * one-too-small quotient of the multiply-high division is repaired by the same lookup. */
     uint16_t inv[HYDK_MAX_CLUSTERS][2 * HYDK_ANS_SLOTS];
+    /* the plain form, slot(r) at base + r for r < freq: half the LDS, used by the kernel variant that
+     * packs a whole LF group into one workgroup and repairs the quotient with two extra operations */
+    uint16_t inv1[HYDK_MAX_CLUSTERS][HYDK_ANS_SLOTS];
     uint32_t alphabet[HYDK_MAX_CLUSTERS];              /* largest token + 1 seen per cluster */
     uint32_t log_alphabet_size;                        /* max(5, ceil log2 of the running max alphabet) */
     uint32_t running_max_alphabet;                     /* after this LF group, in send order */

@@ -112,16 +112,39 @@ __device__ __forceinline__ uint32_t to_u16(float x) { /* format.c:33-36 */
     return (uint32_t)(y < 0 ? 0 : y > 65535 ? 65535 : y);
 }
 
+/* XYB evaluation modes of the integer pixel path (the launcher picks the first one whose
+ * register evaluation reproduces all 65536 host-built LUT entries bit for bit):
+ *   0  registers, reciprocal by v_rcp_f32 + two fused correction steps (Markstein)
+ *   1  registers, IEEE division as the compiler expands it
+ *   2  gathers from the uploaded LUTs */
+constexpr int kXybFastRcp = 0, kXybIeeeDiv = 1, kXybGather = 2;
+
 /* the 65536-entry LUTs of format.c:58-83, evaluated in registers */
 __device__ __forceinline__ uint32_t input_lut16_eval(uint32_t i, int linear_light) {
     const float f = (float)i * kUnit16;
     return to_u16(linear_light ? f : linearize(f));
 }
-__device__ __forceinline__ float bias_lut_eval(uint32_t i) { return bias_curve((float)i * kUnit16); }
+template <int XMODE>
+__device__ __forceinline__ float bias_lut_eval(uint32_t i) {
+    if (XMODE == kXybIeeeDiv)
+        return bias_curve((float)i * kUnit16);
+    /* same operations as bias_curve (format.c:21-31) with 1.0f / z computed as a correctly rounded
+     * reciprocal: explicit fmaf() is a fused operation regardless of the contraction setting, and
+     * is used for the division only, whose IEEE result does not depend on how it is reached */
+    const float x = (float)i * kUnit16 + 0.0037930732552754493f;
+    float z = __uint_as_float(0x548c39cbu - __float_as_uint(x) / 3u);
+    z *= 1.5015480449f - 0.534850249f * x * z * z * z;
+    z *= 1.333333985f - 0.33333333f * x * z * z * z;
+    const float r0 = __builtin_amdgcn_rcpf(z);
+    const float r1 = __builtin_fmaf(r0, __builtin_fmaf(-z, r0, 1.0f), r0);
+    const float r2 = __builtin_fmaf(__builtin_fmaf(-z, r1, 1.0f), r0, r1);
+    return r2 - 0.155954f;
+}
 
-template <bool LUTS>
+template <int XMODE>
 __device__ __forceinline__ void lms_mix_u16(uint32_t r, uint32_t g, uint32_t b, const float *bias_lut, float &X,
                                             float &Y, float &B) {
+    constexpr bool LUTS = XMODE == kXybGather;
     /* format.c:48-56: 16.16 fixed-point LMS mix, high half indexes the bias LUT */
     const uint32_t il = (19661u * r + 40761u * g + 5112u * b) >> 16;
     const uint32_t im = (15073u * r + 45350u * g + 5112u * b) >> 16;
@@ -132,9 +155,9 @@ __device__ __forceinline__ void lms_mix_u16(uint32_t r, uint32_t g, uint32_t b, 
         m = bias_lut[im];
         s = bias_lut[is];
     } else {
-        l = bias_lut_eval(il);
-        m = bias_lut_eval(im);
-        s = bias_lut_eval(is);
+        l = bias_lut_eval<XMODE>(il);
+        m = bias_lut_eval<XMODE>(im);
+        s = bias_lut_eval<XMODE>(is);
     }
     Y = (l + m) * 0.5f;
     X = Y - m;
@@ -218,12 +241,13 @@ struct SampleOf<HYDK_FMT_F32> {
  * Token order inside a group is block raster, channels Y, X, B (encoder.c:707-745), which the
  * strip order + prefix sum reproduces.  The next strip's pixels are in flight during B and C.
  * ======================================================================================== */
-template <int FMT, bool LUTS>
+template <int FMT, int XMODE>
 __global__ __launch_bounds__(kThreads, 3) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
     typedef typename SampleOf<FMT>::type sample_t;
+    constexpr bool LUTS = XMODE == kXybGather;
     constexpr int kWords = FMT == HYDK_FMT_U8 ? 6 : 12; /* dwords holding 8 packed RGB pixels */
     const HydkLfJob job = jobs[blockIdx.x >> 6];
-    if (job.fmt != FMT || (job.use_luts != 0) != LUTS)
+    if (job.fmt != FMT || (FMT != HYDK_FMT_F32 && job.use_luts != XMODE))
         return; /* another template instance of this launch round owns this LF group */
     if ((int)(blockIdx.x & 63) >= job.gcols * job.grows)
         return;
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_transform_tokenize(const HydkLf
                                 rgb[ch] = LUTS ? job.in_lut16[v] : input_lut16_eval(v, job.linear_light);
                             }
                         }
-                        lms_mix_u16<LUTS>(rgb[0], rgb[1], rgb[2], job.bias_lut, xv[i], yv[i], bv[i]);
+                        lms_mix_u16<XMODE>(rgb[0], rgb[1], rgb[2], job.bias_lut, xv[i], yv[i], bv[i]);
                     }
                 } else {
 #pragma unroll
@@ -356,7 +380,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_transform_tokenize(const HydkLf
                                 else
                                     rgb[ch] = LUTS ? job.in_lut16[rgb[ch]] : input_lut16_eval(rgb[ch], job.linear_light);
                             }
-                            lms_mix_u16<LUTS>(rgb[0], rgb[1], rgb[2], job.bias_lut, xv[i], yv[i], bv[i]);
+                            lms_mix_u16<XMODE>(rgb[0], rgb[1], rgb[2], job.bias_lut, xv[i], yv[i], bv[i]);
                         }
                     }
                 }
@@ -714,6 +738,7 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
         const uint32_t at = 2u * s_base[c][sym] + off, f = s_freq[c][sym];
         tab->inv[c][at] = (uint16_t)slot;
         tab->inv[c][at + f] = (uint16_t)(slot + HYDK_ANS_SLOTS);
+        tab->inv1[c][s_base[c][sym] + off] = (uint16_t)slot;
     }
     for (int idx = t; idx < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; idx += kThreads) {
         const int c = idx / HYDK_ALPHABET, k = idx % HYDK_ALPHABET;
@@ -923,6 +948,187 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
     }
 }
 #undef HYDK_RANS_STEP
+
+/* ==========================================================================================
+ * K3a, packed form: four chains per wave, one per 16-lane row; 16 groups per workgroup.  Every
+ * instruction of the serial walk now advances four groups, so the entropy stage of a frame needs
+ * about a quarter of the issue slots of k_rans_encode and other frames' transform kernels can run
+ * beside it.  Per round of 16 symbols per chain: operands are staged through LDS (one
+ * ds_read_b128 per step, broadcast inside a row), states are captured by v_mov_b32_dpp row_shr:1,
+ * and emission is a 16-lane segmented prefix sum into a per-row LDS window.
+ * grid = 4 x LF groups, block = 256.
+ * ======================================================================================== */
+constexpr int kRowWin = 28; /* 16 symbols x 46 bits = 23 words + alignment slack */
+
+/* WAVES = 4: 16 groups per workgroup, doubled table (147 KB of LDS).  WAVES = 16: a whole LF group
+ * per workgroup with the plain table (74 KB), so one CU serves an LF group's entropy stage and
+ * transform workgroups of other frames still fit beside it. */
+template <int WAVES, bool DOUBLED>
+__global__ __launch_bounds__(64 * WAVES) void k_rans_rows(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
+                                                          const uint32_t *sym_count_all, const HydkTables *tabs,
+                                                          uint32_t *bitbuf_all, uint32_t *group_bits_all, int preset_bits) {
+    constexpr int kThreads = 64 * WAVES;
+    constexpr int kBlocksPerLfg = HYDK_GROUPS_PER_LFG / (4 * WAVES);
+    constexpr int kTableEntries = DOUBLED ? kInvEntries : kInvEntries / 2;
+    __shared__ uint16_t s_inv[kTableEntries];
+    __shared__ uint32_t s_fb[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
+    __shared__ uint32_t s_magic[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
+    __shared__ uint4 s_ops[WAVES][4][16];                            /* [wave][row][step]: f or -2f, magic, table address, threshold */
+    __shared__ uint32_t s_win[WAVES][4][kRowWin];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row = lane >> 4, l = lane & 15;
+    const int slot = blockIdx.x / kBlocksPerLfg;
+    const int first_group = (blockIdx.x % kBlocksPerLfg) * 4 * WAVES;
+    const int g = first_group + (wave << 2) + row;
+    const int ngroups = jobs[slot].gcols * jobs[slot].grows;
+    if (first_group >= ngroups) {
+        if (l == 0)
+            group_bits_all[slot * HYDK_GROUPS_PER_LFG + g] = 0;
+        return;
+    }
+    const HydkTables *tab = tabs + slot;
+    {
+        const uint4 *src = DOUBLED ? (const uint4 *)&tab->inv[0][0] : (const uint4 *)&tab->inv1[0][0];
+        uint4 *dst = (uint4 *)s_inv;
+        for (int i = t; i < kTableEntries / 8; i += kThreads)
+            dst[i] = src[i];
+        for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads) {
+            s_fb[i] = (&tab->fb[0][0])[i];
+            s_magic[i] = (&tab->magic[0][0])[i];
+        }
+    }
+    __syncthreads();
+
+    const bool live = g < ngroups;
+    const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + g;
+    const uint64_t *tok = tokens_all + G * HYDK_TOKENS_PER_GROUP;
+    uint32_t *W = bitbuf_all + G * HYDK_BITWORDS_PER_GROUP;
+    uint32_t *win = s_win[wave][row];
+    uint4 *ops = s_ops[wave][row];
+    const int n = live ? (int)sym_count_all[G] : 0;
+    const unsigned char *inv_bytes = (const unsigned char *)s_inv;
+    int nmax = n;
+#pragma unroll
+    for (int d = 32; d; d >>= 1)
+        nmax = max(nmax, __shfl_xor(nmax, d));
+
+    uint32_t cur = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u; /* per row */
+    uint32_t carry = 0;
+    uint32_t state;
+    asm volatile("v_mov_b32 %0, 0x130000" : "=v"(state));
+
+    /* 16-lane segmented emission: lane l = 0 of a row is nearest the bits already written */
+    auto emit = [&](unsigned long long val, uint32_t nbits) {
+        uint32_t inc = nbits;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 16);
+            if (l >= d)
+                inc += o;
+        }
+        const uint32_t total = __shfl(inc, 15, 16);
+        const uint32_t newcur = cur - total;
+        const uint32_t wlo = newcur >> 5, whi = (cur - 1u) >> 5;
+        const uint32_t nwords = total ? whi - wlo + 1u : 0u;
+        for (uint32_t i = l; i < nwords; i += 16)
+            win[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (l == 0 && nwords && (cur & 31u))
+            win[whi - wlo] = carry;
+        __builtin_amdgcn_wave_barrier();
+        if (nbits) {
+            const uint32_t pos = cur - inc - wlo * 32u;
+            const uint32_t w = pos >> 5, sh = pos & 31u;
+            const unsigned long long lo = val << sh;
+            const uint32_t hi = sh ? (uint32_t)(val >> (64u - sh)) : 0u;
+            if ((uint32_t)lo)
+                atomicOr(&win[w], (uint32_t)lo);
+            if ((uint32_t)(lo >> 32))
+                atomicOr(&win[w + 1], (uint32_t)(lo >> 32));
+            if (hi)
+                atomicOr(&win[w + 2], hi);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool low_partial = (newcur & 31u) != 0;
+        for (uint32_t i = l + (low_partial ? 1u : 0u); i < nwords; i += 16)
+            W[wlo + i] = win[i];
+        if (nwords)
+            carry = low_partial ? win[0] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        cur = newcur;
+    };
+
+    uint64_t rec_next = n - 1 - l >= 0 ? tok[n - 1 - l] : 0ull;
+    for (int base = 0; base < nmax; base += 16) {
+        /* lane l of a row owns symbol p = (n - 1 - base) - l, walked at step l */
+        const int hi_p = n - 1 - base;
+        const int p = hi_p - l;
+        const bool valid = p >= 0;
+        const uint64_t rec = rec_next;
+        const int pn = p - 16;
+        rec_next = pn >= 0 ? tok[pn] : 0ull; /* next round's records are in flight during this round's walk */
+        const uint32_t lo = (uint32_t)rec;
+        const uint32_t e = ((lo >> 8) & 0xF) * HYDK_ALPHABET + (lo & 0xFF);
+        const uint32_t fbv = s_fb[e];
+        const uint32_t f = valid ? (fbv & 0xFFFFu) : 1u;
+        const uint32_t thr = (uint32_t)(((unsigned long long)f << 20) - 1ull);
+        uint4 op;
+        op.x = DOUBLED ? (uint32_t)(-2 * (int)f) : f;
+        op.y = s_magic[e];
+        op.z = DOUBLED ? (((lo >> 8) & 0xF) * (2u * HYDK_ANS_SLOTS) + 2u * (fbv >> 16)) * 2u
+                       : (((lo >> 8) & 0xF) * (uint32_t)HYDK_ANS_SLOTS + (fbv >> 16)) * 2u;
+        op.w = thr;
+        ops[l] = op;
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = min(16, hi_p + 1); /* per row; <= 0 once the row's group is finished */
+        uint32_t trail = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k < cnt) {
+                const uint4 o = ops[k];
+                trail = (uint32_t)__builtin_amdgcn_update_dpp((int)state, (int)trail, 0x111, 0xF, 0xF, false);
+                const uint32_t x = state > o.w ? state >> 16 : state;
+                uint32_t q = __umulhi(x, o.y);
+                if (DOUBLED) {
+                    const uint32_t at = (uint32_t)__mul24((int)q, (int)o.x) + (o.z + 2u * x);
+                    state = (q << 12) + *(const uint16_t *)(inv_bytes + at);
+                } else {
+                    /* q is floor(x/f) or one less: fold the remainder back below f and bump q */
+                    const uint32_t r0 = x - __umul24(q, o.x);
+                    const uint32_t r = min(r0, r0 - o.x);
+                    q += r0 >= o.x;
+                    state = (q << 12) | *(const uint16_t *)(inv_bytes + o.z + 2u * r);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        /* the state seen by step j sits in lane cnt-1-j of the row */
+        const uint32_t seen = (uint32_t)__shfl((int)trail, (cnt - 1 - l) & 15, 16);
+        const uint32_t rbits = valid ? (lo >> 16) & 0x3Fu : 0u;
+        const bool refill = valid && seen > thr;
+        const unsigned long long residue = rec >> 32;
+        const unsigned long long val = refill ? (residue << 16) | (seen & 0xFFFFu) : residue;
+        emit(val, valid ? rbits + (refill ? 16u : 0u) : 0u);
+    }
+    {
+        unsigned long long val = 0;
+        uint32_t nb = 0;
+        if (live && l == 0 && n > 0) {
+            val = state;
+            nb = 32;
+        } else if (live && l == 1) {
+            val = jobs[slot].preset;
+            nb = (uint32_t)preset_bits;
+        }
+        emit(val, nb);
+    }
+    if (l == 0) {
+        if (live && (cur & 31u))
+            W[cur >> 5] = carry;
+        group_bits_all[G] = live ? (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u - cur : 0u;
+    }
+}
 
 /* ==========================================================================================
  * K3a, throughput form: the same recurrence with one LANE per group (64 chains per wave, one wave
@@ -1147,6 +1353,7 @@ __global__ __launch_bounds__(kThreads) void k_pack_sections(const uint32_t *bitb
  * Self-test: do the register evaluations of the format.c LUTs reproduce the host-built tables
  * bit for bit?  (If not, the launcher keeps the exact LUT-gather variant of K1.)
  * ======================================================================================== */
+template <int XMODE>
 __global__ void k_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, int linear_light, uint32_t *mismatches) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 65536)
@@ -1154,7 +1361,7 @@ __global__ void k_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, 
     uint32_t bad = 0;
     if (input_lut16_eval(i, linear_light) != in_lut16[i])
         bad++;
-    if (__float_as_uint(bias_lut_eval(i)) != __float_as_uint(bias_lut[i]))
+    if (__float_as_uint(bias_lut_eval<XMODE>(i)) != __float_as_uint(bias_lut[i]))
         bad++;
     if (bad)
         atomicAdd(mismatches, bad);
@@ -1167,23 +1374,29 @@ namespace hydk {
 
 /* One launch per template instance that owns at least one LF group of this round; an instance
  * returns at once for the LF groups of another sample format. */
-hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, bool luts, uint32_t *status,
+hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, int xmode, uint32_t *status,
                             hipStream_t stream) {
     const dim3 grid(num_slots * HYDK_GROUPS_PER_LFG), block(kThreads);
+#define HYDK_LAUNCH_K1(FMT, XM) hipLaunchKernelGGL((k_transform_tokenize<FMT, XM>), grid, block, 0, stream, d_jobs, status)
     if (fmt_mask & (1u << HYDK_FMT_U8)) {
-        if (luts)
-            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U8, true>), grid, block, 0, stream, d_jobs, status);
+        if (xmode == kXybFastRcp)
+            HYDK_LAUNCH_K1(HYDK_FMT_U8, kXybFastRcp);
+        else if (xmode == kXybIeeeDiv)
+            HYDK_LAUNCH_K1(HYDK_FMT_U8, kXybIeeeDiv);
         else
-            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U8, false>), grid, block, 0, stream, d_jobs, status);
+            HYDK_LAUNCH_K1(HYDK_FMT_U8, kXybGather);
     }
     if (fmt_mask & (1u << HYDK_FMT_U16)) {
-        if (luts)
-            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U16, true>), grid, block, 0, stream, d_jobs, status);
+        if (xmode == kXybFastRcp)
+            HYDK_LAUNCH_K1(HYDK_FMT_U16, kXybFastRcp);
+        else if (xmode == kXybIeeeDiv)
+            HYDK_LAUNCH_K1(HYDK_FMT_U16, kXybIeeeDiv);
         else
-            hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_U16, false>), grid, block, 0, stream, d_jobs, status);
+            HYDK_LAUNCH_K1(HYDK_FMT_U16, kXybGather);
     }
     if (fmt_mask & (1u << HYDK_FMT_F32))
-        hipLaunchKernelGGL((k_transform_tokenize<HYDK_FMT_F32, false>), grid, block, 0, stream, d_jobs, status);
+        HYDK_LAUNCH_K1(HYDK_FMT_F32, kXybIeeeDiv);
+#undef HYDK_LAUNCH_K1
     return hipGetLastError();
 }
 
@@ -1208,6 +1421,21 @@ hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const ui
     return hipGetLastError();
 }
 
+hipError_t launch_rans_rows(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
+                            uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int whole_lf_group,
+                            hipStream_t stream) {
+    if (whole_lf_group == 2)
+        hipLaunchKernelGGL((k_rans_rows<8, false>), dim3(num_slots * 2), dim3(512), 0, stream, d_jobs, tokens, sym_count, tabs,
+                           bitbuf, group_bits, preset_bits);
+    else if (whole_lf_group)
+        hipLaunchKernelGGL((k_rans_rows<16, false>), dim3(num_slots), dim3(1024), 0, stream, d_jobs, tokens, sym_count, tabs,
+                           bitbuf, group_bits, preset_bits);
+    else
+        hipLaunchKernelGGL((k_rans_rows<4, true>), dim3(num_slots * 4), dim3(256), 0, stream, d_jobs, tokens, sym_count, tabs,
+                           bitbuf, group_bits, preset_bits);
+    return hipGetLastError();
+}
+
 hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
                              uint32_t *final_state, uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots,
                              hipStream_t stream) {
@@ -1228,9 +1456,14 @@ hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const
     return hipGetLastError();
 }
 
-hipError_t launch_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, int linear_light, uint32_t *mismatches,
-                               hipStream_t stream) {
-    hipLaunchKernelGGL(k_lut_selftest, dim3(256), dim3(256), 0, stream, in_lut16, bias_lut, linear_light, mismatches);
+hipError_t launch_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, int linear_light, int xmode,
+                               uint32_t *mismatches, hipStream_t stream) {
+    if (xmode == kXybFastRcp)
+        hipLaunchKernelGGL(k_lut_selftest<kXybFastRcp>, dim3(256), dim3(256), 0, stream, in_lut16, bias_lut, linear_light,
+                           mismatches);
+    else
+        hipLaunchKernelGGL(k_lut_selftest<kXybIeeeDiv>, dim3(256), dim3(256), 0, stream, in_lut16, bias_lut, linear_light,
+                           mismatches);
     return hipGetLastError();
 }
 

@@ -54,6 +54,8 @@ def dll(path: Optional[str] = None):
         d.hydamd_get_stream.argtypes = [vp]
         d.hydamd_uses_register_luts.argtypes = [vp]
         d.hydamd_force_luts.argtypes = [vp, i]
+        d.hydamd_xyb_mode.argtypes = [vp]
+        d.hydamd_set_xyb_mode.argtypes = [vp, i]
         d.hydamd_begin_frame.argtypes = [vp, u]
         d.hydamd_set_rans_waves.argtypes = [vp, i]
         lf_args = [vp, i, C.POINTER(vp), C.c_ssize_t, C.c_ssize_t, i, sz, sz, u]
@@ -116,6 +118,12 @@ class DeviceContext:
 
     def uses_register_luts(self) -> bool:
         return bool(self.d.hydamd_uses_register_luts(self.h))
+
+    def xyb_mode(self) -> int:
+        return self.d.hydamd_xyb_mode(self.h)
+
+    def set_xyb_mode(self, mode: int):
+        self._ck(self.d.hydamd_set_xyb_mode(self.h, mode))
 
     def force_luts(self, use_luts: bool):
         self._ck(self.d.hydamd_force_luts(self.h, int(use_luts)))

@@ -10,8 +10,9 @@ img = synth.make_image(kind, w, h, depth, device="cuda")
 torch.cuda.synchronize()
 n = (-(-w // 2048)) * (-(-h // 2048))
 ctx = device.DeviceContext(0, n, 0)
-for luts in (False, True):
-    ctx.force_luts(luts)
+print("best XYB mode proven exact:", ctx.xyb_mode())
+for luts in range(ctx.xyb_mode(), 3):
+    ctx.set_xyb_mode(luts)
     ctx.encode_image_tensor(img); ctx.sync()
     ctx.profile(True)
     for _ in range(reps):
@@ -24,7 +25,7 @@ for luts in (False, True):
         ctx.encode_image_tensor(img)
         ctx.sync()
     dt = (time.perf_counter() - t0) / reps
-    print(f"{kind} {w}x{h} u{depth} luts={luts}: e2e {dt*1e3:.3f} ms/frame = {w*h/dt/1e6:.0f} Mpx/s, payload {ctx.payload_size()} B")
+    print(f"{kind} {w}x{h} u{depth} xyb_mode={luts}: e2e {dt*1e3:.3f} ms/frame = {w*h/dt/1e6:.0f} Mpx/s, payload {ctx.payload_size()} B")
     for k, (ms, cnt) in prof.items():
         print(f"   {k:20s} {ms/reps:9.3f} ms/frame  ({cnt//reps} launches, {ms/max(cnt,1)*1e3:8.1f} us each)")
     syms = sum(int(ctx.read_symbol_counts(s).sum()) for s in range(n))

@@ -56,9 +56,9 @@ def _check_lf_group(ctx, slot, res, scheme_local_offset, check_planes, pitch_row
     assert np.array_equal(ctx.read_dc(slot, res.vbw, res.vbh), res.dc)
 
 
-@pytest.mark.parametrize("use_luts", [False, True])
+@pytest.mark.parametrize("xyb_mode", [0, 1, 2])  # registers + v_rcp, registers + IEEE division, LUT gathers
 @pytest.mark.parametrize("kind,w,h,depth", CASES)
-def test_lf_group_stages_match_oracle(image, kind, w, h, depth, use_luts):
+def test_lf_group_stages_match_oracle(image, kind, w, h, depth, xyb_mode):
     from hydrium_amd import device
     from oracle import binding as orc
 
@@ -66,8 +66,8 @@ def test_lf_group_stages_match_oracle(image, kind, w, h, depth, use_luts):
     res, _ = orc.encode_lf_group(img)
     timg = _torch_image(img)
     with device.DeviceContext(0, 1, 0, debug_planes=True) as ctx:
-        assert ctx.uses_register_luts(), "register evaluation of the format.c LUTs failed its bit-exactness self-test"
-        ctx.force_luts(use_luts)
+        assert ctx.xyb_mode() == 0, "the fast register evaluation of the format.c LUTs failed its bit-exactness self-test"
+        ctx.set_xyb_mode(xyb_mode)
         ctx.encode_image_tensor(timg)
         ctx.sync()
         rows, pitch = res.vbh * 8, res.stride

@@ -211,7 +211,7 @@ def encode_image(lib: Library, img: np.ndarray, *, linear_light: int = 0, shift_
                 ret = enc.check(enc.flush())
                 code, n = enc.release_output()
                 enc.check(code)
-                out += bytes(buf[:n])
+                out += C.string_at(buf, n)
                 enc.check(enc.provide_output(buf))
                 if ret != HYD_NEED_MORE_OUTPUT:
                     break

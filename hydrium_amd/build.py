@@ -71,10 +71,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
             _run([CC] + C_FLAGS + ["-DHYD_TEST_HOOKS", "-c", src, "-o", tobj])
         test_objs.append(tobj)
     if force or _newer(LIB_PATH, objs):
-        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-soname,libhydrium.so.0", "-o", LIB_PATH] + objs)
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-soname,libhydrium.so.0", "-o", LIB_PATH] + objs + ["-lpthread"])
     if test_objs and (force or _newer(HOSTTEST_PATH, test_objs)):
         hip_objs = [o for o in objs if o.endswith(".hip.o")]
-        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", HOSTTEST_PATH] + test_objs + hip_objs)
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", HOSTTEST_PATH] + test_objs + hip_objs + ["-lpthread"])
     return LIB_PATH
 
 

@@ -29,8 +29,13 @@
  *   - output never lands in caller memory beyond the provided length (bitwriter.c:42-51 would
  *     realloc() the caller's buffer).
  */
+#define _POSIX_C_SOURCE 200809L /* clock_gettime under -std=c99 */
+#include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "bitio.h"
 #include "frame.h"
@@ -72,9 +77,92 @@ struct HYDEncoder {
 
 #define FAIL(enc, code, msg) ((enc)->error = (msg), (code))
 
+/* HYDAMD_TRACE=1 prints where the host-pointer API path spends its wall time (stderr) */
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static int trace_on(void) {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("HYDAMD_TRACE");
+        on = e && *e && *e != '0';
+    }
+    return on;
+}
+#define TRACE(label, t0)                                                          \
+    do {                                                                          \
+        if (trace_on())                                                           \
+            fprintf(stderr, "[hydrium] %-28s %8.3f ms\n", (label), now_ms() - (t0)); \
+    } while (0)
+
 /* ---------------------------------------------------------------------------------------------
  * frame assembly (shared by the product path and the CPU-only test hook)
  * ------------------------------------------------------------------------------------------- */
+
+/* The LF groups of a frame are independent prefix-coded sections; in a frame with more than one
+ * group each starts on a byte boundary, so they are coded by a few host threads into private
+ * buffers and appended in send order. */
+typedef struct LfWork {
+    const HydFrameShape *shape;
+    const LfgResult *res;
+    HydBits *out;       /* [lfg_count] */
+    int *status;        /* [lfg_count] */
+    const char **err;   /* [lfg_count] */
+    size_t first, stride;
+} LfWork;
+
+static void *lf_worker(void *arg) {
+    const LfWork *w = arg;
+    for (size_t s = w->first; s < w->shape->lfg_count; s += w->stride) {
+        const size_t vbw = (w->shape->lfg[s].width + 7) >> 3, vbh = (w->shape->lfg[s].height + 7) >> 3;
+        hb_init(&w->out[s]);
+        w->err[s] = NULL;
+        w->status[s] = hyd_write_lf_group(&w->out[s], w->res[s].dc, vbw, vbh, &w->err[s]);
+        hb_align(&w->out[s]);
+    }
+    return NULL;
+}
+
+static int code_lf_groups_parallel(HYDEncoder *e, const HydFrameShape *shape, const LfgResult *res, HydBits *out) {
+    const size_t n = shape->lfg_count;
+    int *status = calloc(n, sizeof(int));
+    const char **err = calloc(n, sizeof(char *));
+    if (!status || !err) {
+        free(status);
+        free(err);
+        return FAIL(e, HYD_NOMEM, "out of memory");
+    }
+    long cores = sysconf(_SC_NPROCESSORS_ONLN);
+    size_t threads = cores > 1 ? (size_t)cores : 1;
+    if (threads > n)
+        threads = n;
+    if (threads > 16)
+        threads = 16;
+    LfWork work[16];
+    pthread_t tid[16];
+    size_t started = 0;
+    for (size_t i = 0; i < threads; i++) {
+        work[i] = (LfWork){shape, res, out, status, err, i, threads};
+        if (i + 1 < threads && pthread_create(&tid[started], NULL, lf_worker, &work[i]) == 0)
+            started++;
+        else
+            lf_worker(&work[i]); /* the calling thread takes the last share (and any that could not be spawned) */
+    }
+    for (size_t i = 0; i < started; i++)
+        pthread_join(tid[i], NULL);
+    int ret = 0;
+    for (size_t s = 0; s < n && !ret; s++) {
+        if (status[s] || out[s].failed) {
+            e->error = err[s] ? err[s] : "LF group coding failed";
+            ret = status[s] ? status[s] : HYD_NOMEM;
+        }
+    }
+    free(status);
+    free(err);
+    return ret;
+}
 
 static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgResult *res, unsigned max_alphabet,
                           const uint8_t *payload, size_t payload_len) {
@@ -104,12 +192,31 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
 
     hyd_write_lf_global(&body);
     CLOSE_SECTION();
-    for (size_t s = 0; s < shape->lfg_count; s++) {
-        const size_t vbw = (shape->lfg[s].width + 7) >> 3, vbh = (shape->lfg[s].height + 7) >> 3;
-        ret = hyd_write_lf_group(&body, res[s].dc, vbw, vbh, &e->error);
+    if (multi && shape->lfg_count > 1) {
+        HydBits *lf = calloc(shape->lfg_count, sizeof(HydBits));
+        if (!lf) {
+            ret = FAIL(e, HYD_NOMEM, "out of memory");
+            goto done;
+        }
+        ret = code_lf_groups_parallel(e, shape, res, lf);
+        for (size_t s = 0; s < shape->lfg_count; s++) {
+            if (!ret) {
+                hb_append_bytes(&body, lf[s].data, lf[s].len);
+                CLOSE_SECTION();
+            }
+            hb_free(&lf[s]);
+        }
+        free(lf);
         if (ret)
             goto done;
-        CLOSE_SECTION();
+    } else {
+        for (size_t s = 0; s < shape->lfg_count; s++) {
+            const size_t vbw = (shape->lfg[s].width + 7) >> 3, vbh = (shape->lfg[s].height + 7) >> 3;
+            ret = hyd_write_lf_group(&body, res[s].dc, vbw, vbh, &e->error);
+            if (ret)
+                goto done;
+            CLOSE_SECTION();
+        }
     }
     /* tables are signalled per preset = raster LF-group id, whatever the send order was */
     for (size_t s = 0; s < shape->lfg_count; s++) {
@@ -304,11 +411,14 @@ static int device_fail(HYDEncoder *e, int code) {
 /* read back everything the frame assembler needs and write the frame */
 static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
     const size_t n = shape->lfg_count;
+    double t0 = now_ms();
     int ret = hydamd_finish_frame(e->dev, (int)n);
     if (!ret)
         ret = hydamd_sync(e->dev);
     if (ret)
         return device_fail(e, ret);
+    TRACE("GPU hot path (finish+sync)", t0);
+    t0 = now_ms();
     LfgResult *res = calloc(n, sizeof(LfgResult));
     uint8_t *payload = NULL;
     if (!res)
@@ -341,7 +451,10 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
         ret = device_fail(e, ret);
         goto done;
     }
+    TRACE("read back results", t0);
+    t0 = now_ms();
     ret = assemble_frame(e, shape, res, max_alphabet, payload, payload_len);
+    TRACE("assemble frame (host)", t0);
 done:
     for (size_t s = 0; s < n; s++)
         free(res[s].dc);
@@ -374,7 +487,9 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
 
     if (!e->dev) {
         int st = 0;
+        const double tc = now_ms();
         e->dev = hydamd_create(0, (int)e->lfg_per_frame, e->metadata.linear_light, 0, &st);
+        TRACE("create device context", tc);
         if (!e->dev) {
             const char *m = hydamd_error(NULL);
             if (st == HYD_NOMEM)
@@ -396,10 +511,12 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
     l->y = tile_y;
     l->width = tw;
     l->height = th;
+    const double tu = now_ms();
     ret = hydamd_encode_lf_group_host(e->dev, (int)slot, buffer, row_stride, pixel_stride, (int)sample_fmt, tw, th,
                                       (unsigned)l->raster_id);
     if (ret)
         return device_fail(e, ret);
+    TRACE("stage + upload tile", tu);
 
     if (e->one_frame) {
         e->tiles_sent++;

@@ -30,7 +30,7 @@ namespace hydk {
 hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, int xmode, uint32_t *status,
                             hipStream_t stream);
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int num_slots,
-                         hipStream_t stream);
+                         uint32_t alpha_floor, hipStream_t stream);
 hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
                        uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int waves,
                        hipStream_t stream);
@@ -80,6 +80,7 @@ struct HydAmdContext {
     int register_luts_ok = 0;
     int rans_waves = 4;             /* groups per rANS workgroup: 4 (latency) .. 16 (throughput) */
     int rans_lanes = 0;             /* 1: lane-per-group chain kernel + parallel emit (throughput form) */
+    uint32_t alpha_floor = 0;       /* running maximum alphabet of the LF groups coded before this context's */
     uint32_t *final_state = nullptr; /* [slots][64] */
     unsigned num_presets = 1;
     int scheme = 0;
@@ -567,6 +568,7 @@ int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
                                 (size_t)ctx->max_slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->alpha_max, 0, (size_t)ctx->max_slots * sizeof(uint32_t), ctx->stream));
     ctx->fmt_mask = 0;
+    ctx->alpha_floor = 0;
     HIP_TRY(ctx, hipMemsetAsync(ctx->status, 0, sizeof(uint32_t), ctx->stream));
     return ST_OK;
 }
@@ -615,13 +617,12 @@ int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, const void *const 
     return record_lf_group(ctx, slot, dsrc, (ptrdiff_t)(3 * width), 3, sample_fmt, width, height, preset);
 }
 
-int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
+int hydamd_run_transform(HydAmdContext *ctx, int num_slots) {
     if (!ctx)
         return ST_API_ERROR;
     if (num_slots < 1 || num_slots > ctx->max_slots)
         return fail(ctx, ST_API_ERROR, "slot count out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int count = num_slots * HYDK_GROUPS_PER_LFG;
     ctx->results_valid = false;
     for (int i = 0; i < num_slots; i++)
         if (ctx->h_jobs[i].width == 0)
@@ -634,9 +635,38 @@ int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
         HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs, num_slots, ctx->fmt_mask, ctx->use_luts, ctx->status,
                                             ctx->stream));
     }
+    return ST_OK;
+}
+
+int hydamd_read_alphabet_max(HydAmdContext *ctx, int slot, uint32_t *max_token_plus_one) {
+    int st = check_slot(ctx, slot);
+    if (st != ST_OK)
+        return st;
+    HIP_TRY(ctx, hipMemcpyAsync(max_token_plus_one, ctx->alpha_max + slot, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ST_OK;
+}
+
+int hydamd_set_alphabet_floor(HydAmdContext *ctx, uint32_t floor) {
+    if (!ctx)
+        return ST_API_ERROR;
+    ctx->alpha_floor = floor;
+    return ST_OK;
+}
+
+int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (num_slots < 1 || num_slots > ctx->max_slots)
+        return fail(ctx, ST_API_ERROR, "slot count out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int count = num_slots * HYDK_GROUPS_PER_LFG;
+    ctx->results_valid = false;
     {
         ScopedTimer timer(ctx, HYDAMD_K_TABLES);
-        HIP_TRY(ctx, hydk::launch_tables(ctx->hist, ctx->tables, ctx->alpha_max, ctx->nclusters, num_slots, ctx->stream));
+        HIP_TRY(ctx, hydk::launch_tables(ctx->hist, ctx->tables, ctx->alpha_max, ctx->nclusters, num_slots,
+                                         ctx->alpha_floor, ctx->stream));
     }
     {
         ScopedTimer timer(ctx, HYDAMD_K_RANS);
@@ -660,6 +690,13 @@ int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status_pinned, ctx->status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     ctx->slots_finished = num_slots;
     return ST_OK;
+}
+
+int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
+    int st = hydamd_run_transform(ctx, num_slots);
+    if (st != ST_OK)
+        return st;
+    return hydamd_run_entropy(ctx, num_slots);
 }
 
 int hydamd_sync(HydAmdContext *ctx) {

@@ -581,7 +581,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_transform_tokenize(const HydkLf
  * K2: per-LF-group ANS tables.  grid = LF groups of the frame (send order), block = 256.
  * ======================================================================================== */
 __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_all, HydkTables *tabs,
-                                                           const uint32_t *alpha_max_all, int nclusters) {
+                                                           const uint32_t *alpha_max_all, int nclusters,
+                                                           uint32_t alpha_floor) {
     const uint32_t *hist = hist_all + (size_t)blockIdx.x * HYDK_MAX_CLUSTERS * HYDK_ALPHABET;
     HydkTables *tab = tabs + blockIdx.x;
     __shared__ uint32_t s_freq[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
     if (t == 0) {
         /* the stream-wide alphabet maximum is never reset between LF groups (entropy.c:459-460,952):
          * LF group n codes with the maximum over LF groups 0..n in send order */
-        uint32_t mx = 0;
+        uint32_t mx = alpha_floor; /* maximum over the LF groups other GPUs coded before ours */
         for (unsigned sl = 0; sl <= blockIdx.x; sl++)
             mx = max(mx, alpha_max_all[sl]);
         uint32_t lg = mx > 1 ? 32 - __clz((int)(mx - 1)) : 0; /* ceil(log2(mx)) */
@@ -1401,8 +1402,9 @@ hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt
 }
 
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int num_slots,
-                         hipStream_t stream) {
-    hipLaunchKernelGGL(k_build_tables, dim3(num_slots), dim3(kThreads), 0, stream, hist, tabs, alpha_max, nclusters);
+                         uint32_t alpha_floor, hipStream_t stream) {
+    hipLaunchKernelGGL(k_build_tables, dim3(num_slots), dim3(kThreads), 0, stream, hist, tabs, alpha_max, nclusters,
+                       alpha_floor);
     return hipGetLastError();
 }
 

@@ -631,25 +631,24 @@ HYDRIUM_EXPORT HYDStatusCode hyd_set_suggested_icc_profile(HYDEncoder *e, const 
 }
 
 /* ---------------------------------------------------------------------------------------------
- * CPU-only test hook: assemble a frame from stage results supplied by the caller (the tests feed
- * it the oracle's outputs, so the frame glue can be checked against the reference on machines
- * without a GPU).  Compiled only into libhydrium_hosttest.so.
+ * Additive entry point (include/hydrium_amd.h): wrap LF-group results that were produced elsewhere
+ * — on other GPUs of the node, or by several contexts — into one frame.  This is the same
+ * assemble_frame() hyd_send_tile ends in; it touches no GPU.
  * ------------------------------------------------------------------------------------------- */
-#ifdef HYD_TEST_HOOKS
-#define HYDT_EXPORT __attribute__((visibility("default")))
-
-HYDT_EXPORT int hydt_frame_from_stages(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
-                                       const uint32_t *tile_xy, const int32_t *const *dc, const uint32_t *freq,
-                                       const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
-                                       const uint8_t *payload, size_t payload_len, const uint8_t *icc, size_t icc_size,
-                                       uint8_t **out, size_t *out_len, const char **err) {
+HYDRIUM_EXPORT int hydamd_frame_from_results(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
+                                             const uint32_t *tile_xy, const int32_t *const *dc, const uint32_t *freq,
+                                             const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
+                                             const uint8_t *payload, size_t payload_len, const uint8_t *icc,
+                                             size_t icc_size, uint8_t **out, size_t *out_len, const char **err) {
     HYDEncoder *e = hyd_encoder_new();
     if (!e)
         return HYD_NOMEM;
     int ret = hyd_set_metadata(e, md);
     if (!ret && icc)
         ret = hyd_set_suggested_icc_profile(e, icc, icc_size);
-    LfgResult *res = calloc(lfg_count, sizeof(LfgResult));
+    if (!ret && lfg_count != e->lfg_per_frame)
+        ret = FAIL(e, HYD_API_ERROR, "a frame needs every one of its LF groups");
+    LfgResult *res = calloc(lfg_count ? lfg_count : 1, sizeof(LfgResult));
     if (!ret && !res)
         ret = HYD_NOMEM;
     if (!ret && write_header)
@@ -658,6 +657,10 @@ HYDT_EXPORT int hydt_frame_from_stages(const HYDImageMetadata *md, int write_hea
         const size_t W = md->width, H = md->height;
         for (size_t s = 0; s < lfg_count; s++) {
             const size_t tx = tile_xy[2 * s], ty = tile_xy[2 * s + 1];
+            if (tx >= (W + e->tile_w - 1) / e->tile_w || ty >= (H + e->tile_h - 1) / e->tile_h) {
+                ret = FAIL(e, HYD_API_ERROR, "tile out of bounds");
+                break;
+            }
             e->sent[s].raster_id = e->one_frame ? ty * e->lfg_count_x + tx : 0;
             e->sent[s].x = tx;
             e->sent[s].y = ty;
@@ -668,13 +671,15 @@ HYDT_EXPORT int hydt_frame_from_stages(const HYDImageMetadata *md, int write_hea
             memcpy(res[s].alphabet, alphabet + s * HYD_FRAME_MAX_CLUSTERS, sizeof(res[s].alphabet));
             memcpy(res[s].bits, group_bits + s * HYDAMD_GROUPS_PER_LFG, sizeof(res[s].bits));
         }
+    }
+    if (!ret) {
         HydFrameShape shape;
         memset(&shape, 0, sizeof(shape));
         shape.one_frame = e->one_frame;
-        shape.image_width = W;
-        shape.image_height = H;
-        shape.frame_width = e->one_frame ? W : e->sent[0].width;
-        shape.frame_height = e->one_frame ? H : e->sent[0].height;
+        shape.image_width = md->width;
+        shape.image_height = md->height;
+        shape.frame_width = e->one_frame ? md->width : e->sent[0].width;
+        shape.frame_height = e->one_frame ? md->height : e->sent[0].height;
         shape.tile_count_x = e->tile_w >> 8;
         shape.tile_count_y = e->tile_h >> 8;
         shape.lfg_count = lfg_count;
@@ -698,5 +703,18 @@ HYDT_EXPORT int hydt_frame_from_stages(const HYDImageMetadata *md, int write_hea
     return ret;
 }
 
+HYDRIUM_EXPORT void hydamd_free(void *p) { free(p); }
+
+/* the CPU-only tests drive the same function through libhydrium_hosttest.so */
+#ifdef HYD_TEST_HOOKS
+#define HYDT_EXPORT __attribute__((visibility("default")))
+HYDT_EXPORT int hydt_frame_from_stages(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
+                                       const uint32_t *tile_xy, const int32_t *const *dc, const uint32_t *freq,
+                                       const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
+                                       const uint8_t *payload, size_t payload_len, const uint8_t *icc, size_t icc_size,
+                                       uint8_t **out, size_t *out_len, const char **err) {
+    return hydamd_frame_from_results(md, write_header, is_last, lfg_count, tile_xy, dc, freq, alphabet, group_bits,
+                                     max_alphabet, payload, payload_len, icc, icc_size, out, out_len, err);
+}
 HYDT_EXPORT void hydt_free(void *p) { free(p); }
 #endif /* HYD_TEST_HOOKS */

@@ -62,6 +62,15 @@ def dll(path: Optional[str] = None):
         d.hydamd_encode_lf_group.argtypes = lf_args
         d.hydamd_encode_lf_group_host.argtypes = lf_args
         d.hydamd_finish_frame.argtypes = [vp, i]
+        d.hydamd_run_transform.argtypes = [vp, i]
+        d.hydamd_run_entropy.argtypes = [vp, i]
+        d.hydamd_read_alphabet_max.argtypes = [vp, i, C.POINTER(C.c_uint32)]
+        d.hydamd_set_alphabet_floor.argtypes = [vp, C.c_uint32]
+        d.hydamd_frame_from_results.restype = i
+        d.hydamd_frame_from_results.argtypes = [
+            C.POINTER(api.HYDImageMetadata), i, i, sz, vp, C.POINTER(vp), vp, vp, vp, u, vp, sz, C.c_char_p, sz,
+            C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_char_p)]
+        d.hydamd_free.argtypes = [vp]
         d.hydamd_sync.argtypes = [vp]
         d.hydamd_payload_size.restype = sz
         d.hydamd_payload_size.argtypes = [vp]
@@ -142,6 +151,20 @@ class DeviceContext:
 
     def finish_frame(self, num_slots: int):
         self._ck(self.d.hydamd_finish_frame(self.h, num_slots))
+
+    def run_transform(self, num_slots: int):
+        self._ck(self.d.hydamd_run_transform(self.h, num_slots))
+
+    def run_entropy(self, num_slots: int):
+        self._ck(self.d.hydamd_run_entropy(self.h, num_slots))
+
+    def read_alphabet_max(self, slot: int) -> int:
+        v = C.c_uint32(0)
+        self._ck(self.d.hydamd_read_alphabet_max(self.h, slot, C.byref(v)))
+        return v.value
+
+    def set_alphabet_floor(self, floor: int):
+        self._ck(self.d.hydamd_set_alphabet_floor(self.h, floor))
 
     def sync(self):
         self._ck(self.d.hydamd_sync(self.h))
@@ -251,6 +274,29 @@ class DeviceContext:
         n = (C.c_uint64 * 4)()
         self._ck(self.d.hydamd_profile_read(self.h, ms, n))
         return {K_NAMES[i]: (ms[i], n[i]) for i in range(4)}
+
+
+def frame_from_results(md: "api.HYDImageMetadata", tiles, dcs, freqs, alphabets, group_bits, max_alphabet: int,
+                       payload: bytes, *, write_header=True, is_last=True, icc: Optional[bytes] = None) -> bytes:
+    """hydamd_frame_from_results: codestream bytes from LF-group results in `tiles` order (host only)."""
+    d = dll()
+    n = len(tiles)
+    tile_xy = np.ascontiguousarray(np.array(tiles, np.uint32).reshape(-1))
+    dc_arrays = [np.ascontiguousarray(a, np.int32) for a in dcs]
+    dcp = (C.c_void_p * n)(*[a.ctypes.data for a in dc_arrays])
+    freq = np.ascontiguousarray(np.stack(freqs).astype(np.uint32))
+    alpha = np.ascontiguousarray(np.stack(alphabets).astype(np.uint32))
+    bits = np.ascontiguousarray(np.stack(group_bits).astype(np.uint32))
+    out, out_len, err = C.c_void_p(0), C.c_size_t(0), C.c_char_p(None)
+    ret = d.hydamd_frame_from_results(C.byref(md), int(write_header), int(is_last), n, tile_xy.ctypes.data, dcp,
+                                      freq.ctypes.data, alpha.ctypes.data, bits.ctypes.data, max_alphabet, payload,
+                                      len(payload), icc, len(icc) if icc else 0, C.byref(out), C.byref(out_len),
+                                      C.byref(err))
+    if ret:
+        raise DeviceError(ret, (err.value or b"").decode())
+    data = C.string_at(out.value, out_len.value)
+    d.hydamd_free(out)
+    return data
 
 
 def decode_token_records(rec: np.ndarray):

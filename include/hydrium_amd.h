@@ -25,6 +25,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "libhydrium/libhydrium.h"
+
 #if defined(__GNUC__) || defined(__clang__)
 #define HYDAMD_EXPORT __attribute__((visibility("default")))
 #else
@@ -126,6 +128,35 @@ HYDAMD_EXPORT int hydamd_read_symbol_counts(HydAmdContext *ctx, int slot, uint32
 HYDAMD_EXPORT int hydamd_read_tokens(HydAmdContext *ctx, int slot, int group, uint64_t *dst, size_t capacity);
 /* which: 0 XYB, 1 DCT (float), 2 quantised (int32); dst[c][y][x] with row pitch `pitch` elements */
 HYDAMD_EXPORT int hydamd_read_debug_plane(HydAmdContext *ctx, int which, void *dst, size_t pitch, size_t rows);
+
+/* ---- multi-GPU: only the entropy tables of LF group n depend on earlier LF groups, through the
+ * running maximum alphabet (reference entropy.c:459-460,952).  A rank that codes LF groups
+ * k..k+m of a frame runs the transform stage, exchanges the per-LF-group maxima, sets the maximum
+ * over LF groups 0..k-1 as its floor, then runs the entropy stage.  hydamd_finish_frame() is the
+ * two stages back to back with floor 0. ---- */
+HYDAMD_EXPORT int hydamd_run_transform(HydAmdContext *ctx, int num_slots);
+HYDAMD_EXPORT int hydamd_read_alphabet_max(HydAmdContext *ctx, int slot, uint32_t *max_token_plus_one);
+HYDAMD_EXPORT int hydamd_set_alphabet_floor(HydAmdContext *ctx, uint32_t floor);
+HYDAMD_EXPORT int hydamd_run_entropy(HydAmdContext *ctx, int num_slots);
+
+/*
+ * Wrap LF-group results — from this or other GPUs — into codestream bytes (host only, no GPU).
+ *   md            image metadata, as for hyd_set_metadata (one-frame mode: every LF group must be present)
+ *   tile_xy       [lfg_count][2] tile coordinates, in the order the sections appear in `payload`
+ *   dc            [lfg_count] pointers to LF ints as hydamd_read_dc returns them
+ *   freq/alphabet [lfg_count][9][128] / [lfg_count][9] as hydamd_read_tables returns them
+ *   group_bits    [lfg_count][64] as hydamd_read_sections returns them
+ *   max_alphabet  final running maximum (largest running_max_alphabet of any LF group)
+ *   payload       the packed HF sections of all LF groups, concatenated in the same order
+ * On success *out is a malloc'ed buffer (release with hydamd_free) holding the file header (if
+ * write_header) and the frame.
+ */
+HYDAMD_EXPORT int hydamd_frame_from_results(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
+                                            const uint32_t *tile_xy, const int32_t *const *dc, const uint32_t *freq,
+                                            const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
+                                            const uint8_t *payload, size_t payload_len, const uint8_t *icc,
+                                            size_t icc_size, uint8_t **out, size_t *out_len, const char **err);
+HYDAMD_EXPORT void hydamd_free(void *p);
 
 /* ---- optional per-kernel timing with HIP events on the context's stream ---- */
 HYDAMD_EXPORT int hydamd_profile(HydAmdContext *ctx, int enable);

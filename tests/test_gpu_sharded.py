@@ -1,0 +1,74 @@
+"""GPU: the multi-GPU sharding choreography run on one GPU (N shards, one after another) must give
+the same file as the unsharded encode / the reference, and a batch of independent
+frames round-robined over contexts (config C5) must give the same files as one at a time."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from hydrium_amd import api
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+def _cuda(img):
+    import torch
+
+    if img.dtype == np.uint16:
+        return torch.from_numpy(img.view(np.int16).copy()).cuda()
+    return torch.from_numpy(np.ascontiguousarray(img)).cuda()
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3, 4, 8])
+def test_sharded_frame_equals_reference(image, shards):
+    from hydrium_amd import multigpu
+    from oracle import refprobe
+
+    img = image("photo", 4096 + 200, 2 * 2048 + 72, 8)  # 3 x 3 LF groups, ragged right and bottom
+    got = multigpu.encode_serial(_cuda(img), shards)
+    whole = api.encode_image(api.Library(), img)
+    assert got == whole
+    if refprobe.available():
+        assert got == api.encode_image(refprobe.reference_library(), img)
+
+
+def test_sharded_float_frame_with_growing_alphabet():
+    """Out-of-gamut floats make later LF groups need a larger alphabet than earlier ones: the
+    running-maximum floor that shards exchange must reproduce the single-context result."""
+    import torch
+    from hydrium_amd import multigpu, synth
+
+    img = synth.make_image_f32("photo", 2048 + 64, 2048 + 64)
+    img[2048:, 2048:] *= 4000.0        # huge coefficients only in the last LF group
+    img[:64, :64] *= 300.0
+    t = torch.from_numpy(img).cuda()
+    one = multigpu.encode_serial(t, 1)
+    for shards in (2, 4):
+        assert multigpu.encode_serial(t, shards) == one
+    assert one == api.encode_image(api.Library(), img)
+
+
+def test_batch_of_frames_round_robin_contexts(image):
+    """Config C5 in miniature: independent frames, frame i on context i mod 2, all queued before any sync."""
+    from hydrium_amd import device
+    from oracle import binding as orc
+
+    frames = [image("photo", 960, 540, 8, seed=100 + i) for i in range(5)]
+    ctxs = [device.DeviceContext(0, 1, 0) for _ in range(2)]
+    try:
+        got = []
+        for i in range(0, len(frames), 2):
+            batch = frames[i:i + 2]
+            keep = [_cuda(f) for f in batch]  # device pixels must stay alive until the queued work has run
+            for j, t in enumerate(keep):
+                ctxs[j].encode_image_tensor(t)
+            for j, f in enumerate(batch):
+                ctxs[j].sync()
+                got.append(ctxs[j].read_payload())
+    finally:
+        for c in ctxs:
+            c.close()
+    for f, g in zip(frames, got):
+        res, _ = orc.encode_lf_group(np.ascontiguousarray(f))
+        assert g == res.stream

@@ -171,7 +171,10 @@ class DeviceContext:
 
     # -- whole-image helpers -----------------------------------------------------------------------
     def encode_image_tensor(self, img, num_slots_check: bool = True):
-        """Enqueue the hot path for every LF group of an interleaved (H, W, 3) torch CUDA tensor."""
+        """Enqueue the hot path for every LF group of an interleaved (H, W, 3) torch CUDA tensor.
+
+        The kernels read the tensor's memory asynchronously: the caller must keep it alive (and
+        unmodified) until ``sync()``."""
         h, w, _ = img.shape
         isz = img.element_size()
         fmt = {1: 0, 2: 1, 4: 2}[isz]

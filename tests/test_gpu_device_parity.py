@@ -94,12 +94,14 @@ def test_f32_input_and_nan_rejection(image):
     img = synth.make_image_f32("photo", 300, 270)
     res, _ = orc.encode_lf_group(img)
     with device.DeviceContext(0, 1, 0) as ctx:
-        ctx.encode_image_tensor(torch.from_numpy(img).cuda())
+        t_img = torch.from_numpy(img).cuda()  # must outlive the queued work
+        ctx.encode_image_tensor(t_img)
         ctx.sync()
         assert ctx.read_payload() == res.stream
         bad = img.copy()
         bad[7, 9, 2] = np.inf
-        ctx.encode_image_tensor(torch.from_numpy(bad).cuda())
+        t_bad = torch.from_numpy(bad).cuda()
+        ctx.encode_image_tensor(t_bad)
         with pytest.raises(device.DeviceError) as ei:
             ctx.sync()
         assert ei.value.code == -14 and "NaN" in ei.value.message
@@ -119,7 +121,8 @@ def test_multi_lf_group_frame_host_and_device_paths(image):
             expected.append(res)
     want = b"".join(r.stream for r in expected)
     with device.DeviceContext(0, 4, 0) as ctx:
-        ctx.encode_image_tensor(_torch_image(img))
+        t_img = _torch_image(img)  # must outlive the queued work
+        ctx.encode_image_tensor(t_img)
         ctx.sync()
         got_dev = ctx.read_payload()
         for slot, res in enumerate(expected):

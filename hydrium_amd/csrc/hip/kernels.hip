@@ -242,7 +242,7 @@ struct SampleOf<HYDK_FMT_F32> {
  * strip order + prefix sum reproduces.  The next strip's pixels are in flight during B and C.
  * ======================================================================================== */
 template <int FMT, int XMODE>
-__global__ __launch_bounds__(kThreads, 3) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
+__global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
     typedef typename SampleOf<FMT>::type sample_t;
     constexpr bool LUTS = XMODE == kXybGather;
     constexpr int kWords = FMT == HYDK_FMT_U8 ? 6 : 12; /* dwords holding 8 packed RGB pixels */

@@ -436,7 +436,7 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     ctx->use_luts = ctx->best_register_mode;
     if (const char *env = getenv("HYDAMD_RANS_WAVES")) {
         const int w = atoi(env);
-        if (w == 4 || w == 8 || w == 16)
+        if (w == 4)
             ctx->rans_waves = w;
         if (w == 64)
             ctx->rans_lanes = 1;
@@ -523,8 +523,8 @@ int hydamd_set_rans_waves(HydAmdContext *ctx, int waves) {
         ctx->rans_lanes = waves + 1;
         return ST_OK;
     }
-    if (waves != 4 && waves != 8 && waves != 16)
-        return fail(ctx, ST_API_ERROR, "rANS workgroups hold 4, 8 or 16 groups (64 selects the lane-per-group form)");
+    if (waves != 4)
+        return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group), 1/2/3 (row forms) or 64 (lane per group)");
     ctx->rans_waves = waves;
     ctx->rans_lanes = 0;
     return ST_OK;

@@ -776,26 +776,24 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
 constexpr int kWinWords = 100; /* 64 symbols x 46 bits = 92 words + alignment slack */
 constexpr int kInvEntries = HYDK_MAX_CLUSTERS * 2 * HYDK_ANS_SLOTS;
 
-/* one step of the recurrence for the symbol whose operands sit in lane `src` (wave-uniform) */
+/* one step of the recurrence; the symbol's operands {-2f, floor(2^32/f), table address, threshold}
+ * were staged in LDS by the lane that owns it and arrive by one broadcast ds_read_b128 */
 #define HYDK_RANS_STEP(src)                                                                   \
     do {                                                                                      \
-        const int n2 = __builtin_amdgcn_readlane(neg2f, (src));                               \
-        const uint32_t mk = __builtin_amdgcn_readlane(mg, (src));                             \
-        const uint32_t ak = __builtin_amdgcn_readlane(adr, (src));                            \
-        const uint32_t tk = __builtin_amdgcn_readlane(thr, (src));                            \
+        const uint4 o = ops[(src)];                                                           \
         /* lane 0 <- state, lane l <- trail[l-1]: the states file past, newest in lane 0 */   \
         trail = (uint32_t)__builtin_amdgcn_update_dpp((int)state, (int)trail, 0x138, 0xF, 0xF, false); \
-        const uint32_t x = state > tk ? state >> 16 : state;                                  \
+        const uint32_t x = state > o.w ? state >> 16 : state;                                 \
         /* q = mulhi(x, floor(2^32/f)) is floor(x/f) or one less, so r = x - q*f < 2f; the   \
          * doubled table returns slot(r mod f) + 4096*(r >= f), which also repairs q.  The    \
          * byte address adr + 2r is formed as (adr + 2x) + q*(-2f): one op after the mulhi */  \
-        const uint32_t q = __umulhi(x, mk);                                                   \
-        const uint32_t at = (uint32_t)__mul24((int)q, n2) + (ak + 2u * x);                    \
+        const uint32_t q = __umulhi(x, o.y);                                                  \
+        const uint32_t at = (uint32_t)__mul24((int)q, (int)o.x) + (o.z + 2u * x);             \
         const uint32_t ent = *(const uint16_t *)(inv_bytes + at);                             \
         state = (q << 12) + ent;                                                              \
     } while (0)
 
-template <int WAVES> /* groups (= waves) per workgroup: 4 for latency, 8 / 16 to pack more chains per CU */
+template <int WAVES> /* groups (= waves) per workgroup */
 __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
                                                             const uint32_t *sym_count_all, const HydkTables *tabs,
                                                             uint32_t *bitbuf_all, uint32_t *group_bits_all,
@@ -806,6 +804,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
     __shared__ uint32_t s_fb[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
     __shared__ uint32_t s_magic[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
     __shared__ uint32_t s_win[WAVES][kWinWords];
+    __shared__ uint4 s_ops[WAVES][64];                               /* per-symbol operands of the chunk being walked */
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int slot = blockIdx.x / kBlocksPerLfg;
@@ -839,6 +838,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
     const uint64_t *tok = tokens_all + G * HYDK_TOKENS_PER_GROUP;
     uint32_t *W = bitbuf_all + G * HYDK_BITWORDS_PER_GROUP;
     uint32_t *win = s_win[wave];
+    uint4 *ops = s_ops[wave];
     const int n = __builtin_amdgcn_readfirstlane((int)sym_count_all[G]); /* wave-uniform: scalar loop control */
     const unsigned char *inv_bytes = (const unsigned char *)s_inv;
 
@@ -894,20 +894,26 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
         cur = newcur;
     };
 
+    uint64_t rec_next = n - 1 - lane >= 0 ? tok[n - 1 - lane] : 0ull;
     for (int hi_p = n - 1; hi_p >= 0; hi_p -= 64) {
         /* lane l owns symbol p = hi_p - l; the walk visits lanes 0, 1, 2, ... */
         const int p = hi_p - lane;
         const bool valid = p >= 0;
-        const uint64_t rec = valid ? tok[p] : 0ull;
+        const uint64_t rec = rec_next;
+        rec_next = p - 64 >= 0 ? tok[p - 64] : 0ull; /* the next chunk's records travel during this chunk's walk */
         const uint32_t lo = (uint32_t)rec;
         const uint32_t e = ((lo >> 8) & 0xF) * HYDK_ALPHABET + (lo & 0xFF);
         const uint32_t fbv = s_fb[e];
         const uint32_t f = valid ? (fbv & 0xFFFFu) : 1u;
-        const int neg2f = -2 * (int)f;
-        const uint32_t mg = s_magic[e];
-        const uint32_t adr = (((lo >> 8) & 0xF) * (2u * HYDK_ANS_SLOTS) + 2u * (fbv >> 16)) * 2u;
         /* (state >> 20) >= f  <=>  state > (f << 20) - 1, exact for f up to 4096 (entropy.c:1092) */
         const uint32_t thr = (uint32_t)(((unsigned long long)f << 20) - 1ull);
+        uint4 op;
+        op.x = (uint32_t)(-2 * (int)f);
+        op.y = s_magic[e];
+        op.z = (((lo >> 8) & 0xF) * (2u * HYDK_ANS_SLOTS) + 2u * (fbv >> 16)) * 2u;
+        op.w = thr;
+        ops[lane] = op;
+        __builtin_amdgcn_wave_barrier();
         const int cnt = min(64, hi_p + 1);
         uint32_t trail = 0;
         if (cnt == 64) {
@@ -920,6 +926,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
             for (int k = 0; k < cnt; k++)
                 HYDK_RANS_STEP(k);
         }
+        __builtin_amdgcn_wave_barrier();
         /* the state seen by step j now sits in lane cnt-1-j; give it back to lane j */
         const uint32_t seen = (uint32_t)__shfl((int)trail, (cnt - 1 - lane) & 63);
         /* refill p is written just before residue p (entropy.c:1134-1147), i.e. prepended after it */
@@ -1411,14 +1418,8 @@ hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t 
 hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
                        uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int waves,
                        hipStream_t stream) {
-    if (waves == 16)
-        hipLaunchKernelGGL(k_rans_encode<16>, dim3(num_slots * 4), dim3(1024), 0, stream, d_jobs, tokens, sym_count, tabs,
-                           bitbuf, group_bits, preset_bits);
-    else if (waves == 8)
-        hipLaunchKernelGGL(k_rans_encode<8>, dim3(num_slots * 8), dim3(512), 0, stream, d_jobs, tokens, sym_count, tabs,
-                           bitbuf, group_bits, preset_bits);
-    else
-        hipLaunchKernelGGL(k_rans_encode<4>, dim3(num_slots * 16), dim3(256), 0, stream, d_jobs, tokens, sym_count, tabs,
+    (void)waves; /* the doubled table + operand staging leave LDS room for exactly four groups per workgroup */
+    hipLaunchKernelGGL(k_rans_encode<4>, dim3(num_slots * 16), dim3(256), 0, stream, d_jobs, tokens, sym_count, tabs,
                            bitbuf, group_bits, preset_bits);
     return hipGetLastError();
 }

@@ -76,11 +76,13 @@ HYDAMD_EXPORT int hydamd_force_luts(HydAmdContext *ctx, int use_luts);
 HYDAMD_EXPORT int hydamd_xyb_mode(HydAmdContext *ctx);
 HYDAMD_EXPORT int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode);
 
-/* Groups (= wavefronts) per rANS workgroup: 4 (default) gives each chain a SIMD of its own and the
- * lowest single-frame latency; 8 or 16 pack more chains per CU so that several frames queued on
- * different contexts/streams can run their entropy stage side by side; 64 selects the
- * lane-per-group form (64 chains per wavefront + a parallel emit kernel): slightly longer latency
- * for one frame, but the entropy stage then occupies one CU per LF group only (throughput mode). */
+/* Form of the entropy (rANS) stage.  The recurrence is serial per group, so the forms trade the
+ * latency of one frame against how much of the GPU the stage occupies while it runs:
+ *   4   one wavefront per group, 4 groups per workgroup (default): lowest single-frame latency
+ *   1   four chains per wavefront (one per 16-lane row), 16 groups per workgroup
+ *   3   same, half an LF group (32 groups) per workgroup, half-size table: best when many frames are in flight
+ *   2   same, a whole LF group (64 groups) per workgroup
+ *   64  one lane per group, 64 chains per wavefront, followed by a parallel emit kernel */
 HYDAMD_EXPORT int hydamd_set_rans_waves(HydAmdContext *ctx, int waves);
 
 /* Start a frame of `num_presets` presets (= LF groups, at most 255): clears histograms and the running alphabet. */

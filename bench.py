@@ -109,13 +109,25 @@ def main():
     for c in ctxs:
         c.set_rans_waves(args.rans_waves)
 
+    pending = []  # contexts whose frame is queued but whose sections have not been exchanged yet
+
+    def exchange(ctx):
+        """N > 1: concatenate every rank's packed sections for the frame `ctx` just coded (RCCL all-gather)."""
+        ctx.sync()
+        sharding.all_gather_sections(ctx.payload_tensor(), dist.group.WORLD)
+
     def step(i):
         ctx = ctxs[i % len(ctxs)]
+        if world > 1 and len(pending) == len(ctxs):
+            exchange(pending.pop(0))  # the oldest frame in flight; its context is the one reused now
         ctx.encode_image_tensor(img)
         if world > 1:
-            ctx.sync()
-            sharding.all_gather_sections(ctx.payload_tensor(), dist.group.WORLD)
+            pending.append(ctx)
         return ctx
+
+    def drain():
+        while pending:
+            exchange(pending.pop(0))
 
     # initialisation, not measurement: every context codes one frame once so that its freshly
     # allocated buffers have been touched before anything is timed; then the W warm-up steps
@@ -125,6 +137,7 @@ def main():
         c.sync()
     for i in range(args.warmup):
         step(i)
+    drain()
     for c in ctxs:
         c.sync()
         c.profile(True)
@@ -134,6 +147,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain()
     for c in ctxs:
         c.sync()
     torch.cuda.synchronize()

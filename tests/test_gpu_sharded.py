@@ -72,3 +72,37 @@ def test_batch_of_frames_round_robin_contexts(image):
     for f, g in zip(frames, got):
         res, _ = orc.encode_lf_group(np.ascontiguousarray(f))
         assert g == res.stream
+
+
+def test_payload_tensor_and_rccl_gather_world_of_one(image):
+    """The pieces bench.py --gpus N strings together, as far as one GPU can exercise them: the
+    zero-copy torch view of the packed sections and sharding.all_gather_sections over the "nccl"
+    (= RCCL) backend."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+    from hydrium_amd import device, sharding
+
+    img = image("photo", 1000, 700, 8)
+    t = _cuda(img)
+    with device.DeviceContext(0, 1, 0) as ctx:
+        ctx.encode_image_tensor(t)
+        ctx.sync()
+        want = ctx.read_payload()
+        view = ctx.payload_tensor()
+        assert view.is_cuda and view.dtype == torch.uint8 and view.numel() == len(want)
+        assert bytes(view.cpu().numpy()) == want
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        try:
+            sizes, gathered = sharding.all_gather_sections(view)
+            torch.cuda.synchronize()
+            assert [int(x) for x in sizes] == [len(want)]
+            assert sharding.concatenate(sizes, gathered) == want
+        finally:
+            dist.destroy_process_group()

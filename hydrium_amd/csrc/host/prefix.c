@@ -237,15 +237,15 @@ int hps_code_lengths(const uint32_t *freq, uint32_t *lengths, uint32_t n, int ma
     HuffNode *nodes = calloc(2 * (size_t)n - 1, sizeof(HuffNode));
     if (!nodes)
         return ST_NOMEM;
-    uint32_t live = 0;
+    uint32_t live_count = 0;
     for (uint32_t i = 0; i < n; i++) {
         nodes[i].freq = freq[i];
         nodes[i].token = (int32_t)i + 1;
         nodes[i].left = nodes[i].right = -1;
-        live += freq[i] != 0;
+        live_count += freq[i] != 0;
     }
     int ret = 0;
-    if (!live) {
+    if (!live_count) {
         ret = ST_INTERNAL;
         goto done;
     }
@@ -253,12 +253,24 @@ int hps_code_lengths(const uint32_t *freq, uint32_t *lengths, uint32_t n, int ma
         max_depth = clog2_u32(n + 1);
     /* Round k settles slots 2k and 2k+1 as the children of merged node n+k.  Candidates are the
      * unsettled slots [2k, n+k) with non-zero weight whose subtree may still grow one level
-     * without the final tree exceeding max_depth. */
-    for (uint32_t k = 0; k + 1 < n; k++, live--) {
-        const int32_t limit = max_depth - clog2_u32(live) + 1;
+     * without the final tree exceeding max_depth.  The reference walks every slot each round;
+     * with LZ77 length tokens starting at 16384 almost all of them have weight zero, so we keep
+     * the weighted slots in an ascending list instead — same visiting order, same result. */
+    uint32_t *live = malloc((2 * (size_t)n) * sizeof(uint32_t));
+    if (!live) {
+        ret = ST_NOMEM;
+        goto done;
+    }
+    size_t nlive = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (nodes[i].freq)
+            live[nlive++] = i;
+    for (uint32_t k = 0; k + 1 < n; k++, live_count--) {
+        const int32_t limit = max_depth - clog2_u32(live_count) + 1;
         int32_t first = -1, second = -1;
-        for (uint32_t j = 2 * k; j < n + k; j++) {
-            if (!nodes[j].freq || nodes[j].deepest >= limit)
+        for (size_t li = 0; li < nlive; li++) {
+            const uint32_t j = live[li];
+            if (nodes[j].deepest >= limit)
                 continue;
             if (first < 0 || node_before(&nodes[j], &nodes[first])) {
                 second = first;
@@ -269,7 +281,7 @@ int hps_code_lengths(const uint32_t *freq, uint32_t *lengths, uint32_t n, int ma
         }
         if (first < 0) {
             ret = ST_INTERNAL;
-            goto done;
+            break;
         }
         HuffNode tmp = nodes[first];
         nodes[first] = nodes[2 * k];
@@ -286,7 +298,23 @@ int hps_code_lengths(const uint32_t *freq, uint32_t *lengths, uint32_t n, int ma
         parent->left = (int32_t)(2 * k);
         parent->right = (int32_t)(2 * k + 1);
         deepen(nodes, (int32_t)(n + k));
+        /* rebuild the ascending list: slots 2k and 2k+1 are settled; the slots the two picks came
+         * from now hold whatever used to sit in 2k / 2k+1 (possibly weightless); n+k is new */
+        size_t w = 0;
+        for (size_t li = 0; li < nlive; li++) {
+            const uint32_t j = live[li];
+            if (j > 2 * k + 1 && nodes[j].freq)
+                live[w++] = j;
+        }
+        /* a pick that came from beyond the list's old entries cannot exist (picks are list members);
+         * but a displaced weighted node may have landed in a slot that was not in the list before
+         * only if that slot was a pick, which the filter above has kept when it now has weight */
+        live[w++] = n + k;
+        nlive = w;
     }
+    free(live);
+    if (ret)
+        goto done;
     for (uint32_t j = 0; j < 2 * n - 1; j++)
         if (nodes[j].token)
             lengths[nodes[j].token - 1] = (uint32_t)nodes[j].depth;

@@ -758,6 +758,22 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
     }
 }
 
+/* inclusive prefix sums in registers (DPP), no LDS round trips */
+#define HYDK_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xF, false))
+__device__ __forceinline__ uint32_t scan16_inclusive(uint32_t v) { /* within each 16-lane row */
+    v += HYDK_DPP(v, 0x111, 0xF); /* row_shr:1 */
+    v += HYDK_DPP(v, 0x112, 0xF); /* row_shr:2 */
+    v += HYDK_DPP(v, 0x114, 0xF); /* row_shr:4 */
+    v += HYDK_DPP(v, 0x118, 0xF); /* row_shr:8 */
+    return v;
+}
+__device__ __forceinline__ uint32_t scan64_inclusive(uint32_t v) {
+    v = scan16_inclusive(v);
+    v += HYDK_DPP(v, 0x142, 0xA); /* row_bcast:15 into rows 1 and 3 */
+    v += HYDK_DPP(v, 0x143, 0xC); /* row_bcast:31 into rows 2 and 3 */
+    return v;
+}
+
 /* ==========================================================================================
  * K3a: reverse rANS.  One wave per group, 4 groups of one LF group per workgroup (they share the
  * preset's tables in LDS).  The state -> state recurrence is strictly serial per group
@@ -852,14 +868,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
     /* wave-parallel emission of one (value, nbits) per lane, lane 0 nearest the already written
      * bits (= latest in stream order), lane 63 earliest */
     auto emit = [&](unsigned long long val, uint32_t nbits) {
-        uint32_t inc = nbits;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d);
-            if (lane >= d)
-                inc += o;
-        }
-        const uint32_t total = __shfl(inc, 63);
+        const uint32_t inc = scan64_inclusive(nbits);
+        const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
         if (!total)
             return;
         const uint32_t newcur = cur - total;
@@ -1028,13 +1038,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_rows(const HydkLfJob *__res
 
     /* 16-lane segmented emission: lane l = 0 of a row is nearest the bits already written */
     auto emit = [&](unsigned long long val, uint32_t nbits) {
-        uint32_t inc = nbits;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d, 16);
-            if (l >= d)
-                inc += o;
-        }
+        const uint32_t inc = scan16_inclusive(nbits);
         const uint32_t total = __shfl(inc, 15, 16);
         const uint32_t newcur = cur - total;
         const uint32_t wlo = newcur >> 5, whi = (cur - 1u) >> 5;
@@ -1091,25 +1095,35 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_rows(const HydkLfJob *__res
         __builtin_amdgcn_wave_barrier();
         const int cnt = min(16, hi_p + 1); /* per row; <= 0 once the row's group is finished */
         uint32_t trail = 0;
+#define HYDK_ROW_STEP(k)                                                                                   \
+    do {                                                                                                   \
+        const uint4 o = ops[(k)];                                                                          \
+        trail = (uint32_t)__builtin_amdgcn_update_dpp((int)state, (int)trail, 0x111, 0xF, 0xF, false);     \
+        const uint32_t x = state > o.w ? state >> 16 : state;                                              \
+        uint32_t q = __umulhi(x, o.y);                                                                     \
+        if (DOUBLED) {                                                                                     \
+            const uint32_t at = (uint32_t)__mul24((int)q, (int)o.x) + (o.z + 2u * x);                      \
+            state = (q << 12) + *(const uint16_t *)(inv_bytes + at);                                       \
+        } else {                                                                                           \
+            /* q is floor(x/f) or one less: fold the remainder back below f and bump q */                  \
+            const uint32_t r0 = x - __umul24(q, o.x);                                                      \
+            const uint32_t r = min(r0, r0 - o.x);                                                          \
+            q += r0 >= o.x;                                                                                \
+            state = (q << 12) | *(const uint16_t *)(inv_bytes + o.z + 2u * r);                             \
+        }                                                                                                  \
+    } while (0)
+        if (__all(cnt == 16)) {
+            /* every row of the wave has a full round: no per-step predication */
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            if (k < cnt) {
-                const uint4 o = ops[k];
-                trail = (uint32_t)__builtin_amdgcn_update_dpp((int)state, (int)trail, 0x111, 0xF, 0xF, false);
-                const uint32_t x = state > o.w ? state >> 16 : state;
-                uint32_t q = __umulhi(x, o.y);
-                if (DOUBLED) {
-                    const uint32_t at = (uint32_t)__mul24((int)q, (int)o.x) + (o.z + 2u * x);
-                    state = (q << 12) + *(const uint16_t *)(inv_bytes + at);
-                } else {
-                    /* q is floor(x/f) or one less: fold the remainder back below f and bump q */
-                    const uint32_t r0 = x - __umul24(q, o.x);
-                    const uint32_t r = min(r0, r0 - o.x);
-                    q += r0 >= o.x;
-                    state = (q << 12) | *(const uint16_t *)(inv_bytes + o.z + 2u * r);
-                }
-            }
+            for (int k = 0; k < 16; k++)
+                HYDK_ROW_STEP(k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < cnt)
+                    HYDK_ROW_STEP(k);
         }
+#undef HYDK_ROW_STEP
         __builtin_amdgcn_wave_barrier();
         /* the state seen by step j sits in lane cnt-1-j of the row */
         const uint32_t seen = (uint32_t)__shfl((int)trail, (cnt - 1 - l) & 15, 16);
@@ -1238,14 +1252,8 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
     uint32_t carry = 0;
 
     auto emit = [&](unsigned long long val, uint32_t nbits) {
-        uint32_t inc = nbits;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d);
-            if (lane >= d)
-                inc += o;
-        }
-        const uint32_t total = __shfl(inc, 63);
+        const uint32_t inc = scan64_inclusive(nbits);
+        const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
         if (!total)
             return;
         const uint32_t newcur = cur - total;

@@ -24,6 +24,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CC = os.environ.get("CC", "gcc")
 
 HIP_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+             "-fno-slp-vectorize",  # packed-f32 chains need a wait state per dependent op on gfx950: slower than scalar
              "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}"]
 C_FLAGS = ["-std=c99", "-O2", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall", "-Wextra",
            "-Wno-unused-parameter", "-DHYDRIUM_INTERNAL_BUILD", f"-I{os.path.join(ROOT, 'include')}",

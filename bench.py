@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--rans-waves", type=int, default=3, choices=(1, 2, 3, 4, 64),
                     help="entropy-stage form, see hydamd_set_rans_waves: 3 = four chains per wave, half an LF group "
                          "per workgroup (throughput); 4 = one wave per group (lowest single-frame latency)")
+    ap.add_argument("--lf-coder", default="on", choices=("on", "off"),
+                    help="code the LF coefficient streams on the GPU inside the timed loop (default) or leave them out")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
     return ap.parse_args()
@@ -108,6 +110,7 @@ def main():
     ctxs = [device.DeviceContext(local, lfg, 0) for _ in range(max(1, args.streams))]
     for c in ctxs:
         c.set_rans_waves(args.rans_waves)
+        c.set_lf_coder(args.lf_coder == "on")
 
     pending = []  # contexts whose frame is queued but whose sections have not been exchanged yet
 
@@ -192,6 +195,30 @@ def main():
         lat = {"ms_per_frame": round(tl * 1e3, 4), "Mpixel/s": round(W * H / tl / 1e6, 1), "kernel_avg_ms": lk,
                "note": "one stream, one frame at a time, rANS form 4 (one wave per group); kernels not overlapped"}
 
+    # reference leg: the same loop with the LF-group coder switched off (SURVEY.md 8(d)(ii)'s narrower
+    # definition: device-resident input -> HF group sections only)
+    hf_only = None
+    if world == 1 and args.lf_coder == "on":
+        for c in ctxs:
+            c.set_lf_coder(False)
+        for i in range(len(ctxs)):
+            step(i)
+        for c in ctxs:
+            c.sync()
+        torch.cuda.synchronize()
+        k2 = max(len(ctxs), args.steps // 2)
+        t2 = time.perf_counter()
+        for i in range(k2):
+            step(i)
+        for c in ctxs:
+            c.sync()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter() - t2
+        hf_only = {"Mpixel/s": round(W * H * k2 / t2 / 1e6, 1), "steps": k2,
+                   "note": "same loop, LF coder off: HF group sections only, LF ints left for a host coder"}
+        for c in ctxs:
+            c.set_lf_coder(True)
+
     if rank == 0:
         bytes_in = W * H * 3 * (args.depth // 8)
         kernels = {k: {"avg_ms": round(v[0] / max(v[1], 1), 4), "launches": v[1],
@@ -215,7 +242,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{W}x{H} RGB{args.depth} '{args.kind}' frame per GPU (BASELINE configs[2]); "
                                    "hot path device-resident RGB -> packed HF group sections "
-                                   "(XYB, DCT, quantise, tokenise, ANS tables, rANS, pack)",
+                                   "(XYB, DCT, quantise, tokenise, ANS tables, rANS, pack)" +
+                                   (" + prefix-coded LF coefficient streams" if args.lf_coder == "on" else ""),
+                       "lf_coder": "gpu" if args.lf_coder == "on" else "off",
                        "groups": lfg * 64 if W % 2048 == 0 and H % 2048 == 0 else None, "lf_groups": lfg,
                        "streams": len(ctxs), "rans_groups_per_workgroup": args.rans_waves, "parallelism": f"{world} x (one frame per GPU)" +
                                                             (", RCCL all-gather of sections" if world > 1 else "")},
@@ -225,6 +254,7 @@ def main():
             "kernels": kernels,
             "kernels_note": "per-launch durations in the timed region, where the streams' kernels overlap each other",
             "single_frame": lat,
+            "hf_sections_only": hf_only,
             "symbols_per_pixel": round(symbols / (W * H), 4),
             "section_bytes": payload_bytes,
             "hbm_read_roofline_Mpx_s": round(HBM_PEAK_GBS * 1e9 / (3 * args.depth // 8) / 1e6, 0),
@@ -235,7 +265,7 @@ def main():
             arr = img.cpu().numpy()
             host_img = np.ascontiguousarray(arr.view(np.uint16) if args.depth == 16 else arr)
         if world == 1 and not args.no_api:
-            # API end-to-end through the drop-in hyd_send_tile (host pixels: includes PCIe, host LF coder, assembly)
+            # API end-to-end through the drop-in hyd_send_tile (host pixels: includes PCIe, read-back, assembly)
             lib = api.Library()
             api.encode_image(lib, host_img[:2048, :2048].copy())  # warm the library
             t1 = time.perf_counter()
@@ -243,7 +273,7 @@ def main():
             t_api = time.perf_counter() - t1
             out["api_end_to_end"] = {"Mpixel/s": round(W * H / t_api / 1e6, 1), "ms": round(t_api * 1e3, 1),
                                      "bytes": len(data), "md5": hashlib.md5(data).hexdigest(),
-                                     "note": "host-pointer hyd_send_tile path, one-frame mode; PCIe + host LF coder inclusive"}
+                                     "note": "host-pointer hyd_send_tile path, one-frame mode; PCIe, read-back and host frame assembly inclusive"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_img)
             if "api_end_to_end" in out and "md5" in out["cpu_baseline"]:

@@ -7,6 +7,7 @@
  *                       tables   HydkTables                          =  86 KB
  *                       dc       3 x 256 x 256 int32                 = 768 KB
  *                       hist / counts / section bits+offsets         <   8 KB
+ *                       LF coder: records 196608 x 8 B + bits        =   3.0 MB  (hard worst case)
  *   per context         in_lut8 (512 B), in_lut16 (128 KB), bias_lut (256 KB)
  *                       payload  packed HF sections, sized like bitbuf (its hard upper bound)
  *                       2 x (pinned host + device) staging tiles for the host-pointer path
@@ -43,6 +44,9 @@ hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, uint64_t *tokens, const ui
 hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, hipStream_t stream);
 hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
                        int count, hipStream_t stream);
+hipError_t launch_lf_coder(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, HydkLfStream *streams,
+                           uint32_t *bits, int num_slots, hipStream_t stream);
+hipError_t launch_lf_huffman_only(const uint32_t *hist, HydkLfStream *stream_out, uint32_t *codes, hipStream_t stream);
 hipError_t launch_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, int linear_light, int xmode,
                                uint32_t *mismatches, hipStream_t stream);
 } // namespace hydk
@@ -54,7 +58,7 @@ hipError_t launch_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, 
 #define ST_INTERNAL_ERROR (-15)
 
 static_assert(HYDAMD_MAX_CLUSTERS == HYDK_MAX_CLUSTERS && HYDAMD_ALPHABET == HYDK_ALPHABET &&
-                  HYDAMD_GROUPS_PER_LFG == HYDK_GROUPS_PER_LFG,
+                  HYDAMD_GROUPS_PER_LFG == HYDK_GROUPS_PER_LFG && HYDAMD_LF_CODES == HYDK_LF_CODES,
               "public and kernel-side table shapes must agree");
 
 namespace {
@@ -113,6 +117,17 @@ struct HydAmdContext {
     float *bias_lut = nullptr;
     uint8_t *payload = nullptr;
     size_t payload_cap = 0;
+
+    /* LF-group coder (lf_coder.hip): runs on its own stream between two events of the main one */
+    int lf_on_device = 1;
+    unsigned long long *lf_recs = nullptr; /* [slots][HYDK_LF_SYMBOLS] */
+    uint32_t *lf_hist = nullptr;           /* [slots + 1][HYDK_LF_CODES]; the last entry is hydamd_debug_lf_code's scratch */
+    uint32_t *lf_codes = nullptr;          /* [HYDK_LF_CODES] likewise */
+    HydkLfStream *lf_streams = nullptr;    /* [slots + 1] */
+    uint32_t *lf_bits = nullptr;           /* [slots][HYDK_LF_BITWORDS] */
+    hipStream_t lf_stream = nullptr;
+    hipEvent_t lf_fork = nullptr, lf_join = nullptr;
+    bool lf_pending = false;
     float *dbg_xyb = nullptr, *dbg_dct = nullptr;
     int32_t *dbg_quant = nullptr;
 
@@ -135,8 +150,8 @@ struct HydAmdContext {
     /* profiling */
     bool profiling = false;
     std::vector<TimedLaunch> timed;
-    double prof_ms[HYDAMD_K_COUNT] = {0, 0, 0, 0};
-    uint64_t prof_n[HYDAMD_K_COUNT] = {0, 0, 0, 0};
+    double prof_ms[HYDAMD_K_COUNT] = {0, 0, 0, 0, 0};
+    uint64_t prof_n[HYDAMD_K_COUNT] = {0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -193,18 +208,19 @@ struct ScopedTimer {
     HydAmdContext *ctx;
     TimedLaunch tl;
     bool on;
-    ScopedTimer(HydAmdContext *c, int cls) : ctx(c), on(c->profiling) {
+    hipStream_t stream;
+    ScopedTimer(HydAmdContext *c, int cls, hipStream_t s = nullptr) : ctx(c), on(c->profiling), stream(s ? s : c->stream) {
         if (!on)
             return;
         tl.cls = cls;
         (void)hipEventCreate(&tl.start);
         (void)hipEventCreate(&tl.stop);
-        (void)hipEventRecord(tl.start, ctx->stream);
+        (void)hipEventRecord(tl.start, stream);
     }
     ~ScopedTimer() {
         if (!on)
             return;
-        (void)hipEventRecord(tl.stop, ctx->stream);
+        (void)hipEventRecord(tl.stop, stream);
         ctx->timed.push_back(tl);
     }
 };
@@ -338,6 +354,18 @@ void hydamd_destroy(HydAmdContext *ctx) {
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     drain_timers(ctx);
+    if (ctx->lf_stream) {
+        (void)hipStreamSynchronize(ctx->lf_stream);
+        (void)hipStreamDestroy(ctx->lf_stream);
+    }
+    if (ctx->lf_fork)
+        (void)hipEventDestroy(ctx->lf_fork);
+    if (ctx->lf_join)
+        (void)hipEventDestroy(ctx->lf_join);
+    void *lfdev[] = {ctx->lf_recs, ctx->lf_hist, ctx->lf_codes, ctx->lf_streams, ctx->lf_bits};
+    for (void *p : lfdev)
+        if (p)
+            (void)hipFree(p);
     void *dev[] = {ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->hist, ctx->sym_count, ctx->group_bits,
                    ctx->offsets, ctx->total, ctx->status, ctx->alpha_max, ctx->final_state, ctx->d_jobs, ctx->in_lut8, ctx->in_lut16,
                    ctx->bias_lut, ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant, ctx->d_arena};
@@ -383,6 +411,15 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipMalloc(&ctx->alpha_max, slots * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->final_state, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_jobs, slots * sizeof(HydkLfJob)));
+    HIP_TRY(ctx, hipMalloc(&ctx->lf_recs, slots * HYDK_LF_SYMBOLS * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc(&ctx->lf_hist, (slots + 1) * HYDK_LF_CODES * sizeof(uint32_t))); /* +1: the unit-test entry's scratch */
+    HIP_TRY(ctx, hipMalloc(&ctx->lf_codes, HYDK_LF_CODES * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->lf_streams, (slots + 1) * sizeof(HydkLfStream)));
+    HIP_TRY(ctx, hipMalloc(&ctx->lf_bits, slots * HYDK_LF_BITWORDS * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemset(ctx->lf_streams, 0, (slots + 1) * sizeof(HydkLfStream)));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lf_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_fork, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_join, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) {
         HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_jobs_ring[i], slots * sizeof(HydkLfJob), hipHostMallocDefault));
         memset(ctx->h_jobs_ring[i], 0, slots * sizeof(HydkLfJob));
@@ -443,6 +480,8 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
         if (w >= 1 && w <= 3)
             ctx->rans_lanes = w + 1;
     }
+    if (const char *env = getenv("HYDAMD_LF_CODER")) /* 0: leave the LF ints to the host coder (A/B measurements) */
+        ctx->lf_on_device = atoi(env) != 0;
     if (const char *env = getenv("HYDAMD_XYB_MODE")) { /* 0 / 1 / 2, never faster than what was proven exact */
         const int m = atoi(env);
         if (m >= ctx->best_register_mode && m <= 2)
@@ -635,6 +674,27 @@ int hydamd_run_transform(HydAmdContext *ctx, int num_slots) {
         HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs, num_slots, ctx->fmt_mask, ctx->use_luts, ctx->status,
                                             ctx->stream));
     }
+    if (ctx->lf_on_device) {
+        /* the LF coder needs only the LF ints the transform kernel just wrote: fork it onto its own
+         * stream so it overlaps the HF entropy stage; hydamd_run_entropy / hydamd_sync join it */
+        HIP_TRY(ctx, hipEventRecord(ctx->lf_fork, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->lf_stream, ctx->lf_fork, 0));
+        {
+            ScopedTimer timer(ctx, HYDAMD_K_LF, ctx->lf_stream);
+            HIP_TRY(ctx, hydk::launch_lf_coder(ctx->d_jobs, ctx->lf_recs, ctx->lf_hist, ctx->lf_streams, ctx->lf_bits,
+                                               num_slots, ctx->lf_stream));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->lf_join, ctx->lf_stream));
+        ctx->lf_pending = true;
+    }
+    return ST_OK;
+}
+
+static int join_lf(HydAmdContext *ctx) {
+    if (ctx->lf_pending) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->lf_join, 0));
+        ctx->lf_pending = false;
+    }
     return ST_OK;
 }
 
@@ -686,6 +746,11 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
         HIP_TRY(ctx, hydk::launch_scan(ctx->group_bits, count, ctx->offsets, ctx->total, ctx->stream));
         HIP_TRY(ctx, hydk::launch_pack(ctx->bitbuf, ctx->group_bits, ctx->offsets, ctx->payload, count, ctx->stream));
     }
+    {
+        const int st = join_lf(ctx);
+        if (st != ST_OK)
+            return st;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_total_pinned, ctx->total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status_pinned, ctx->status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     ctx->slots_finished = num_slots;
@@ -703,6 +768,11 @@ int hydamd_sync(HydAmdContext *ctx) {
     if (!ctx)
         return ST_API_ERROR;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        const int st = join_lf(ctx);
+        if (st != ST_OK)
+            return st;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     drain_timers(ctx);
     ctx->h_total = *ctx->h_total_pinned;
@@ -774,6 +844,72 @@ int hydamd_read_dc(HydAmdContext *ctx, int slot, int32_t *dst, size_t vbw, size_
         HIP_TRY(ctx, hipMemcpy2D(dst + (size_t)c * vbw * vbh, vbw * sizeof(int32_t),
                                  src + (size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH, HYDK_DC_PITCH * sizeof(int32_t),
                                  vbw * sizeof(int32_t), vbh, hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int hydamd_set_lf_coder(HydAmdContext *ctx, int on_device) {
+    if (!ctx)
+        return ST_API_ERROR;
+    ctx->lf_on_device = on_device != 0;
+    return ST_OK;
+}
+
+int hydamd_lf_coder(HydAmdContext *ctx) { return ctx ? ctx->lf_on_device : 0; }
+
+int hydamd_read_lf_stream(HydAmdContext *ctx, int slot, uint8_t lengths[HYDAMD_LF_CODES], uint32_t *alphabet,
+                          uint32_t *run_pairs, uint32_t *bit_count) {
+    int st = check_slot(ctx, slot);
+    if (st != ST_OK)
+        return st;
+    if (!ctx->lf_on_device || !ctx->results_valid)
+        return fail(ctx, ST_API_ERROR, "no device-coded LF stream: the LF coder is off or the frame was not synchronised");
+    HydkLfStream h;
+    HIP_TRY(ctx, hipMemcpy(&h, ctx->lf_streams + slot, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.error)
+        return fail(ctx, ST_INTERNAL_ERROR, "LF code construction failed on the device");
+    memcpy(lengths, h.lengths, HYDK_LF_CODES);
+    if (alphabet)
+        *alphabet = h.alphabet;
+    if (run_pairs)
+        *run_pairs = h.run_pairs;
+    if (bit_count)
+        *bit_count = h.bit_count;
+    return ST_OK;
+}
+
+int hydamd_read_lf_bits(HydAmdContext *ctx, int slot, uint8_t *dst, size_t capacity) {
+    int st = check_slot(ctx, slot);
+    if (st != ST_OK)
+        return st;
+    if (!ctx->lf_on_device || !ctx->results_valid)
+        return fail(ctx, ST_API_ERROR, "no device-coded LF stream: the LF coder is off or the frame was not synchronised");
+    if (capacity > (size_t)HYDK_LF_BITWORDS * sizeof(uint32_t))
+        return fail(ctx, ST_API_ERROR, "LF bit request too large");
+    if (capacity)
+        HIP_TRY(ctx, hipMemcpy(dst, ctx->lf_bits + (size_t)slot * HYDK_LF_BITWORDS, capacity, hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int hydamd_debug_lf_code(HydAmdContext *ctx, const uint32_t hist[HYDAMD_LF_CODES], uint8_t lengths[HYDAMD_LF_CODES],
+                         uint32_t codes[HYDAMD_LF_CODES], uint32_t *alphabet, uint32_t *error) {
+    if (!ctx)
+        return ST_API_ERROR;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t spare = (size_t)ctx->max_slots; /* the scratch entry behind the frame's slots */
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->lf_stream));
+    uint32_t *d_hist = ctx->lf_hist + spare * HYDK_LF_CODES;
+    HIP_TRY(ctx, hipMemcpy(d_hist, hist, HYDK_LF_CODES * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hydk::launch_lf_huffman_only(d_hist, ctx->lf_streams + spare, ctx->lf_codes, ctx->lf_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->lf_stream));
+    HydkLfStream h;
+    HIP_TRY(ctx, hipMemcpy(&h, ctx->lf_streams + spare, sizeof(h), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(codes, ctx->lf_codes, HYDK_LF_CODES * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    memcpy(lengths, h.lengths, HYDK_LF_CODES);
+    if (alphabet)
+        *alphabet = h.alphabet;
+    if (error)
+        *error = h.error;
     return ST_OK;
 }
 

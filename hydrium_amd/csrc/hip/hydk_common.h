@@ -74,4 +74,23 @@ typedef struct HydkLfJob {
     int32_t *dbg_quant;
 } HydkLfJob;
 
+/* ---- LF-group coder (the modular sub-stream of the LF coefficients, encoder.c:560-596) ----
+ * One LF group sends 3 x vbw x vbh residuals through a prefix-coded stream with hybrid-uint
+ * config (7,1,1) and LZ77 used as run-length coding (min symbol 16384, min length 3).  Only these
+ * tokens can occur: literals 0..227 and run tokens 16385..16508; the coder keeps them in a compact
+ * index space of HYDK_LF_CODES entries: [0,256) literals, [256,384) token 16384 + (i - 256). */
+#define HYDK_LF_SYMBOLS (3 * HYDK_DC_PITCH * HYDK_DC_PITCH)
+#define HYDK_LF_CODES 384
+#define HYDK_LF_RUN_BASE 16384
+/* worst case per coefficient: 15-bit code + 29 residue bits + a 15-bit run code = 59 bits */
+#define HYDK_LF_BITWORDS (HYDK_LF_SYMBOLS * 2 + 2)
+
+typedef struct HydkLfStream {
+    uint32_t bit_count;                /* bits of symbol data in the slot's bit buffer */
+    uint32_t alphabet;                 /* largest token + 1 of the value cluster */
+    uint32_t run_pairs;                /* (run token, distance) pairs sent; the distance cluster only ever sees token 1 */
+    uint32_t error;                    /* non-zero: code construction failed */
+    uint8_t lengths[HYDK_LF_CODES];    /* prefix-code length per compact token index (0 = unused) */
+} HydkLfStream;
+
 #endif /* HYDK_COMMON_H_ */

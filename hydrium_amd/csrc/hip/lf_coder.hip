@@ -1,0 +1,739 @@
+/*
+ * lf_coder.hip — the LF-group coder on the GPU.
+ *
+ * What it replaces (file:line relative to /root/reference/src/libhydrium/): the LF-coefficient
+ * sub-stream of write_lf_group (encoder.c:560-596): clamped-gradient prediction of the LF ints,
+ * hyd_entropy_send_symbol with LZ77 used as run-length coding (entropy.c:473-524), the
+ * depth-limited Huffman construction with its selection order (entropy.c:577-662), canonical code
+ * assignment (entropy.c:664-707) and the symbol write-out (entropy.c:1003-1021).  The constant
+ * sub-streams around it (MA tree, HF metadata) and the code-length header stay on the host
+ * (csrc/host/frame.c), which receives the code lengths and the packed symbol bits from here.
+ *
+ * The stream is one value sequence per LF group: channels Y, X, B, raster inside a channel,
+ * n = 3 * vbw * vbh <= 196608 values.  One workgroup of 1024 threads per LF group, three phases:
+ *
+ *   tokens        residuals -> run structure -> one 8-byte record per value + token histogram.
+ *                 A maximal run of equal values is cut into chunks of 128: the chunk's first value
+ *                 is a literal; the r <= 127 repeats behind it become one (run token r - 3,
+ *                 distance) pair when r > 3 and r literals otherwise.  What a position emits
+ *                 therefore depends only on its offset in its run (forward max-scan of run starts)
+ *                 and on at most 127 values ahead, so a pass decides 3968 positions from a window
+ *                 of 4096.
+ *   code          one wavefront: the reference's O(n^2) selection loop with the two smallest
+ *                 candidates found by a wave-wide minimum over a total order that reproduces its
+ *                 comparator and slot-visiting order; subtree depth recursion replaced by subtree
+ *                 heights and a parent walk.  Runs in a compact slot space (only the slots the
+ *                 16509-entry alphabet can ever touch) with all candidates held in registers: no
+ *                 LDS traffic or barrier inside the merge loop.
+ *   pack          per-value bit strings (<= 59 bits), block prefix sum, OR into an LDS window,
+ *                 coalesced flush; LSB-first like HYDBitWriter (bitwriter.c:110-124).
+ *
+ * k_lf_tokens is the first phase, k_lf_code the other two (see the note above the kernels).
+ *
+ * None of this is throughput-critical (<= 196608 values per 4.2 Mpx LF group); it exists so that a
+ * frame's sections are complete on the device and the host's per-frame serial work disappears.
+ * The kernels run on a side stream, concurrently with the HF entropy stage.
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "hydk_common.h"
+
+namespace {
+
+constexpr int kLfThreads = 1024;
+constexpr int kScanSpan = kLfThreads * 4;       /* values looked at per pass */
+constexpr int kAhead = 128;                     /* a run chunk is at most 128 values */
+constexpr int kEmitSpan = kScanSpan - kAhead;   /* values decided per pass of k_lf_tokens */
+constexpr int kPlane = HYDK_DC_PITCH * HYDK_DC_PITCH;
+
+/* record: bits 0-31 value, bit 32 "emit a literal", bits 33-39 run length r (0: no run pair) */
+#define LF_REC(v, lit, r) ((unsigned long long)(v) | ((unsigned long long)((uint32_t)(lit) | ((uint32_t)(r) << 1)) << 32))
+
+struct LfShape {
+    int vbw, blocks, n;
+};
+
+__device__ __forceinline__ LfShape lf_shape(const HydkLfJob &job) {
+    LfShape sh;
+    sh.vbw = (job.width + 7) >> 3;
+    sh.blocks = sh.vbw * ((job.height + 7) >> 3);
+    sh.n = 3 * sh.blocks;
+    return sh;
+}
+
+/* hybrid-uint config (split 7, msb 1, lsb 1), entropy.c:427-444 */
+__device__ __forceinline__ void lf_hybrid(uint32_t v, uint32_t &token, uint32_t &nbits, uint32_t &residue) {
+    if (v < 128u) {
+        token = v;
+        nbits = 0;
+        residue = 0;
+        return;
+    }
+    const uint32_t nb = (31u - (uint32_t)__clz(v)) - 2u;
+    residue = (v >> 1) & ((1u << nb) - 1u);
+    token = 128u + (((nb - 5u) << 2) | (((v >> (nb + 1u)) & 1u) << 1) | (v & 1u));
+    nbits = nb;
+}
+
+#define LF_DPP_KEEP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, rmask, 0xF, false))
+#define LF_DPP_ZERO(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xF, false))
+
+/* inclusive scans over the wavefront: row_shr 1/2/4/8 inside each row of 16, then row_bcast 15 / 31 */
+__device__ __forceinline__ int wave_incl_max(int v) {
+    int t;
+    t = (int)LF_DPP_KEEP(v, 0x111, 0xF);
+    v = v > t ? v : t;
+    t = (int)LF_DPP_KEEP(v, 0x112, 0xF);
+    v = v > t ? v : t;
+    t = (int)LF_DPP_KEEP(v, 0x114, 0xF);
+    v = v > t ? v : t;
+    t = (int)LF_DPP_KEEP(v, 0x118, 0xF);
+    v = v > t ? v : t;
+    t = (int)LF_DPP_KEEP(v, 0x142, 0xA);
+    v = v > t ? v : t;
+    t = (int)LF_DPP_KEEP(v, 0x143, 0xC);
+    v = v > t ? v : t;
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
+    v += LF_DPP_ZERO(v, 0x111, 0xF);
+    v += LF_DPP_ZERO(v, 0x112, 0xF);
+    v += LF_DPP_ZERO(v, 0x114, 0xF);
+    v += LF_DPP_ZERO(v, 0x118, 0xF);
+    v += LF_DPP_ZERO(v, 0x142, 0xA);
+    v += LF_DPP_ZERO(v, 0x143, 0xC);
+    return v;
+}
+
+/* wave-level ordering of LDS traffic inside one wavefront (lock-step execution + in-order LDS make
+ * the data visible; this only pins the compiler) */
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* ==========================================================================================
+ * phase 1 (all 1024 threads): residuals -> run structure -> records + token histogram in LDS.
+ * Thread t owns window positions 4t .. 4t+3.  Two barriers per pass: the LF ints of the next pass
+ * are fetched while this one is processed, values stay in registers, run starts and wave totals
+ * are double-buffered.
+ * ======================================================================================== */
+struct LfTokenScratch {
+    int wtot[2][kLfThreads / 64];
+};
+
+struct LfWindow {
+    uint32_t v[4];   /* the thread's four values */
+    uint32_t before; /* the value in front of v[0]; fetched by lane 0 of each wave only */
+};
+
+/* value of the stream at plane c, block (y, x): pack_signed(lf - clamped_gradient(w, n, nw)),
+ * encoder.c:574-594, in 32-bit wrap-around arithmetic (as the reference's int32 code behaves on the
+ * targets it runs on); four unconditional loads with edge-clamped indices */
+__device__ __forceinline__ uint32_t lf_residual_at(const int32_t *dc, int c, int y, int x) {
+    const int idx = c * kPlane + y * HYDK_DC_PITCH + x;
+    const int iw = x ? idx - 1 : y ? idx - HYDK_DC_PITCH : idx;
+    const int in = y ? idx - HYDK_DC_PITCH : iw;
+    const int inw = x && y ? idx - HYDK_DC_PITCH - 1 : iw;
+    const int32_t cur = dc[idx];
+    int32_t w = dc[iw];
+    int32_t n = dc[in];
+    int32_t nw = dc[inw];
+    if (!(x | y)) /* top-left block: all three neighbours count as 0 */
+        w = n = nw = 0;
+    const int32_t lo = w < n ? w : n, hi = w < n ? n : w;
+    int32_t pred = (int32_t)((uint32_t)w + (uint32_t)n - (uint32_t)nw);
+    pred = pred < lo ? lo : pred > hi ? hi : pred;
+    const uint32_t d = (uint32_t)cur - (uint32_t)pred;
+    return (d << 1) ^ (0u - (d >> 31));
+}
+
+/* the thread's four consecutive values from stream position i0 on: one division, then stepping
+ * (measured: a branch-free variant with all twenty loads in flight is slower — the phase is bound by
+ * instruction issue on its one CU, not by load latency) */
+__device__ __forceinline__ void lf_fetch(const int32_t *dc, const LfShape &sh, int i0, int lane, LfWindow &w) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        w.v[j] = 0;
+    w.before = 0;
+    if (i0 > sh.n)
+        return;
+    int visit = (i0 >= sh.blocks) + (i0 >= 2 * sh.blocks) + (i0 >= 3 * sh.blocks);
+    const int rem = i0 - visit * sh.blocks;
+    int y = rem / sh.vbw, x = rem - y * sh.vbw;
+    const int vbh = sh.blocks / sh.vbw;
+    if (lane == 0 && i0 > 0) { /* position i0 - 1 */
+        int pv = visit, py = y, px = x - 1;
+        if (px < 0) {
+            px = sh.vbw - 1;
+            if (--py < 0) {
+                py = vbh - 1;
+                pv--;
+            }
+        }
+        w.before = lf_residual_at(dc, pv < 2 ? 1 - pv : 2, py, px);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (visit < 3)
+            w.v[j] = lf_residual_at(dc, visit < 2 ? 1 - visit : 2, y, x);
+        if (++x == sh.vbw) {
+            x = 0;
+            if (++y == vbh) {
+                y = 0;
+                visit++;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void lf_tokens_phase(const HydkLfJob &job, const LfShape &sh, unsigned long long *__restrict__ recs,
+                                                int *s_rs2 /* [2][kScanSpan] */, uint32_t *s_hist, LfTokenScratch &S) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *dc = job.dc;
+    const int q0 = tid * 4;
+
+    for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads)
+        s_hist[i] = 0;
+
+    LfWindow next;
+    lf_fetch(dc, sh, q0, lane, next);
+    int carry = 0; /* run start of the position in front of the window (position 0 is a head, so unused at first) */
+    int buf = 0;
+    for (int tb = 0; tb < sh.n; tb += kEmitSpan, buf ^= 1) {
+        const LfWindow cur = next;
+        if (tb + kEmitSpan < sh.n)
+            lf_fetch(dc, sh, tb + kEmitSpan + q0, lane, next);
+        int *s_rs = s_rs2 + buf * kScanSpan;
+
+        /* start of the run each position belongs to (absolute index): max-scan of run heads */
+        uint32_t prev = LF_DPP_KEEP(cur.v[3], 0x138, 0xF); /* wave_shr:1 — the previous lane's last value */
+        if (lane == 0)
+            prev = cur.before;
+        int rs[4];
+        int last = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = tb + q0 + j;
+            if (i == 0 || i >= sh.n || cur.v[j] != prev)
+                last = i;
+            rs[j] = last;
+            prev = cur.v[j];
+        }
+        const int inc = wave_incl_max(last);
+        if (lane == 63)
+            S.wtot[buf][wave] = inc;
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wave; w++) {
+            const int t = S.wtot[buf][w];
+            pre = pre > t ? pre : t;
+        }
+        {
+            int excl = (int)LF_DPP_KEEP(inc, 0x138, 0xF);
+            if (lane == 0)
+                excl = -1;
+            pre = pre > excl ? pre : excl;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (rs[j] < 0)
+                rs[j] = pre;
+        *(int4 *)&s_rs[q0] = make_int4(rs[0], rs[1], rs[2], rs[3]);
+        __syncthreads();
+        carry = s_rs[kEmitSpan - 1];
+
+        /* what each position sends */
+        unsigned long long out[4];
+        bool store = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q = q0 + j, i = tb + q;
+            out[j] = 0;
+            if (q >= kEmitSpan || i >= sh.n)
+                continue;
+            store = true;
+            const int c = (i - rs[j]) & 127; /* offset inside the run's current 128-chunk */
+            uint32_t lit = 0, r = 0;
+            if (c <= 3) {
+                const int s4 = q - c + 4; /* fifth value of the chunk, window-relative */
+                const bool same4 = tb + s4 < sh.n && s_rs[s4] == rs[j];
+                if (c == 0) {
+                    lit = 1;
+                    if (same4) { /* more than 3 repeats: how many, up to 127 */
+                        int lo = s4, hi = q + 127;
+                        if (hi > sh.n - 1 - tb)
+                            hi = sh.n - 1 - tb;
+                        while (lo < hi) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (s_rs[mid] == rs[j])
+                                lo = mid;
+                            else
+                                hi = mid - 1;
+                        }
+                        r = (uint32_t)(lo - q);
+                    }
+                } else {
+                    lit = !same4;
+                }
+            }
+            out[j] = LF_REC(cur.v[j], lit, r);
+            if (lit) {
+                uint32_t token, nb, res;
+                lf_hybrid(cur.v[j], token, nb, res);
+                atomicAdd(&s_hist[token], 1u);
+            }
+            if (r)
+                atomicAdd(&s_hist[256u + r - 3u], 1u);
+        }
+        if (store) { /* a thread's four records are 32 contiguous bytes; the tail of the stream is padded, never read */
+            ulonglong2 *dst = (ulonglong2 *)(recs + tb + q0);
+            dst[0] = make_ulonglong2(out[0], out[1]);
+            dst[1] = make_ulonglong2(out[2], out[3]);
+        }
+    }
+    __syncthreads();
+}
+
+/* ==========================================================================================
+ * k_lf_huffman: grid = LF groups, block = 64 (one wavefront)
+ *
+ * Slot space of the reference's node array for an alphabet of n tokens: leaves 0..n-1, merged node
+ * k at n + k; round k settles slots 2k and 2k+1.  With at most 352 weighted tokens there are at
+ * most 351 rounds, so only these slots ever hold or receive a weighted node:
+ *   [0, 768)              low leaves and the settle targets 2k, 2k+1 <= 703
+ *   [16384, 16512)        run tokens                                  -> compact 768 + (s - 16384)
+ *   [n, n + 384)          merged nodes                                -> compact 896 + (s - n)
+ * The map is monotonic, so "ascending slot order" (the reference's visiting order, which decides
+ * ties between merged nodes) is ascending compact order.
+ * ======================================================================================== */
+constexpr int kRunLo = 768, kMergedLo = 896, kSlots = 1280;
+constexpr int kMaxDepth = 15;
+
+__device__ __forceinline__ int lf_compact(int slot, int n) {
+    return slot >= n ? kMergedLo + (slot - n) : slot >= HYDK_LF_RUN_BASE ? kRunLo + (slot - HYDK_LF_RUN_BASE) : slot;
+}
+
+/* A candidate ("entry") is a tree root still waiting to be merged.  Entries live in registers, 6 per
+ * lane (384 = the number of leaves; every merge retires two candidates and creates one, which
+ * takes over a retired entry).
+ *   meta: bits 0-10 slot (compact), 11-20 "who" (the node's identity: compact token for a leaf,
+ *         384 + k for the node merged in round k), 21-25 subtree height
+ *   key:  weight << 12 | order, where order = token for a leaf and 0x800 | (2047 - slot) for a merged
+ *         node: ascending key is exactly the reference's selection order (entropy.c:577-581: weight,
+ *         then leaves before merged nodes, leaves by token, merged nodes by descending slot).
+ *         0xFFFFFFFF marks a retired entry.  Weights stay below 2^20 (<= 2 symbols per LF value). */
+constexpr int kEntries = HYDK_LF_CODES / 64;
+constexpr uint32_t kDead = 0xFFFFFFFFu;
+#define M_SLOT(m) ((m) & 2047u)
+#define M_WHO(m) (((m) >> 11) & 1023u)
+#define M_DEEP(m) (((m) >> 21) & 31u)
+#define M_MAKE(slot, who, deep) ((uint32_t)(slot) | ((uint32_t)(who) << 11) | ((uint32_t)(deep) << 21))
+
+__device__ __forceinline__ uint32_t lf_key(uint32_t weight, uint32_t who, uint32_t slot) {
+    return (weight << 12) | (who >= (uint32_t)HYDK_LF_CODES ? 0x800u | (2047u - slot) : who);
+}
+
+#define LF_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, rmask, 0xF, false))
+
+/* minimum over the wavefront, returned to every lane: row_shr 1/2/4/8, row_bcast 15/31, read lane 63 */
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    uint32_t t;
+    t = LF_DPP(v, 0x111, 0xF);
+    v = t < v ? t : v;
+    t = LF_DPP(v, 0x112, 0xF);
+    v = t < v ? t : v;
+    t = LF_DPP(v, 0x114, 0xF);
+    v = t < v ? t : v;
+    t = LF_DPP(v, 0x118, 0xF);
+    v = t < v ? t : v;
+    t = LF_DPP(v, 0x142, 0xA);
+    v = t < v ? t : v;
+    t = LF_DPP(v, 0x143, 0xC);
+    v = t < v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+/* the value `v` of the one lane where `has` is set (0 when there is none) */
+__device__ __forceinline__ uint32_t pick_lane(bool has, uint32_t v, bool &any) {
+    const unsigned long long m = __ballot(has);
+    any = m != 0;
+    return any ? (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_ctzll(m)) : 0u;
+}
+
+__device__ __forceinline__ int clog2_i(int v) { return v <= 1 ? 0 : 32 - __clz(v - 1); }
+
+struct LfHuffScratch {
+    uint16_t par[2 * HYDK_LF_CODES];   /* round in which the node (leaf, then merged) was settled as a child */
+    uint16_t depth[2 * HYDK_LF_CODES]; /* merged nodes above it */
+    uint32_t cnt[16], first[16];
+    uint32_t err;
+};
+
+/* run by ONE wavefront (lane = 0..63); hist / codes may live in LDS or in global memory */
+__device__ __forceinline__ void lf_huffman_wave(const uint32_t *hist, uint32_t *codes, HydkLfStream *st, LfHuffScratch &S,
+                                                int lane) {
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
+    uint16_t *s_par = S.par, *s_depth = S.depth;
+    uint32_t *s_cnt = S.cnt, *s_first = S.first;
+    uint32_t &s_err = S.err;
+
+    if (lane < 16)
+        s_cnt[lane] = 0;
+    if (lane == 0)
+        s_err = 0;
+
+    uint32_t ek[kEntries], em[kEntries], f6[kEntries];
+    int maxidx = -1, live0 = 0;
+    uint32_t pairs = 0, total = 0;
+#pragma unroll
+    for (int t = 0; t < kEntries; t++) {
+        const int ci = t * 64 + lane;
+        const uint32_t f = hist[ci];
+        const uint32_t sl = ci < 256 ? ci : kRunLo + (ci - 256);
+        f6[t] = f;
+        em[t] = M_MAKE(sl, ci, 0);
+        ek[t] = f ? lf_key(f, ci, sl) : kDead;
+        if (f)
+            maxidx = ci;
+        live0 += (int)__popcll(__ballot(f != 0));
+        total += f;
+        if (ci >= 256)
+            pairs += f;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int t = __shfl_xor(maxidx, d);
+        maxidx = t > maxidx ? t : maxidx;
+        pairs += __shfl_xor(pairs, d);
+        const uint32_t hi = __shfl_xor(total, d);
+        total = total + hi < total ? 0xFFFFFFFFu : total + hi; /* saturating */
+    }
+    const int n = maxidx < 0 ? 0 : (maxidx < 256 ? maxidx : HYDK_LF_RUN_BASE + maxidx - 256) + 1;
+
+    uint32_t err = live0 == 0 ? 1u : total >= (1u << 20) ? 6u : 0u;
+    int merges = 0;
+    for (int k = 0; k + 1 < n && !err; k++) {
+        const uint32_t limit = (uint32_t)(kMaxDepth - clog2_i(live0 - k) + 1);
+        const uint32_t c2k = (uint32_t)lf_compact(2 * k, n), c2k1 = (uint32_t)lf_compact(2 * k + 1, n);
+        /* the two smallest candidates; those whose subtree is too tall for the depth limit sit the round out */
+        uint32_t b1 = kDead, b2 = kDead, m1 = 0, m2 = 0;
+#pragma unroll
+        for (int t = 0; t < kEntries; t++) {
+            const uint32_t key = M_DEEP(em[t]) < limit ? ek[t] : kDead;
+            const bool lt1 = key < b1, lt2 = key < b2;
+            b2 = lt1 ? b1 : lt2 ? key : b2;
+            m2 = lt1 ? m1 : lt2 ? em[t] : m2;
+            b1 = lt1 ? key : b1;
+            m1 = lt1 ? em[t] : m1;
+        }
+        const uint32_t first = wave_min_u32(b1);
+        if (first == kDead) {
+            err = 2;
+            break;
+        }
+        bool any;
+        const uint32_t fm = pick_lane(b1 == first, m1, any);
+        const uint32_t c = b1 == first ? b2 : b1, cm = b1 == first ? m2 : m1;
+        const uint32_t second = wave_min_u32(c);
+        const uint32_t sm = pick_lane(second != kDead && c == second, cm, any);
+        const uint32_t f1 = M_SLOT(fm);
+
+        /* "swap the pick with slot 2k": the pick settles there; whatever weighted node sat in slot 2k
+         * moves to the pick's old slot */
+        uint32_t ak = kDead, am = 0;
+#pragma unroll
+        for (int t = 0; t < kEntries; t++) {
+            const bool hit = ek[t] != kDead && M_SLOT(em[t]) == c2k;
+            ak = hit ? ek[t] : ak;
+            am = hit ? em[t] : am;
+        }
+        bool has_a;
+        const uint32_t a_k = pick_lane(ak != kDead, ak, has_a), a_m = pick_lane(ak != kDead, am, any);
+#pragma unroll
+        for (int t = 0; t < kEntries; t++) {
+            const uint32_t sl = M_SLOT(em[t]);
+            const bool alive = ek[t] != kDead;
+            const bool at2k = alive && sl == c2k, atf1 = alive && sl == f1 && sl != c2k;
+            const uint32_t moved_m = sl | (a_m & ~2047u);
+            ek[t] = at2k ? kDead : atf1 ? (has_a ? lf_key(a_k >> 12, M_WHO(a_m), sl) : kDead) : ek[t];
+            em[t] = atf1 && has_a ? moved_m : em[t];
+        }
+        if (second == kDead)
+            break; /* a single tree is left */
+        uint32_t f2 = M_SLOT(sm);
+        if (f2 == c2k)
+            f2 = f1; /* it was just moved out of slot 2k */
+        uint32_t bk = kDead, bm = 0;
+#pragma unroll
+        for (int t = 0; t < kEntries; t++) {
+            const bool hit = ek[t] != kDead && M_SLOT(em[t]) == c2k1;
+            bk = hit ? ek[t] : bk;
+            bm = hit ? em[t] : bm;
+        }
+        bool has_b;
+        const uint32_t b_k = pick_lane(bk != kDead, bk, has_b), b_m = pick_lane(bk != kDead, bm, any);
+        /* same for slot 2k+1; the entry this retires is reused for the merged node, which enters as
+         * the highest slot so far */
+        const uint32_t hf = M_DEEP(fm), hs = M_DEEP(sm);
+        const uint32_t pslot = (uint32_t)(kMergedLo + k), pwho = (uint32_t)(HYDK_LF_CODES + k);
+        const uint32_t parent_m = M_MAKE(pslot, pwho, 1u + (hf > hs ? hf : hs));
+        const uint32_t parent_k = lf_key((first >> 12) + (second >> 12), pwho, pslot);
+#pragma unroll
+        for (int t = 0; t < kEntries; t++) {
+            const uint32_t sl = M_SLOT(em[t]);
+            const bool alive = ek[t] != kDead;
+            const bool at2k1 = alive && sl == c2k1, atf2 = alive && sl == f2 && sl != c2k1;
+            const bool takes_b = atf2 && has_b, becomes_parent = at2k1 || (atf2 && !has_b);
+            ek[t] = becomes_parent ? parent_k : takes_b ? lf_key(b_k >> 12, M_WHO(b_m), sl) : ek[t];
+            em[t] = becomes_parent ? parent_m : takes_b ? (sl | (b_m & ~2047u)) : em[t];
+        }
+        if (lane == 0) {
+            s_par[M_WHO(fm)] = (uint16_t)k;
+            s_par[M_WHO(sm)] = (uint16_t)k;
+        }
+        merges = k + 1;
+    }
+    if (!err && live0 - merges != 1)
+        err = 3; /* the depth limit left more than one tree */
+    wave_sync();
+
+    /* code length of a leaf = merged nodes above it; the node merged last is the root */
+    if (lane == 0 && merges > 0) {
+        s_depth[HYDK_LF_CODES + merges - 1] = 0;
+        for (int m = merges - 2; m >= 0; m--)
+            s_depth[HYDK_LF_CODES + m] = (uint16_t)(s_depth[HYDK_LF_CODES + s_par[HYDK_LF_CODES + m]] + 1);
+    }
+    wave_sync();
+    uint32_t len6[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const int ci = j * 64 + lane;
+        uint32_t len = 0;
+        if (f6[j] && merges > 0 && !err)
+            len = (uint32_t)s_depth[HYDK_LF_CODES + s_par[ci]] + 1u;
+        if (len > (uint32_t)kMaxDepth) {
+            err = 4;
+            len = 0;
+        }
+        len6[j] = len;
+        if (len)
+            atomicAdd(&s_cnt[len], 1u);
+    }
+    wave_sync();
+    /* canonical codes: shorter first, ties by token (entropy.c:664-707) */
+    if (lane == 0) {
+        unsigned long long next = 0;
+        for (int L = 1; L <= kMaxDepth; L++) {
+            s_first[L] = (uint32_t)(next >> (32 - L));
+            next += (unsigned long long)s_cnt[L] << (32 - L);
+        }
+        if (next && next != (1ull << 32))
+            atomicOr(&s_err, 5u);
+    }
+    if (err)
+        atomicOr(&s_err, err);
+    wave_sync();
+    uint32_t run[kMaxDepth + 1];
+#pragma unroll
+    for (int L = 1; L <= kMaxDepth; L++)
+        run[L] = s_first[L];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const int ci = j * 64 + lane;
+        uint32_t code = 0;
+#pragma unroll
+        for (int L = 1; L <= kMaxDepth; L++) {
+            const unsigned long long m = __ballot(len6[j] == (uint32_t)L);
+            if (len6[j] == (uint32_t)L)
+                code = run[L] + (uint32_t)__popcll(m & ltmask);
+            run[L] += (uint32_t)__popcll(m);
+        }
+        const uint32_t len = len6[j];
+        codes[ci] = len ? (len << 16) | (__brev(code) >> (32u - len)) : 0u;
+        st->lengths[ci] = (uint8_t)len;
+    }
+    if (lane == 0) {
+        st->alphabet = (uint32_t)n;
+        st->run_pairs = pairs;
+        st->error = s_err;
+    }
+}
+
+/* ==========================================================================================
+ * phase 3 (all 1024 threads): per-value bit strings -> prefix sum -> LDS window -> coalesced flush.
+ * Two barriers per pass: two bit windows alternate (one is flushed and the other cleared while the
+ * next pass's records are already on their way).
+ * ======================================================================================== */
+constexpr int kPackWords = (31 + kScanSpan * 59) / 32 + 2;
+
+__device__ __forceinline__ void lf_fetch_recs(const LfShape &sh, const unsigned long long *__restrict__ recs, int i0,
+                                              unsigned long long (&r)[4]) {
+    if (i0 < sh.n) { /* records are stored in padded groups of four */
+        const ulonglong2 a = ((const ulonglong2 *)(recs + i0))[0], b = ((const ulonglong2 *)(recs + i0))[1];
+        r[0] = a.x;
+        r[1] = a.y;
+        r[2] = b.x;
+        r[3] = b.y;
+    } else {
+        r[0] = r[1] = r[2] = r[3] = 0;
+    }
+}
+
+__device__ __forceinline__ uint32_t lf_pack_phase(const LfShape &sh, const unsigned long long *__restrict__ recs,
+                                                  const uint32_t *s_code, uint32_t *s_bits2 /* [2][kPackWords] */,
+                                                  uint32_t (*s_wsum)[kLfThreads / 64], uint32_t *__restrict__ out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t gbits = 0; /* bits written so far (uniform) */
+    for (int w = tid; w < 2 * kPackWords; w += kLfThreads)
+        s_bits2[w] = 0;
+    unsigned long long next[4];
+    lf_fetch_recs(sh, recs, tid * 4, next);
+    int buf = 0;
+    for (int tb = 0; tb < sh.n; tb += kScanSpan, buf ^= 1) {
+        unsigned long long rec[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            rec[j] = next[j];
+        lf_fetch_recs(sh, recs, tb + kScanSpan + tid * 4, next);
+        uint32_t *s_bits = s_bits2 + buf * kPackWords, *s_other = s_bits2 + (buf ^ 1) * kPackWords;
+
+        unsigned long long val[4];
+        uint32_t len[4], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = tb + tid * 4 + j;
+            val[j] = 0;
+            len[j] = 0;
+            if (i < sh.n) {
+                const uint32_t v = (uint32_t)rec[j], lit = (uint32_t)(rec[j] >> 32) & 1u, r = (uint32_t)(rec[j] >> 33) & 127u;
+                if (lit) {
+                    uint32_t token, nb, res;
+                    lf_hybrid(v, token, nb, res);
+                    const uint32_t e = s_code[token];
+                    val[j] = (e & 0xFFFFu) | ((unsigned long long)res << (e >> 16));
+                    len[j] = (e >> 16) + nb;
+                }
+                if (r) {
+                    const uint32_t e = s_code[256u + r - 3u];
+                    val[j] |= (unsigned long long)(e & 0xFFFFu) << len[j];
+                    len[j] += e >> 16;
+                }
+            }
+            mine += len[j];
+        }
+        const uint32_t inc = wave_incl_sum(mine);
+        if (lane == 63)
+            s_wsum[buf][wave] = inc;
+        __syncthreads(); /* also: the other pass's flush and this window's clearing are complete */
+        uint32_t pos = (gbits & 31u) + inc - mine, total = 0;
+        for (int w = 0; w < kLfThreads / 64; w++) {
+            const uint32_t t = s_wsum[buf][w];
+            if (w < wave)
+                pos += t;
+            total += t;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!len[j])
+                continue;
+            const uint32_t w = pos >> 5, shl = pos & 31u;
+            const unsigned long long lo = val[j] << shl;
+            const uint32_t hi = shl ? (uint32_t)(val[j] >> (64u - shl)) : 0u;
+            if ((uint32_t)lo)
+                atomicOr(&s_bits[w], (uint32_t)lo);
+            if ((uint32_t)(lo >> 32))
+                atomicOr(&s_bits[w + 1], (uint32_t)(lo >> 32));
+            if (hi)
+                atomicOr(&s_bits[w + 2], hi);
+            pos += len[j];
+        }
+        __syncthreads();
+        /* whole words go out; the partly filled last word opens the other window, which is cleared otherwise */
+        const uint32_t end = (gbits & 31u) + total, full = end >> 5;
+        uint32_t *dst = out + (gbits >> 5);
+        const uint32_t carry = s_bits[full];
+        for (uint32_t w = tid; w < full; w += kLfThreads)
+            dst[w] = s_bits[w];
+        for (int w = tid; w < kPackWords; w += kLfThreads)
+            s_other[w] = w ? 0u : carry;
+        gbits += total;
+        if (tb + kScanSpan >= sh.n && tid == 0 && (gbits & 31u))
+            out[gbits >> 5] = carry;
+    }
+    return gbits;
+}
+
+/* ==========================================================================================
+ * The two kernels, grid = LF groups, block = 1024.
+ *
+ * Why two and not one or three: the workgroup dispatcher does not start placing a kernel's
+ * workgroups while an earlier-started kernel (the HF entropy stage with its thousands of workgroups)
+ * still has workgroups waiting to be placed.  k_lf_tokens is enqueued right behind the transform
+ * kernel and gets its CUs before the entropy stage starts; k_lf_code then lands in the entropy
+ * stage's tail, where CUs are idle anyway.  A single fused kernel would sit on 16 CUs for its whole
+ * life (measured: the entropy stage 14 % slower); three kernels leave the one-wave code construction
+ * waiting in the queue for most of the entropy stage (measured: 1.8 ms instead of 0.18 ms).
+ * ======================================================================================== */
+__global__ __launch_bounds__(kLfThreads) void k_lf_tokens(const HydkLfJob *__restrict__ jobs,
+                                                          unsigned long long *__restrict__ recs_all,
+                                                          uint32_t *__restrict__ hist_all) {
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const HydkLfJob &job = jobs[slot];
+    const LfShape sh = lf_shape(job);
+    __shared__ __attribute__((aligned(16))) int s_rs[2 * kScanSpan];
+    __shared__ uint32_t s_hist[HYDK_LF_CODES];
+    __shared__ LfTokenScratch s_tok;
+    lf_tokens_phase(job, sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, s_rs, s_hist, s_tok);
+    for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads)
+        hist_all[(size_t)slot * HYDK_LF_CODES + i] = s_hist[i];
+}
+
+__global__ __launch_bounds__(kLfThreads) void k_lf_code(const HydkLfJob *__restrict__ jobs,
+                                                        const unsigned long long *__restrict__ recs_all,
+                                                        const uint32_t *__restrict__ hist_all, HydkLfStream *__restrict__ streams,
+                                                        uint32_t *__restrict__ bits_all) {
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const LfShape sh = lf_shape(jobs[slot]);
+    __shared__ uint32_t s_bits[2 * kPackWords];
+    __shared__ uint32_t s_code[HYDK_LF_CODES];
+    __shared__ uint32_t s_wsum[2][kLfThreads / 64];
+    __shared__ LfHuffScratch s_huff;
+    if (tid < 64)
+        lf_huffman_wave(hist_all + (size_t)slot * HYDK_LF_CODES, s_code, streams + slot, s_huff, tid);
+    __syncthreads();
+    const uint32_t nbits = lf_pack_phase(sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, s_code, s_bits, s_wsum,
+                                         bits_all + (size_t)slot * HYDK_LF_BITWORDS);
+    if (tid == 0)
+        streams[slot].bit_count = nbits;
+}
+
+/* unit-test entry: the code construction alone, on a histogram in global memory */
+__global__ __launch_bounds__(64) void k_lf_huffman(const uint32_t *__restrict__ hist, HydkLfStream *__restrict__ stream_out,
+                                                   uint32_t *__restrict__ codes) {
+    __shared__ LfHuffScratch s_huff;
+    lf_huffman_wave(hist, codes, stream_out, s_huff, (int)threadIdx.x);
+}
+
+} // namespace
+
+namespace hydk {
+
+hipError_t launch_lf_coder(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, HydkLfStream *streams,
+                           uint32_t *bits, int num_slots, hipStream_t stream) {
+    hipLaunchKernelGGL(k_lf_tokens, dim3(num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist);
+    hipLaunchKernelGGL(k_lf_code, dim3(num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist, streams, bits);
+    return hipGetLastError();
+}
+
+/* debug / unit-test entry: code lengths and codes for one caller-supplied histogram (device pointers) */
+hipError_t launch_lf_huffman_only(const uint32_t *hist, HydkLfStream *stream_out, uint32_t *codes, hipStream_t stream) {
+    hipLaunchKernelGGL(k_lf_huffman, dim3(1), dim3(64), 0, stream, hist, stream_out, codes);
+    return hipGetLastError();
+}
+
+} // namespace hydk

@@ -82,6 +82,11 @@ void hb_append_bits(HydBits *b, const uint8_t *src, uint64_t nbits) {
         src += whole;
         nbits &= 7;
     }
+    while (nbits >= 32) { /* unaligned splice, four bytes at a time */
+        hb_put(b, (uint64_t)src[0] | ((uint64_t)src[1] << 8) | ((uint64_t)src[2] << 16) | ((uint64_t)src[3] << 24), 32);
+        src += 4;
+        nbits -= 32;
+    }
     while (nbits >= 8) {
         hb_put(b, *src++, 8);
         nbits -= 8;

@@ -39,11 +39,15 @@
 
 #include "bitio.h"
 #include "frame.h"
+#include "prefix.h"
 #include "hydrium_amd.h"
 #include "libhydrium/libhydrium.h"
 
 typedef struct LfgResult {
-    int32_t *dc; /* [3][vbh][vbw] */
+    int32_t *dc; /* [3][vbh][vbw]; NULL when the LF coefficients were coded on the device */
+    uint8_t *lf_bits;                    /* device-coded LF-coefficient symbols (malloc'ed) or NULL */
+    uint8_t lf_lengths[HYD_LF_CODES];
+    uint32_t lf_alphabet, lf_run_pairs, lf_bit_count;
     uint32_t freq[HYD_FRAME_MAX_CLUSTERS][HYD_FRAME_ALPHABET];
     uint32_t alphabet[HYD_FRAME_MAX_CLUSTERS];
     uint32_t bits[HYDAMD_GROUPS_PER_LFG];
@@ -113,13 +117,21 @@ typedef struct LfWork {
     size_t first, stride;
 } LfWork;
 
+static int write_one_lf_group(HydBits *out, const LfgResult *r, size_t vbw, size_t vbh, const char **err) {
+    if (r->lf_bits) {
+        const HydLfCoded lf = {r->lf_lengths, r->lf_alphabet, r->lf_run_pairs, r->lf_bits, r->lf_bit_count};
+        return hyd_write_lf_group_coded(out, vbw, vbh, &lf, err);
+    }
+    return hyd_write_lf_group(out, r->dc, vbw, vbh, err);
+}
+
 static void *lf_worker(void *arg) {
     const LfWork *w = arg;
     for (size_t s = w->first; s < w->shape->lfg_count; s += w->stride) {
         const size_t vbw = (w->shape->lfg[s].width + 7) >> 3, vbh = (w->shape->lfg[s].height + 7) >> 3;
         hb_init(&w->out[s]);
         w->err[s] = NULL;
-        w->status[s] = hyd_write_lf_group(&w->out[s], w->res[s].dc, vbw, vbh, &w->err[s]);
+        w->status[s] = write_one_lf_group(&w->out[s], &w->res[s], vbw, vbh, &w->err[s]);
         hb_align(&w->out[s]);
     }
     return NULL;
@@ -212,7 +224,7 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
     } else {
         for (size_t s = 0; s < shape->lfg_count; s++) {
             const size_t vbw = (shape->lfg[s].width + 7) >> 3, vbh = (shape->lfg[s].height + 7) >> 3;
-            ret = hyd_write_lf_group(&body, res[s].dc, vbw, vbh, &e->error);
+            ret = write_one_lf_group(&body, &res[s], vbw, vbh, &e->error);
             if (ret)
                 goto done;
             CLOSE_SECTION();
@@ -434,12 +446,26 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
     for (size_t s = 0; s < n && !ret; s++) {
         const size_t vbw = (shape->lfg[s].width + 7) >> 3, vbh = (shape->lfg[s].height + 7) >> 3;
         uint32_t log_alpha = 0, running = 0;
-        res[s].dc = malloc(3 * vbw * vbh * sizeof(int32_t));
-        if (!res[s].dc) {
-            ret = HYD_NOMEM;
-            break;
+        if (hydamd_lf_coder(e->dev)) { /* the LF coefficients were coded on the GPU */
+            ret = hydamd_read_lf_stream(e->dev, (int)s, res[s].lf_lengths, &res[s].lf_alphabet, &res[s].lf_run_pairs,
+                                        &res[s].lf_bit_count);
+            if (ret)
+                break;
+            const size_t nbytes = ((size_t)res[s].lf_bit_count + 7) >> 3;
+            res[s].lf_bits = malloc(nbytes ? nbytes : 1);
+            if (!res[s].lf_bits) {
+                ret = HYD_NOMEM;
+                break;
+            }
+            ret = hydamd_read_lf_bits(e->dev, (int)s, res[s].lf_bits, nbytes);
+        } else {
+            res[s].dc = malloc(3 * vbw * vbh * sizeof(int32_t));
+            if (!res[s].dc) {
+                ret = HYD_NOMEM;
+                break;
+            }
+            ret = hydamd_read_dc(e->dev, (int)s, res[s].dc, vbw, vbh);
         }
-        ret = hydamd_read_dc(e->dev, (int)s, res[s].dc, vbw, vbh);
         if (!ret)
             ret = hydamd_read_tables(e->dev, (int)s, res[s].freq, res[s].alphabet, &log_alpha, &running);
         if (!ret)
@@ -456,8 +482,10 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
     ret = assemble_frame(e, shape, res, max_alphabet, payload, payload_len);
     TRACE("assemble frame (host)", t0);
 done:
-    for (size_t s = 0; s < n; s++)
+    for (size_t s = 0; s < n; s++) {
         free(res[s].dc);
+        free(res[s].lf_bits);
+    }
     free(res);
     free(payload);
     return ret;
@@ -717,4 +745,44 @@ HYDT_EXPORT int hydt_frame_from_stages(const HYDImageMetadata *md, int write_hea
                                      max_alphabet, payload, payload_len, icc, icc_size, out, out_len, err);
 }
 HYDT_EXPORT void hydt_free(void *p) { free(p); }
+
+/* depth-limited code lengths of the host prefix coder (prefix.c), for comparison with the device's */
+HYDT_EXPORT int hydt_code_lengths(const uint32_t *freq, uint32_t *lengths, uint32_t n, int max_depth) {
+    return hps_code_lengths(freq, lengths, n, max_depth);
+}
+
+static int hydt_take(HydBits *b, int ret, uint8_t **out, size_t *out_len) {
+    hb_align(b);
+    if (!ret && b->failed)
+        ret = HYD_NOMEM;
+    if (!ret) {
+        *out = malloc(b->len ? b->len : 1);
+        if (*out) {
+            memcpy(*out, b->data, b->len);
+            *out_len = b->len;
+        } else {
+            ret = HYD_NOMEM;
+        }
+    }
+    hb_free(b);
+    return ret;
+}
+
+/* one byte-padded LFGroup section from LF ints (host coder) ... */
+HYDT_EXPORT int hydt_lf_group(const int32_t *dc, size_t vbw, size_t vbh, uint8_t **out, size_t *out_len) {
+    HydBits b;
+    const char *err = NULL;
+    hb_init(&b);
+    return hydt_take(&b, hyd_write_lf_group(&b, dc, vbw, vbh, &err), out, out_len);
+}
+
+/* ... and from an LF-coefficient stream coded elsewhere (the GPU, or the tests' model of it) */
+HYDT_EXPORT int hydt_lf_group_coded(size_t vbw, size_t vbh, const uint8_t *lengths, uint32_t alphabet, uint32_t run_pairs,
+                                    const uint8_t *bits, uint64_t bit_count, uint8_t **out, size_t *out_len) {
+    HydBits b;
+    const char *err = NULL;
+    const HydLfCoded lf = {lengths, alphabet, run_pairs, bits, bit_count};
+    hb_init(&b);
+    return hydt_take(&b, hyd_write_lf_group_coded(&b, vbw, vbh, &lf, &err), out, out_len);
+}
 #endif /* HYD_TEST_HOOKS */

@@ -268,19 +268,36 @@ void hyd_write_lf_global(HydBits *out) {
     hb_bool(out, 0);                         /* no global modular tree */
 }
 
-int hyd_write_lf_group(HydBits *out, const int32_t *dc, size_t vbw, size_t vbh, const char **err) {
+/* LF group, part 1: modular header and the MA tree, a single leaf with the clamped-gradient
+ * predictor (encoder.c:539-558) */
+static int lf_group_prologue(HydBits *out, const char **err) {
     static const uint32_t ma_tree[5][2] = {{1, 0}, {2, 5}, {3, 0}, {4, 0}, {5, 0}}; /* encoder.c:114-116 */
     HydSymStream s;
-    int ret;
     hb_put(out, 0, 2);   /* extra precision 0 */
     hb_bool(out, 0);     /* local tree */
     hb_bool(out, 1);     /* weighted-predictor params default */
     hb_put(out, 0, 2);   /* no transforms */
-
-    /* MA tree: a single leaf with the clamped-gradient predictor */
-    ret = hps_init(&s, kZeroMap, 6, 0, 0, 0);
+    int ret = hps_init(&s, kZeroMap, 6, 0, 0, 0);
     for (int i = 0; i < 5 && !ret; i++)
         ret = hps_send(&s, ma_tree[i][0], ma_tree[i][1]);
+    if (ret) {
+        hps_free(&s);
+        return ret;
+    }
+    return hps_finish_prefix(&s, out, err);
+}
+
+/* LF group, part 3: varblock count, then a modular sub-image that says "8x8 DCT, hf_mult 5" for
+ * every block and zero chroma-from-luma factors (encoder.c:598-626).  Depends on the LF group's
+ * geometry only. */
+static int lf_group_hf_metadata(HydBits *out, size_t vbw, size_t vbh, const char **err) {
+    HydSymStream s;
+    const size_t blocks = vbw * vbh;
+    hb_put(out, blocks - 1, clog2_u64(blocks));
+    hb_put(out, 0x2, 4);
+    int ret = hps_init(&s, kZeroMap, 6, 0, 0, 0);
+    for (uint32_t ctx = 1; ctx <= 5 && !ret; ctx++)
+        ret = hps_send(&s, ctx, 0);
     if (ret) {
         hps_free(&s);
         return ret;
@@ -288,11 +305,32 @@ int hyd_write_lf_group(HydBits *out, const int32_t *dc, size_t vbw, size_t vbh, 
     ret = hps_finish_prefix(&s, out, err);
     if (ret)
         return ret;
+    const size_t cfl = ((vbw + 7) >> 3) * ((vbh + 7) >> 3);
+    const size_t leading_zeros = 2 * cfl + blocks;
+    ret = hps_init(&s, kZeroMap, 1, 0, 29, 1);
+    for (size_t i = 0; i < leading_zeros && !ret; i++)
+        ret = hps_send(&s, 0, 0);
+    for (size_t i = 0; i < blocks && !ret; i++)
+        ret = hps_send(&s, 0, (5 - 1) * 2); /* pack_signed(hf_mult - 1) */
+    for (size_t i = 0; i < blocks && !ret; i++)
+        ret = hps_send(&s, 0, 0);
+    if (ret) {
+        hps_free(&s);
+        return ret;
+    }
+    return hps_finish_prefix(&s, out, err);
+}
+
+int hyd_write_lf_group(HydBits *out, const int32_t *dc, size_t vbw, size_t vbh, const char **err) {
+    HydSymStream s;
+    int ret = lf_group_prologue(out, err);
+    if (ret)
+        return ret;
 
     /* LF coefficients, channel order Y, X, B (encoder.c:574-594); the ints themselves come from
      * the transform kernel */
     const size_t blocks = vbw * vbh;
-    ret = hps_init(&s, kZeroMap, 1, 1, 1u << 14, 1);
+    ret = hps_init(&s, kZeroMap, 1, 1, HYD_LF_RUN_BASE, 1);
     if (ret)
         return ret;
     hps_set_config(&s, 0, 0, 7, 1, 1);
@@ -318,35 +356,42 @@ int hyd_write_lf_group(HydBits *out, const int32_t *dc, size_t vbw, size_t vbh, 
     ret = hps_finish_prefix(&s, out, err);
     if (ret)
         return ret;
-
-    /* HF metadata: varblock count, then a modular sub-image that says "8x8 DCT, hf_mult 5" for
-     * every block and zero chroma-from-luma factors (encoder.c:598-626) */
-    hb_put(out, blocks - 1, clog2_u64(blocks));
-    hb_put(out, 0x2, 4);
-    ret = hps_init(&s, kZeroMap, 6, 0, 0, 0);
-    for (uint32_t ctx = 1; ctx <= 5 && !ret; ctx++)
-        ret = hps_send(&s, ctx, 0);
-    if (ret) {
-        hps_free(&s);
-        return ret;
-    }
-    ret = hps_finish_prefix(&s, out, err);
+    ret = lf_group_hf_metadata(out, vbw, vbh, err);
     if (ret)
         return ret;
-    const size_t cfl = ((vbw + 7) >> 3) * ((vbh + 7) >> 3);
-    const size_t leading_zeros = 2 * cfl + blocks;
-    ret = hps_init(&s, kZeroMap, 1, 0, 29, 1);
-    for (size_t i = 0; i < leading_zeros && !ret; i++)
-        ret = hps_send(&s, 0, 0);
-    for (size_t i = 0; i < blocks && !ret; i++)
-        ret = hps_send(&s, 0, (5 - 1) * 2); /* pack_signed(hf_mult - 1) */
-    for (size_t i = 0; i < blocks && !ret; i++)
-        ret = hps_send(&s, 0, 0);
-    if (ret) {
-        hps_free(&s);
+    return out->failed ? ST_NOMEM : 0;
+}
+
+int hyd_write_lf_group_coded(HydBits *out, size_t vbw, size_t vbh, const HydLfCoded *lf, const char **err) {
+    int ret = lf_group_prologue(out, err);
+    if (ret)
         return ret;
+    /* the LF-coefficient stream: the same layout hyd_write_lf_group sets up (one value context plus
+     * the LZ77 distance context, both with config (7,1,1)); lengths and symbol bits come from the GPU */
+    if (lf->alphabet < 1 || lf->alphabet > HYD_LF_RUN_BASE + 128u || lf->bit_count > ((uint64_t)3 * vbw * vbh) * 64) {
+        if (err)
+            *err = "LF stream from the device is malformed";
+        return ST_INTERNAL;
     }
-    ret = hps_finish_prefix(&s, out, err);
+    static const uint8_t map[2] = {0, 1};
+    static const HydUintConfig config[2] = {{7, 1, 1}, {7, 1, 1}};
+    const uint16_t alphabet[2] = {(uint16_t)lf->alphabet, (uint16_t)(lf->run_pairs ? 2 : 0)};
+    uint32_t *lengths = calloc((size_t)alphabet[0] + alphabet[1], sizeof(uint32_t));
+    if (!lengths)
+        return ST_NOMEM;
+    for (uint32_t t = 0; t < lf->alphabet; t++) {
+        if (t < 256)
+            lengths[t] = lf->lengths[t];
+        else if (t >= HYD_LF_RUN_BASE)
+            lengths[t] = lf->lengths[256 + (t - HYD_LF_RUN_BASE)];
+    }
+    const HydPrefixLayout lay = {HYD_LF_RUN_BASE, 3, map, 2, 2, config, alphabet};
+    ret = hps_write_header(out, &lay, lengths, err);
+    free(lengths);
+    if (ret)
+        return ret;
+    hb_append_bits(out, lf->bits, lf->bit_count);
+    ret = lf_group_hf_metadata(out, vbw, vbh, err);
     if (ret)
         return ret;
     return out->failed ? ST_NOMEM : 0;

@@ -45,6 +45,20 @@ void hyd_write_lf_global(HydBits *out);                                         
 /* dc[c][by][bx] with row pitch vbw, channels X, Y, B (encoder.c:539-629) */
 int hyd_write_lf_group(HydBits *out, const int32_t *dc, size_t vbw, size_t vbh, const char **err);
 
+/* The same section when the LF-coefficient stream was coded on the GPU (csrc/hip/lf_coder.hip): the
+ * host writes the constant sub-streams and the code-length header around the device's symbol bits.
+ * lengths[] is indexed by compact token: [0,256) literal tokens, [256,384) token 16384 + (i - 256). */
+#define HYD_LF_RUN_BASE 16384u
+#define HYD_LF_CODES 384
+typedef struct HydLfCoded {
+    const uint8_t *lengths;   /* [HYD_LF_CODES] */
+    uint32_t alphabet;        /* largest token + 1 of the value cluster */
+    uint32_t run_pairs;       /* (run token, distance) pairs in the stream */
+    const uint8_t *bits;      /* symbol bits, LSB first */
+    uint64_t bit_count;
+} HydLfCoded;
+int hyd_write_lf_group_coded(HydBits *out, size_t vbw, size_t vbh, const HydLfCoded *lf, const char **err);
+
 /* HF context -> cluster map of a frame with num_presets presets (encoder.c:852-901); returns clusters per preset */
 int hyd_hf_cluster_map(uint8_t *map, unsigned num_presets);
 

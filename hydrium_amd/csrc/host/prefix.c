@@ -449,82 +449,56 @@ static void swap_pick(Pick *a, Pick *b) {
     *b = t;
 }
 
-int hps_finish_prefix(HydSymStream *s, HydBits *out, const char **err) {
+/* Everything of a prefix-coded stream that precedes its symbols: the fields shared with the ANS
+ * header (entropy.c:546-575, log_alphabet_size = 0), the alphabet sizes (entropy.c:835-844) and one
+ * code per cluster in the simple or the complex form (entropy.c:846-927).  `lengths` holds the code
+ * lengths of cluster c at offset sum(alphabet[0..c)). */
+int hps_write_header(HydBits *out, const HydPrefixLayout *lay, const uint32_t *lengths, const char **err) {
     int ret = 0;
-    uint32_t *freq = NULL, *lengths = NULL;
-    Code *codes = NULL;
-    size_t base[257];
-
-    /* ---- fields shared with the ANS header (entropy.c:546-575, log_alphabet_size = 0) ---- */
-    hb_bool(out, s->rle_min_symbol != 0);
-    if (s->rle_min_symbol) {
-        ret = flush_run(s);
-        if (ret)
-            goto done;
-        hb_u32(out, &kRleMinSymbol, s->rle_min_symbol);
-        hb_u32(out, &kRleMinLength, s->rle_min_length);
+    hb_bool(out, lay->rle_min_symbol != 0);
+    if (lay->rle_min_symbol) {
+        hb_u32(out, &kRleMinSymbol, lay->rle_min_symbol);
+        hb_u32(out, &kRleMinLength, lay->rle_min_length);
         hps_write_uint_config(out, &kRunLengthConfig, 8);
     }
-    ret = hps_write_cluster_map(s->cluster_map, s->num_dists, s->num_clusters, out, err);
+    ret = hps_write_cluster_map(lay->cluster_map, lay->num_dists, lay->num_clusters, out, err);
     if (ret)
         goto done;
     hb_bool(out, 1); /* prefix codes */
-    for (size_t c = 0; c < s->num_clusters; c++)
-        hps_write_uint_config(out, &s->config[c], 15);
+    for (size_t c = 0; c < lay->num_clusters; c++)
+        hps_write_uint_config(out, &lay->config[c], 15);
 
-    /* ---- histograms ---- */
-    base[0] = 0;
-    for (size_t c = 0; c < s->num_clusters; c++)
-        base[c + 1] = base[c] + s->alphabet[c];
-    const size_t total = base[s->num_clusters] ? base[s->num_clusters] : 1;
-    const size_t width = s->max_alphabet ? s->max_alphabet : 1;
-    freq = calloc(total, sizeof(uint32_t));
-    lengths = calloc(width, sizeof(uint32_t));
-    codes = calloc(total, sizeof(Code));
-    if (!freq || !lengths || !codes) {
-        ret = ST_NOMEM;
-        goto done;
-    }
-    for (size_t i = 0; i < s->count; i++)
-        freq[base[s->sym[i].cluster] + s->sym[i].token]++;
-
-    /* ---- alphabet sizes (entropy.c:835-844) ---- */
-    for (size_t c = 0; c < s->num_clusters; c++) {
-        if (s->alphabet[c] <= 1) {
+    for (size_t c = 0; c < lay->num_clusters; c++) {
+        if (lay->alphabet[c] <= 1) {
             hb_bool(out, 0);
             continue;
         }
         hb_bool(out, 1);
-        const int n = ilog2_u32(s->alphabet[c] - 1u);
+        const int n = ilog2_u32(lay->alphabet[c] - 1u);
         hb_put(out, (uint64_t)n, 4);
-        hb_put(out, s->alphabet[c] - 1u, n);
+        hb_put(out, lay->alphabet[c] - 1u, n);
     }
 
-    /* ---- one code per cluster (entropy.c:846-927) ---- */
-    for (size_t c = 0; c < s->num_clusters; c++) {
-        const uint32_t n = s->alphabet[c];
+    size_t base = 0;
+    for (size_t c = 0; c < lay->num_clusters; base += lay->alphabet[c], c++) {
+        const uint32_t n = lay->alphabet[c];
+        const uint32_t *len = lengths + base;
         if (n <= 1)
             continue;
-        memset(lengths, 0, width * sizeof(uint32_t));
-        ret = hps_code_lengths(freq + base[c], lengths, n, 15);
-        if (ret)
-            goto done;
         uint32_t used = 0;
         Pick pick[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
         for (uint32_t j = 0; j < n; j++) {
-            if (!lengths[j])
+            if (!len[j])
                 continue;
             if (used < 4) {
                 pick[used].symbol = j;
-                pick[used].len = lengths[j];
+                pick[used].len = len[j];
             }
             if (++used > 4)
                 break;
         }
         if (used > 4) {
-            ret = put_complex_lengths(out, n, lengths);
-            if (!ret)
-                ret = assign_codes(codes + base[c], lengths, n);
+            ret = put_complex_lengths(out, n, len);
             if (ret)
                 goto done;
             continue;
@@ -554,12 +528,58 @@ int hps_finish_prefix(HydSymStream *s, HydBits *out, const char **err) {
             hb_put(out, pick[i].symbol, symbol_bits);
         if (used == 4)
             hb_bool(out, skewed);
-        ret = assign_codes(codes + base[c], lengths, n);
+    }
+done:
+    if (ret && err && !*err)
+        *err = ret == ST_NOMEM ? "out of memory in prefix coder" : "prefix coder internal error";
+    return ret;
+}
+
+int hps_finish_prefix(HydSymStream *s, HydBits *out, const char **err) {
+    int ret = 0;
+    uint32_t *freq = NULL, *lengths = NULL;
+    Code *codes = NULL;
+    size_t base[257];
+
+    if (s->rle_min_symbol) {
+        ret = flush_run(s);
         if (ret)
             goto done;
     }
 
-    /* ---- the symbols (entropy.c:1003-1021) ---- */
+    /* ---- histograms and code lengths ---- */
+    base[0] = 0;
+    for (size_t c = 0; c < s->num_clusters; c++)
+        base[c + 1] = base[c] + s->alphabet[c];
+    const size_t total = base[s->num_clusters] ? base[s->num_clusters] : 1;
+    freq = calloc(total, sizeof(uint32_t));
+    lengths = calloc(total, sizeof(uint32_t));
+    codes = calloc(total, sizeof(Code));
+    if (!freq || !lengths || !codes) {
+        ret = ST_NOMEM;
+        goto done;
+    }
+    for (size_t i = 0; i < s->count; i++)
+        freq[base[s->sym[i].cluster] + s->sym[i].token]++;
+    for (size_t c = 0; c < s->num_clusters; c++) {
+        const uint32_t n = s->alphabet[c];
+        if (n <= 1)
+            continue;
+        ret = hps_code_lengths(freq + base[c], lengths + base[c], n, 15);
+        if (!ret)
+            ret = assign_codes(codes + base[c], lengths + base[c], n);
+        if (ret)
+            goto done;
+    }
+
+    /* ---- header, then the symbols (entropy.c:1003-1021) ---- */
+    {
+        const HydPrefixLayout lay = {s->rle_min_symbol, s->rle_min_length, s->cluster_map, s->num_dists,
+                                     s->num_clusters,   s->config,         s->alphabet};
+        ret = hps_write_header(out, &lay, lengths, err);
+        if (ret)
+            goto done;
+    }
     for (size_t i = 0; i < s->count; i++) {
         const HydSym *sym = &s->sym[i];
         const Code *code = &codes[base[sym->cluster] + sym->token];

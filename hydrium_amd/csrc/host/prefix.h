@@ -56,6 +56,18 @@ int hps_send(HydSymStream *s, size_t dist, uint32_t value);
 int hps_finish_prefix(HydSymStream *s, HydBits *out, const char **err);
 void hps_free(HydSymStream *s);
 
+/* The part of a prefix-coded stream in front of its symbols, for callers whose symbols were coded
+ * elsewhere (the GPU LF-group coder): lengths[] holds the code lengths of cluster c at offset
+ * sum(alphabet[0..c)). */
+typedef struct HydPrefixLayout {
+    uint32_t rle_min_symbol, rle_min_length;
+    const uint8_t *cluster_map;
+    size_t num_dists, num_clusters;
+    const HydUintConfig *config;
+    const uint16_t *alphabet;
+} HydPrefixLayout;
+int hps_write_header(HydBits *out, const HydPrefixLayout *lay, const uint32_t *lengths, const char **err);
+
 /* pieces shared with the ANS stream header written by frame.c */
 void hps_hybridize(uint32_t value, const HydUintConfig *cfg, HydSym *out);
 int hps_write_cluster_map(const uint8_t *map, size_t num_dists, size_t num_clusters, HydBits *out, const char **err);

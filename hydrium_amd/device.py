@@ -17,7 +17,8 @@ from . import api
 MAX_CLUSTERS = 9
 ALPHABET = 128
 GROUPS_PER_LFG = 64
-K_NAMES = ("transform_tokenize", "build_tables", "rans_encode", "pack_sections")
+K_NAMES = ("transform_tokenize", "build_tables", "rans_encode", "pack_sections", "lf_coder")
+LF_CODES = 384  # compact token space of the LF-coefficient stream (include/hydrium_amd.h HYDAMD_LF_CODES)
 
 FMT_OF_DTYPE = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.float32): 2}
 
@@ -83,6 +84,11 @@ def dll(path: Optional[str] = None):
         d.hydamd_read_symbol_counts.argtypes = [vp, i, vp]
         d.hydamd_read_tokens.argtypes = [vp, i, i, vp, sz]
         d.hydamd_read_debug_plane.argtypes = [vp, i, vp, sz, sz]
+        d.hydamd_set_lf_coder.argtypes = [vp, i]
+        d.hydamd_lf_coder.argtypes = [vp]
+        d.hydamd_read_lf_stream.argtypes = [vp, i, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        d.hydamd_read_lf_bits.argtypes = [vp, i, vp, sz]
+        d.hydamd_debug_lf_code.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         d.hydamd_profile.argtypes = [vp, i]
         d.hydamd_profile_read.argtypes = [vp, vp, vp]
         if path is not None:
@@ -273,10 +279,40 @@ class DeviceContext:
         self._ck(self.d.hydamd_profile(self.h, int(enable)))
 
     def profile_read(self):
-        ms = (C.c_double * 4)()
-        n = (C.c_uint64 * 4)()
+        ms = (C.c_double * len(K_NAMES))()
+        n = (C.c_uint64 * len(K_NAMES))()
         self._ck(self.d.hydamd_profile_read(self.h, ms, n))
-        return {K_NAMES[i]: (ms[i], n[i]) for i in range(4)}
+        return {K_NAMES[i]: (ms[i], n[i]) for i in range(len(K_NAMES))}
+
+    # ---- LF-group coder (csrc/hip/lf_coder.hip) ----
+    def set_lf_coder(self, on_device: bool):
+        self._ck(self.d.hydamd_set_lf_coder(self.h, int(on_device)))
+
+    def lf_coder(self) -> bool:
+        return bool(self.d.hydamd_lf_coder(self.h))
+
+    def read_lf_stream(self, slot: int):
+        """(lengths[384] u8, alphabet, run_pairs, bit_count) of the device-coded LF-coefficient stream."""
+        lengths = np.zeros(LF_CODES, np.uint8)
+        a, r, b = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._ck(self.d.hydamd_read_lf_stream(self.h, slot, lengths.ctypes.data, C.byref(a), C.byref(r), C.byref(b)))
+        return lengths, a.value, r.value, b.value
+
+    def read_lf_bits(self, slot: int, bit_count: int) -> np.ndarray:
+        out = np.zeros(max((bit_count + 7) // 8, 1), np.uint8)
+        self._ck(self.d.hydamd_read_lf_bits(self.h, slot, out.ctypes.data, (bit_count + 7) // 8))
+        return out[: (bit_count + 7) // 8]
+
+    def debug_lf_code(self, hist: np.ndarray):
+        """Device code construction for one histogram over the compact token space -> (lengths, codes, alphabet, error)."""
+        hist = np.ascontiguousarray(hist, np.uint32)
+        assert hist.shape == (LF_CODES,)
+        lengths = np.zeros(LF_CODES, np.uint8)
+        codes = np.zeros(LF_CODES, np.uint32)
+        a, e = C.c_uint32(0), C.c_uint32(0)
+        self._ck(self.d.hydamd_debug_lf_code(self.h, hist.ctypes.data, lengths.ctypes.data, codes.ctypes.data,
+                                             C.byref(a), C.byref(e)))
+        return lengths, codes, a.value, e.value
 
 
 def frame_from_results(md: "api.HYDImageMetadata", tiles, dcs, freqs, alphabets, group_bits, max_alphabet: int,

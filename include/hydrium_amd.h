@@ -18,6 +18,9 @@
  *                             hyd_ans_prepare_frequencies (entropy.c:943) and the per-group
  *                             hyd_ans_write_stream_symbols loop (encoder.c:940-950, entropy.c:1064)
  *   hydamd_finish_frame       the byte-padding + concatenation of encoder.c:973-981
+ *   (LF coder, on by default) the LF-coefficient stream of write_lf_group (encoder.c:560-596) with its
+ *                             LZ77-as-RLE symbol buffering (entropy.c:473-524), Huffman code construction
+ *                             (entropy.c:577-707) and symbol write-out (entropy.c:1003-1021)
  */
 #ifndef HYDRIUM_AMD_H_
 #define HYDRIUM_AMD_H_
@@ -44,8 +47,10 @@ extern "C" {
 
 typedef struct HydAmdContext HydAmdContext;
 
+#define HYDAMD_LF_CODES 384        /* compact token space of the LF-coefficient stream: [0,256) literals, [256,384) token 16384 + (i - 256) */
+
 /* Kernel classes timed by the optional profiler. */
-enum { HYDAMD_K_TRANSFORM = 0, HYDAMD_K_TABLES = 1, HYDAMD_K_RANS = 2, HYDAMD_K_PACK = 3, HYDAMD_K_COUNT = 4 };
+enum { HYDAMD_K_TRANSFORM = 0, HYDAMD_K_TABLES = 1, HYDAMD_K_RANS = 2, HYDAMD_K_PACK = 3, HYDAMD_K_LF = 4, HYDAMD_K_COUNT = 5 };
 
 /* Number of usable HIP devices (0 when there is none; never fails). */
 HYDAMD_EXPORT int hydamd_device_count(void);
@@ -123,6 +128,21 @@ HYDAMD_EXPORT int hydamd_read_tables(HydAmdContext *ctx, int slot, uint32_t freq
                                      uint32_t *running_max_alphabet);
 /* LF ints, dst[c][by][bx] with row pitch vbw, channel order X, Y, B */
 HYDAMD_EXPORT int hydamd_read_dc(HydAmdContext *ctx, int slot, int32_t *dst, size_t vbw, size_t vbh);
+
+/* ---- LF-group coder: the LF-coefficient sub-stream of every submitted LF group is coded on the
+ * GPU alongside the HF entropy stage (on by default; 0 leaves the LF ints to a host coder via
+ * hydamd_read_dc).  Results are valid after hydamd_sync(). ---- */
+HYDAMD_EXPORT int hydamd_set_lf_coder(HydAmdContext *ctx, int on_device);
+HYDAMD_EXPORT int hydamd_lf_coder(HydAmdContext *ctx);
+/* code length per compact token, largest token + 1, number of (run, distance) pairs, bits of symbol data */
+HYDAMD_EXPORT int hydamd_read_lf_stream(HydAmdContext *ctx, int slot, uint8_t lengths[HYDAMD_LF_CODES], uint32_t *alphabet,
+                                        uint32_t *run_pairs, uint32_t *bit_count);
+/* the symbol bits, LSB first; capacity >= (bit_count + 7) / 8 */
+HYDAMD_EXPORT int hydamd_read_lf_bits(HydAmdContext *ctx, int slot, uint8_t *dst, size_t capacity);
+/* unit-test entry: run the device's code construction on one histogram over the compact token space */
+HYDAMD_EXPORT int hydamd_debug_lf_code(HydAmdContext *ctx, const uint32_t hist[HYDAMD_LF_CODES],
+                                       uint8_t lengths[HYDAMD_LF_CODES], uint32_t codes[HYDAMD_LF_CODES],
+                                       uint32_t *alphabet, uint32_t *error);
 
 /* ---- parity / debug read-backs ---- */
 HYDAMD_EXPORT int hydamd_read_symbol_counts(HydAmdContext *ctx, int slot, uint32_t counts[HYDAMD_GROUPS_PER_LFG]);

@@ -3,7 +3,7 @@ os.environ["HYDAMD_TRACE"] = "1"
 sys.path.insert(0, ".")
 import numpy as np
 from hydrium_amd import api, synth
-w, h, d = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+w, h, d = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (8192, 8192, 16)
 img = synth.make_image("photo", w, h, d, device="cuda").cpu().numpy()
 img = np.ascontiguousarray(img.view(np.uint16) if d == 16 else img)
 lib = api.Library()

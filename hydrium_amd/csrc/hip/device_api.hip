@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "../../../include/hydrium_amd.h"
@@ -315,10 +316,11 @@ int ensure_staging(HydAmdContext *ctx, size_t tile_bytes) {
 
 /* interleave the caller's (possibly planar / strided / bottom-up) samples as packed RGB */
 template <typename T>
-void gather_packed(T *dst, const void *const src[3], ptrdiff_t row_stride, ptrdiff_t pixel_stride, size_t w, size_t h) {
+void gather_rows(T *dst, const void *const src[3], ptrdiff_t row_stride, ptrdiff_t pixel_stride, size_t w, size_t y0,
+                 size_t y1) {
     const T *r = (const T *)src[0], *g = (const T *)src[1], *b = (const T *)src[2];
     const bool interleaved = pixel_stride == 3 && g == r + 1 && b == r + 2;
-    for (size_t y = 0; y < h; y++) {
+    for (size_t y = y0; y < y1; y++) {
         T *d = dst + y * w * 3;
         const ptrdiff_t yo = (ptrdiff_t)y * row_stride;
         if (interleaved) {
@@ -332,6 +334,49 @@ void gather_packed(T *dst, const void *const src[3], ptrdiff_t row_stride, ptrdi
             }
         }
     }
+}
+
+/* A 2048 x 2048 RGB16 tile is 25 MB: one core copies it in about 1.2 ms, which made staging the
+ * largest part of hyd_send_tile.  A few threads share the rows (HYDAMD_STAGE_THREADS, default up to 8). */
+int stage_threads() {
+    static int n = 0;
+    if (!n) {
+        const char *env = getenv("HYDAMD_STAGE_THREADS");
+        n = env ? atoi(env) : 0;
+        if (n < 1) {
+            const unsigned hw = std::thread::hardware_concurrency();
+            n = hw > 8 ? 8 : hw > 0 ? (int)hw : 1;
+        }
+        if (n > 32)
+            n = 32;
+    }
+    return n;
+}
+
+template <typename T>
+void gather_packed(T *dst, const void *const src[3], ptrdiff_t row_stride, ptrdiff_t pixel_stride, size_t w, size_t h) {
+    size_t threads = (size_t)stage_threads();
+    if (threads > h / 64)
+        threads = h / 64 ? h / 64 : 1; /* at least 64 rows each */
+    if (threads <= 1) {
+        gather_rows(dst, src, row_stride, pixel_stride, w, 0, h);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (h + threads - 1) / threads;
+    for (size_t t = 1; t < threads; t++) {
+        const size_t y0 = t * per, y1 = y0 + per < h ? y0 + per : h;
+        if (y0 >= h)
+            break;
+        try {
+            pool.emplace_back(gather_rows<T>, dst, src, row_stride, pixel_stride, w, y0, y1);
+        } catch (...) { /* no thread to be had: this one copies the share itself */
+            gather_rows(dst, src, row_stride, pixel_stride, w, y0, y1);
+        }
+    }
+    gather_rows(dst, src, row_stride, pixel_stride, w, 0, per < h ? per : h);
+    for (std::thread &th : pool)
+        th.join();
 }
 
 } // namespace

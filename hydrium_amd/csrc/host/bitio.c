@@ -74,6 +74,15 @@ void hb_append_bytes(HydBits *b, const uint8_t *src, size_t n) {
     b->len += n;
 }
 
+uint8_t *hb_extend(HydBits *b, size_t n) {
+    hb_spill(b);
+    if (b->nacc || !hb_reserve(b, n ? n : 1))
+        return NULL;
+    uint8_t *p = b->data + b->len;
+    b->len += n;
+    return p;
+}
+
 void hb_append_bits(HydBits *b, const uint8_t *src, uint64_t nbits) {
     hb_spill(b);
     if (!b->nacc && nbits >= 8) {

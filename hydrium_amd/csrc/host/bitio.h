@@ -39,6 +39,9 @@ void hb_align(HydBits *b);
 static inline uint64_t hb_bit_count(const HydBits *b) { return (uint64_t)b->len * 8 + (uint64_t)b->nacc; }
 /* append `nbits` bits taken LSB-first from src (bit-granular splice, bitwriter.c:80-108) */
 void hb_append_bits(HydBits *b, const uint8_t *src, uint64_t nbits);
+/* grow a byte-aligned sink by n bytes the caller fills in; NULL if unaligned or out of memory
+ * (the pointer is valid until the next call on this sink) */
+uint8_t *hb_extend(HydBits *b, size_t n);
 /* append whole bytes; the sink must be byte-aligned */
 void hb_append_bytes(HydBits *b, const uint8_t *src, size_t n);
 

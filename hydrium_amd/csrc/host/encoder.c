@@ -77,6 +77,9 @@ struct HYDEncoder {
 
     HydFrameLfg *sent; /* [lfg_per_frame] in send order */
     HydAmdContext *dev;
+    size_t dev_slots;  /* shape the context was created for */
+    int dev_linear;
+    int dev_failed;    /* a device call failed: do not park this context for reuse */
 };
 
 #define FAIL(enc, code, msg) ((enc)->error = (msg), (code))
@@ -117,10 +120,57 @@ typedef struct LfWork {
     size_t first, stride;
 } LfWork;
 
+/* The HF-metadata sub-streams of an LF group depend on its geometry only (frame.c:
+ * hyd_write_lf_group_tail), cost ~200k symbol sends for a full LF group and compress to a few
+ * hundred bytes: keep them per (vbw, vbh) for the life of the process.  Entries are immutable once
+ * published, so readers only need the lock to find them. */
+typedef struct TailEntry {
+    size_t vbw, vbh;
+    HydBits bits;
+} TailEntry;
+static pthread_mutex_t g_tail_lock = PTHREAD_MUTEX_INITIALIZER;
+static TailEntry g_tails[32];
+static int g_ntails;
+
+static const HydBits *find_tail_locked(size_t vbw, size_t vbh) {
+    for (int i = 0; i < g_ntails; i++)
+        if (g_tails[i].vbw == vbw && g_tails[i].vbh == vbh)
+            return &g_tails[i].bits;
+    return NULL;
+}
+
+static const HydBits *lf_tail(size_t vbw, size_t vbh) {
+    pthread_mutex_lock(&g_tail_lock);
+    const HydBits *hit = find_tail_locked(vbw, vbh);
+    pthread_mutex_unlock(&g_tail_lock);
+    if (hit)
+        return hit;
+    HydBits fresh;
+    const char *err = NULL;
+    hb_init(&fresh);
+    if (hyd_write_lf_group_tail(&fresh, vbw, vbh, &err) || fresh.failed) {
+        hb_free(&fresh);
+        return NULL; /* the caller codes it inline and reports the error there */
+    }
+    pthread_mutex_lock(&g_tail_lock);
+    hit = find_tail_locked(vbw, vbh);
+    if (!hit && g_ntails < (int)(sizeof(g_tails) / sizeof(g_tails[0]))) {
+        g_tails[g_ntails].vbw = vbw;
+        g_tails[g_ntails].vbh = vbh;
+        g_tails[g_ntails].bits = fresh;
+        hit = &g_tails[g_ntails++].bits;
+        fresh.data = NULL;
+    }
+    pthread_mutex_unlock(&g_tail_lock);
+    if (fresh.data)
+        hb_free(&fresh);
+    return hit;
+}
+
 static int write_one_lf_group(HydBits *out, const LfgResult *r, size_t vbw, size_t vbh, const char **err) {
     if (r->lf_bits) {
         const HydLfCoded lf = {r->lf_lengths, r->lf_alphabet, r->lf_run_pairs, r->lf_bits, r->lf_bit_count};
-        return hyd_write_lf_group_coded(out, vbw, vbh, &lf, err);
+        return hyd_write_lf_group_coded(out, vbw, vbh, &lf, lf_tail(vbw, vbh), err);
     }
     return hyd_write_lf_group(out, r->dc, vbw, vbh, err);
 }
@@ -176,8 +226,13 @@ static int code_lf_groups_parallel(HYDEncoder *e, const HydFrameShape *shape, co
     return ret;
 }
 
+static int device_fail(HYDEncoder *e, int code);
+
+/* payload == NULL: the packed HF sections are still on the device (e->dev) and are copied straight
+ * into the output stream */
 static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgResult *res, unsigned max_alphabet,
                           const uint8_t *payload, size_t payload_len) {
+    uint8_t *fetched = NULL;
     const size_t fg = ((shape->frame_width + 255) >> 8) * ((shape->frame_height + 255) >> 8);
     const int multi = fg > 1;
     const size_t toc_n = hyd_toc_entries(shape);
@@ -202,6 +257,7 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
         }                                  \
     } while (0)
 
+    double t0 = now_ms();
     hyd_write_lf_global(&body);
     CLOSE_SECTION();
     if (multi && shape->lfg_count > 1) {
@@ -230,6 +286,8 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
             CLOSE_SECTION();
         }
     }
+    TRACE("  LF group sections", t0);
+    t0 = now_ms();
     /* tables are signalled per preset = raster LF-group id, whatever the send order was */
     for (size_t s = 0; s < shape->lfg_count; s++) {
         const size_t p = shape->lfg[s].raster_id;
@@ -241,9 +299,11 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
     if (ret)
         goto done;
     CLOSE_SECTION();
+    TRACE("  HFGlobal", t0);
+    t0 = now_ms();
     if (multi) {
-        /* the device payload already is: byte-padded sections, send order, raster inside an LF group */
-        hb_append_bytes(&body, payload, payload_len);
+        /* the device payload already is: byte-padded sections, send order, raster inside an LF group;
+         * it follows the body, so only its sizes are needed here */
         for (size_t s = 0; s < shape->lfg_count; s++) {
             const size_t ng = ((shape->lfg[s].width + 255) >> 8) * ((shape->lfg[s].height + 255) >> 8);
             for (size_t g = 0; g < ng; g++)
@@ -251,6 +311,19 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
         }
     } else {
         /* a single-group frame is one bit-contiguous section (encoder.c:837-850,968-981 guards) */
+        if (!payload && payload_len) {
+            fetched = malloc(payload_len);
+            if (!fetched) {
+                ret = FAIL(e, HYD_NOMEM, "out of memory");
+                goto done;
+            }
+            ret = hydamd_read_payload(e->dev, fetched, payload_len);
+            if (ret) {
+                ret = device_fail(e, ret);
+                goto done;
+            }
+            payload = fetched;
+        }
         hb_append_bits(&body, payload, res[0].bits[0]);
     }
     hb_align(&body);
@@ -269,9 +342,20 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
         goto done;
     }
     hb_append_bytes(&e->stream, body.data, body.len);
-    if (e->stream.failed)
+    if (multi && payload_len) {
+        if (payload) {
+            hb_append_bytes(&e->stream, payload, payload_len);
+        } else {
+            uint8_t *dst = hb_extend(&e->stream, payload_len);
+            if (dst && (ret = hydamd_read_payload(e->dev, dst, payload_len)) != 0)
+                ret = device_fail(e, ret);
+        }
+    }
+    if (!ret && e->stream.failed)
         ret = FAIL(e, HYD_NOMEM, "out of memory");
+    TRACE("  frame header, TOC, body + HF sections", t0);
 done:
+    free(fetched);
 #undef CLOSE_SECTION
     free(sizes);
     free(freq);
@@ -313,6 +397,59 @@ static void drain(HYDEncoder *e) {
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * device context reuse
+ *
+ * Creating a context allocates its worst-case buffers (245 MB per LF-group slot) and pinned
+ * staging, and destroying it gives them back: about 10 ms per image together, a third of what
+ * hyd_send_tile costs for an 8192 x 8192 frame.  One idle context is therefore parked when an
+ * encoder is destroyed and handed to the next encoder that needs the same shape.  Contexts that
+ * saw a device error, or that are larger than 64 slots (15.7 GB), are not parked;
+ * HYDAMD_CONTEXT_CACHE=0 turns the parking off.
+ * ------------------------------------------------------------------------------------------- */
+static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
+static HydAmdContext *g_ctx;
+static size_t g_ctx_slots;
+static int g_ctx_linear;
+
+static int ctx_cache_on(void) {
+    static int on = -1;
+    if (on < 0) {
+        const char *v = getenv("HYDAMD_CONTEXT_CACHE");
+        on = !(v && *v == '0');
+    }
+    return on;
+}
+
+static HydAmdContext *ctx_acquire(size_t slots, int linear, int *status) {
+    HydAmdContext *c = NULL;
+    pthread_mutex_lock(&g_ctx_lock);
+    if (g_ctx && g_ctx_slots == slots && g_ctx_linear == linear) {
+        c = g_ctx;
+        g_ctx = NULL;
+    }
+    pthread_mutex_unlock(&g_ctx_lock);
+    if (c) {
+        *status = HYD_OK;
+        return c;
+    }
+    return hydamd_create(0, (int)slots, linear, 0, status);
+}
+
+static void ctx_release(HydAmdContext *c, size_t slots, int linear, int healthy) {
+    if (healthy && ctx_cache_on() && slots <= 64 && hydamd_sync(c) == HYD_OK) {
+        pthread_mutex_lock(&g_ctx_lock);
+        HydAmdContext *old = g_ctx; /* keep the most recent shape */
+        g_ctx = c;
+        g_ctx_slots = slots;
+        g_ctx_linear = linear;
+        pthread_mutex_unlock(&g_ctx_lock);
+        c = old;
+    }
+    if (c)
+        hydamd_destroy(c);
+}
+
+/* ---------------------------------------------------------------------------------------------
  * public API
  * ------------------------------------------------------------------------------------------- */
 
@@ -326,8 +463,11 @@ HYDRIUM_EXPORT HYDEncoder *hyd_encoder_new(void) {
 HYDRIUM_EXPORT HYDStatusCode hyd_encoder_destroy(HYDEncoder *e) {
     if (!e)
         return HYD_OK;
-    if (e->dev)
-        hydamd_destroy(e->dev);
+    if (e->dev) {
+        const double t0 = now_ms();
+        ctx_release(e->dev, e->dev_slots, e->dev_linear, !e->dev_failed);
+        TRACE("release device context", t0);
+    }
     hb_free(&e->stream);
     free(e->icc);
     free(e->sent);
@@ -366,7 +506,7 @@ HYDRIUM_EXPORT HYDStatusCode hyd_set_metadata(HYDEncoder *e, const HYDImageMetad
     if (!e->sent)
         return FAIL(e, HYD_NOMEM, "out of memory");
     if (e->dev) { /* metadata changed: the device context is rebuilt lazily */
-        hydamd_destroy(e->dev);
+        ctx_release(e->dev, e->dev_slots, e->dev_linear, !e->dev_failed);
         e->dev = NULL;
     }
     e->have_metadata = 1;
@@ -406,6 +546,7 @@ HYDRIUM_EXPORT HYDStatusCode hyd_flush(HYDEncoder *e) {
 }
 
 static int device_fail(HYDEncoder *e, int code) {
+    e->dev_failed = 1;
     /* hydamd status codes are HYDStatusCode values; keep a static string for the message */
     static const char *const generic = "GPU encode failed (see hydamd_error)";
     const char *m = hydamd_error(e->dev);
@@ -432,17 +573,10 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
     TRACE("GPU hot path (finish+sync)", t0);
     t0 = now_ms();
     LfgResult *res = calloc(n, sizeof(LfgResult));
-    uint8_t *payload = NULL;
     if (!res)
         return FAIL(e, HYD_NOMEM, "out of memory");
     unsigned max_alphabet = 0;
     const size_t payload_len = hydamd_payload_size(e->dev);
-    payload = malloc(payload_len ? payload_len : 1);
-    if (!payload) {
-        ret = FAIL(e, HYD_NOMEM, "out of memory");
-        goto done;
-    }
-    ret = hydamd_read_payload(e->dev, payload, payload_len);
     for (size_t s = 0; s < n && !ret; s++) {
         const size_t vbw = (shape->lfg[s].width + 7) >> 3, vbh = (shape->lfg[s].height + 7) >> 3;
         uint32_t log_alpha = 0, running = 0;
@@ -479,7 +613,7 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
     }
     TRACE("read back results", t0);
     t0 = now_ms();
-    ret = assemble_frame(e, shape, res, max_alphabet, payload, payload_len);
+    ret = assemble_frame(e, shape, res, max_alphabet, NULL, payload_len);
     TRACE("assemble frame (host)", t0);
 done:
     for (size_t s = 0; s < n; s++) {
@@ -487,7 +621,6 @@ done:
         free(res[s].lf_bits);
     }
     free(res);
-    free(payload);
     return ret;
 }
 
@@ -516,8 +649,11 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
     if (!e->dev) {
         int st = 0;
         const double tc = now_ms();
-        e->dev = hydamd_create(0, (int)e->lfg_per_frame, e->metadata.linear_light, 0, &st);
-        TRACE("create device context", tc);
+        e->dev_slots = e->lfg_per_frame;
+        e->dev_linear = e->metadata.linear_light != 0;
+        e->dev_failed = 0;
+        e->dev = ctx_acquire(e->dev_slots, e->dev_linear, &st);
+        TRACE("acquire device context", tc);
         if (!e->dev) {
             const char *m = hydamd_error(NULL);
             if (st == HYD_NOMEM)
@@ -783,6 +919,6 @@ HYDT_EXPORT int hydt_lf_group_coded(size_t vbw, size_t vbh, const uint8_t *lengt
     const char *err = NULL;
     const HydLfCoded lf = {lengths, alphabet, run_pairs, bits, bit_count};
     hb_init(&b);
-    return hydt_take(&b, hyd_write_lf_group_coded(&b, vbw, vbh, &lf, &err), out, out_len);
+    return hydt_take(&b, hyd_write_lf_group_coded(&b, vbw, vbh, &lf, lf_tail(vbw, vbh), &err), out, out_len);
 }
 #endif /* HYD_TEST_HOOKS */

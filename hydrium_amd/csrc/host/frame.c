@@ -362,7 +362,12 @@ int hyd_write_lf_group(HydBits *out, const int32_t *dc, size_t vbw, size_t vbh, 
     return out->failed ? ST_NOMEM : 0;
 }
 
-int hyd_write_lf_group_coded(HydBits *out, size_t vbw, size_t vbh, const HydLfCoded *lf, const char **err) {
+int hyd_write_lf_group_tail(HydBits *out, size_t vbw, size_t vbh, const char **err) {
+    return lf_group_hf_metadata(out, vbw, vbh, err);
+}
+
+int hyd_write_lf_group_coded(HydBits *out, size_t vbw, size_t vbh, const HydLfCoded *lf, const HydBits *tail,
+                             const char **err) {
     int ret = lf_group_prologue(out, err);
     if (ret)
         return ret;
@@ -391,9 +396,15 @@ int hyd_write_lf_group_coded(HydBits *out, size_t vbw, size_t vbh, const HydLfCo
     if (ret)
         return ret;
     hb_append_bits(out, lf->bits, lf->bit_count);
-    ret = lf_group_hf_metadata(out, vbw, vbh, err);
-    if (ret)
-        return ret;
+    if (tail) { /* the geometry-only HF metadata, coded once per distinct LF-group shape by the caller */
+        hb_append_bits(out, tail->data, (uint64_t)tail->len * 8);
+        if (tail->nacc)
+            hb_put(out, tail->acc, tail->nacc);
+    } else {
+        ret = lf_group_hf_metadata(out, vbw, vbh, err);
+        if (ret)
+            return ret;
+    }
     return out->failed ? ST_NOMEM : 0;
 }
 

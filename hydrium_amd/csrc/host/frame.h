@@ -57,7 +57,11 @@ typedef struct HydLfCoded {
     const uint8_t *bits;      /* symbol bits, LSB first */
     uint64_t bit_count;
 } HydLfCoded;
-int hyd_write_lf_group_coded(HydBits *out, size_t vbw, size_t vbh, const HydLfCoded *lf, const char **err);
+/* `tail`: optional result of hyd_write_lf_group_tail for this (vbw, vbh) — the HF-metadata
+ * sub-streams depend on the LF group's geometry only, so a frame needs them coded at most four times */
+int hyd_write_lf_group_coded(HydBits *out, size_t vbw, size_t vbh, const HydLfCoded *lf, const HydBits *tail,
+                             const char **err);
+int hyd_write_lf_group_tail(HydBits *out, size_t vbw, size_t vbh, const char **err);
 
 /* HF context -> cluster map of a frame with num_presets presets (encoder.c:852-901); returns clusters per preset */
 int hyd_hf_cluster_map(uint8_t *map, unsigned num_presets);

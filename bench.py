@@ -118,6 +118,8 @@ def main():
         """N > 1: concatenate every rank's packed sections for the frame `ctx` just coded (RCCL all-gather)."""
         ctx.sync()
         sharding.all_gather_sections(ctx.payload_tensor(), dist.group.WORLD)
+        if args.lf_coder == "on":  # the coded LF streams too: the gathered frame is complete
+            sharding.all_gather_sections(ctx.lf_payload_tensor(), dist.group.WORLD)
 
     def step(i):
         ctx = ctxs[i % len(ctxs)]
@@ -247,7 +249,7 @@ def main():
                        "lf_coder": "gpu" if args.lf_coder == "on" else "off",
                        "groups": lfg * 64 if W % 2048 == 0 and H % 2048 == 0 else None, "lf_groups": lfg,
                        "streams": len(ctxs), "rans_groups_per_workgroup": args.rans_waves, "parallelism": f"{world} x (one frame per GPU)" +
-                                                            (", RCCL all-gather of sections" if world > 1 else "")},
+                                                            (", RCCL all-gather of HF sections and LF streams" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_in, "avg_launch_ms": round(dom_ms, 4)},

@@ -46,7 +46,7 @@ hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets,
 hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
                        int count, hipStream_t stream);
 hipError_t launch_lf_coder(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, HydkLfStream *streams,
-                           uint32_t *bits, int num_slots, hipStream_t stream);
+                           uint32_t *bits, uint32_t *packed, unsigned long long *total, int num_slots, hipStream_t stream);
 hipError_t launch_lf_huffman_only(const uint32_t *hist, HydkLfStream *stream_out, uint32_t *codes, hipStream_t stream);
 hipError_t launch_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, int linear_light, int xmode,
                                uint32_t *mismatches, hipStream_t stream);
@@ -126,9 +126,14 @@ struct HydAmdContext {
     uint32_t *lf_codes = nullptr;          /* [HYDK_LF_CODES] likewise */
     HydkLfStream *lf_streams = nullptr;    /* [slots + 1] */
     uint32_t *lf_bits = nullptr;           /* [slots][HYDK_LF_BITWORDS] */
+    uint32_t *lf_packed = nullptr;         /* the same symbol data, back to back in slot order (4-byte aligned) */
+    unsigned long long *lf_total = nullptr; /* [1] bytes in lf_packed */
+    unsigned long long *h_lf_total_pinned = nullptr;
+    uint64_t h_lf_total = 0;
     hipStream_t lf_stream = nullptr;
     hipEvent_t lf_fork = nullptr, lf_join = nullptr;
     bool lf_pending = false;
+    int lf_slots = 0;                      /* slots covered by the last LF coder run */
     float *dbg_xyb = nullptr, *dbg_dct = nullptr;
     int32_t *dbg_quant = nullptr;
 
@@ -407,7 +412,9 @@ void hydamd_destroy(HydAmdContext *ctx) {
         (void)hipEventDestroy(ctx->lf_fork);
     if (ctx->lf_join)
         (void)hipEventDestroy(ctx->lf_join);
-    void *lfdev[] = {ctx->lf_recs, ctx->lf_hist, ctx->lf_codes, ctx->lf_streams, ctx->lf_bits};
+    if (ctx->h_lf_total_pinned)
+        (void)hipHostFree(ctx->h_lf_total_pinned);
+    void *lfdev[] = {ctx->lf_recs, ctx->lf_hist, ctx->lf_codes, ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total};
     for (void *p : lfdev)
         if (p)
             (void)hipFree(p);
@@ -461,6 +468,10 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipMalloc(&ctx->lf_codes, HYDK_LF_CODES * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->lf_streams, (slots + 1) * sizeof(HydkLfStream)));
     HIP_TRY(ctx, hipMalloc(&ctx->lf_bits, slots * HYDK_LF_BITWORDS * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->lf_packed, slots * HYDK_LF_BITWORDS * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->lf_total, sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_lf_total_pinned, sizeof(unsigned long long), hipHostMallocDefault));
+    *ctx->h_lf_total_pinned = 0;
     HIP_TRY(ctx, hipMemset(ctx->lf_streams, 0, (slots + 1) * sizeof(HydkLfStream)));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lf_stream, hipStreamNonBlocking));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_fork, hipEventDisableTiming));
@@ -727,8 +738,11 @@ int hydamd_run_transform(HydAmdContext *ctx, int num_slots) {
         {
             ScopedTimer timer(ctx, HYDAMD_K_LF, ctx->lf_stream);
             HIP_TRY(ctx, hydk::launch_lf_coder(ctx->d_jobs, ctx->lf_recs, ctx->lf_hist, ctx->lf_streams, ctx->lf_bits,
-                                               num_slots, ctx->lf_stream));
+                                               ctx->lf_packed, ctx->lf_total, num_slots, ctx->lf_stream));
         }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lf_total_pinned, ctx->lf_total, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                    ctx->lf_stream));
+        ctx->lf_slots = num_slots;
         HIP_TRY(ctx, hipEventRecord(ctx->lf_join, ctx->lf_stream));
         ctx->lf_pending = true;
     }
@@ -821,6 +835,7 @@ int hydamd_sync(HydAmdContext *ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     drain_timers(ctx);
     ctx->h_total = *ctx->h_total_pinned;
+    ctx->h_lf_total = *ctx->h_lf_total_pinned;
     ctx->h_status = *ctx->h_status_pinned;
     if (ctx->h_status & 1u)
         return fail(ctx, ST_API_ERROR, "Invalid NaN Float");
@@ -932,6 +947,35 @@ int hydamd_read_lf_bits(HydAmdContext *ctx, int slot, uint8_t *dst, size_t capac
         return fail(ctx, ST_API_ERROR, "LF bit request too large");
     if (capacity)
         HIP_TRY(ctx, hipMemcpy(dst, ctx->lf_bits + (size_t)slot * HYDK_LF_BITWORDS, capacity, hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+size_t hydamd_lf_payload_size(HydAmdContext *ctx) {
+    return ctx && ctx->results_valid && ctx->lf_on_device ? (size_t)ctx->h_lf_total : 0;
+}
+
+const uint8_t *hydamd_lf_payload_device(HydAmdContext *ctx) { return ctx ? (const uint8_t *)ctx->lf_packed : nullptr; }
+
+int hydamd_read_lf_payload(HydAmdContext *ctx, uint8_t *dst, size_t capacity) {
+    if (!ctx || !ctx->lf_on_device || !ctx->results_valid)
+        return fail(ctx, ST_API_ERROR, "no device-coded LF stream: the LF coder is off or the frame was not synchronised");
+    if (capacity < ctx->h_lf_total)
+        return fail(ctx, ST_API_ERROR, "LF payload buffer too small");
+    if (ctx->h_lf_total)
+        HIP_TRY(ctx, hipMemcpy(dst, ctx->lf_packed, ctx->h_lf_total, hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int hydamd_read_lf_streams(HydAmdContext *ctx, int first_slot, int count, HydAmdLfInfo *dst) {
+    if (!ctx || !ctx->lf_on_device || !ctx->results_valid)
+        return fail(ctx, ST_API_ERROR, "no device-coded LF stream: the LF coder is off or the frame was not synchronised");
+    if (first_slot < 0 || count < 1 || first_slot + count > ctx->lf_slots)
+        return fail(ctx, ST_API_ERROR, "LF-group slot range out of bounds");
+    static_assert(sizeof(HydAmdLfInfo) == sizeof(HydkLfStream), "public and kernel-side LF stream records must agree");
+    HIP_TRY(ctx, hipMemcpy(dst, ctx->lf_streams + first_slot, (size_t)count * sizeof(HydkLfStream), hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; i++)
+        if (dst[i].error)
+            return fail(ctx, ST_INTERNAL_ERROR, "LF code construction failed on the device");
     return ST_OK;
 }
 

@@ -90,6 +90,8 @@ typedef struct HydkLfStream {
     uint32_t alphabet;                 /* largest token + 1 of the value cluster */
     uint32_t run_pairs;                /* (run token, distance) pairs sent; the distance cluster only ever sees token 1 */
     uint32_t error;                    /* non-zero: code construction failed */
+    uint32_t offset;                   /* byte offset of the symbol data in the frame's packed LF payload */
+    uint32_t pad[3];
     uint8_t lengths[HYDK_LF_CODES];    /* prefix-code length per compact token index (0 = unused) */
 } HydkLfStream;
 

@@ -712,6 +712,35 @@ __global__ __launch_bounds__(kLfThreads) void k_lf_code(const HydkLfJob *__restr
         streams[slot].bit_count = nbits;
 }
 
+/* The LF groups' symbol data, 4-byte aligned, back to back in slot order: one copy (or one
+ * all-gather) moves a frame's LF streams.  grid = LF groups, block = 256. */
+__global__ __launch_bounds__(256) void k_lf_gather(HydkLfStream *__restrict__ streams, const uint32_t *__restrict__ bits_all,
+                                                   uint32_t *__restrict__ packed, unsigned long long *__restrict__ total,
+                                                   int num_slots) {
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    __shared__ uint32_t s_off;
+    if (tid < 64) {
+        uint32_t mine = 0;
+        for (int s = tid; s < slot; s += 64)
+            mine += (streams[s].bit_count + 31u) >> 5;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            mine += __shfl_xor(mine, d);
+        if (tid == 0)
+            s_off = mine;
+    }
+    __syncthreads();
+    const uint32_t off = s_off, words = (streams[slot].bit_count + 31u) >> 5;
+    const uint32_t *src = bits_all + (size_t)slot * HYDK_LF_BITWORDS;
+    for (uint32_t w = tid; w < words; w += 256)
+        packed[off + w] = src[w];
+    if (tid == 0) {
+        streams[slot].offset = off * 4u;
+        if (slot == num_slots - 1)
+            *total = (unsigned long long)(off + words) * 4ull;
+    }
+}
+
 /* unit-test entry: the code construction alone, on a histogram in global memory */
 __global__ __launch_bounds__(64) void k_lf_huffman(const uint32_t *__restrict__ hist, HydkLfStream *__restrict__ stream_out,
                                                    uint32_t *__restrict__ codes) {
@@ -724,9 +753,10 @@ __global__ __launch_bounds__(64) void k_lf_huffman(const uint32_t *__restrict__ 
 namespace hydk {
 
 hipError_t launch_lf_coder(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, HydkLfStream *streams,
-                           uint32_t *bits, int num_slots, hipStream_t stream) {
+                           uint32_t *bits, uint32_t *packed, unsigned long long *total, int num_slots, hipStream_t stream) {
     hipLaunchKernelGGL(k_lf_tokens, dim3(num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist);
     hipLaunchKernelGGL(k_lf_code, dim3(num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist, streams, bits);
+    hipLaunchKernelGGL(k_lf_gather, dim3(num_slots), dim3(256), 0, stream, streams, bits, packed, total, num_slots);
     return hipGetLastError();
 }
 

@@ -45,7 +45,7 @@
 
 typedef struct LfgResult {
     int32_t *dc; /* [3][vbh][vbw]; NULL when the LF coefficients were coded on the device */
-    uint8_t *lf_bits;                    /* device-coded LF-coefficient symbols (malloc'ed) or NULL */
+    uint8_t *lf_bits;                    /* device-coded LF-coefficient symbols (borrowed) or NULL */
     uint8_t lf_lengths[HYD_LF_CODES];
     uint32_t lf_alphabet, lf_run_pairs, lf_bit_count;
     uint32_t freq[HYD_FRAME_MAX_CLUSTERS][HYD_FRAME_ALPHABET];
@@ -577,21 +577,34 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
         return FAIL(e, HYD_NOMEM, "out of memory");
     unsigned max_alphabet = 0;
     const size_t payload_len = hydamd_payload_size(e->dev);
+    HydAmdLfInfo *lf_info = NULL;
+    uint8_t *lf_blob = NULL;
+    size_t lf_len = 0;
+    if (hydamd_lf_coder(e->dev)) { /* two copies bring every LF group's coded coefficient stream */
+        lf_len = hydamd_lf_payload_size(e->dev);
+        lf_info = malloc(n * sizeof(HydAmdLfInfo));
+        lf_blob = malloc(lf_len ? lf_len : 1);
+        if (!lf_info || !lf_blob) {
+            ret = HYD_NOMEM;
+        } else {
+            ret = hydamd_read_lf_streams(e->dev, 0, (int)n, lf_info);
+            if (!ret)
+                ret = hydamd_read_lf_payload(e->dev, lf_blob, lf_len);
+        }
+    }
     for (size_t s = 0; s < n && !ret; s++) {
         const size_t vbw = (shape->lfg[s].width + 7) >> 3, vbh = (shape->lfg[s].height + 7) >> 3;
         uint32_t log_alpha = 0, running = 0;
-        if (hydamd_lf_coder(e->dev)) { /* the LF coefficients were coded on the GPU */
-            ret = hydamd_read_lf_stream(e->dev, (int)s, res[s].lf_lengths, &res[s].lf_alphabet, &res[s].lf_run_pairs,
-                                        &res[s].lf_bit_count);
-            if (ret)
-                break;
-            const size_t nbytes = ((size_t)res[s].lf_bit_count + 7) >> 3;
-            res[s].lf_bits = malloc(nbytes ? nbytes : 1);
-            if (!res[s].lf_bits) {
-                ret = HYD_NOMEM;
+        if (lf_info) { /* the LF coefficients were coded on the GPU: records and symbol data are already here */
+            if ((size_t)lf_info[s].offset + (((size_t)lf_info[s].bit_count + 7) >> 3) > lf_len) {
+                ret = HYD_INTERNAL_ERROR;
                 break;
             }
-            ret = hydamd_read_lf_bits(e->dev, (int)s, res[s].lf_bits, nbytes);
+            memcpy(res[s].lf_lengths, lf_info[s].lengths, HYD_LF_CODES);
+            res[s].lf_alphabet = lf_info[s].alphabet;
+            res[s].lf_run_pairs = lf_info[s].run_pairs;
+            res[s].lf_bit_count = lf_info[s].bit_count;
+            res[s].lf_bits = lf_blob + lf_info[s].offset; /* borrowed from lf_blob */
         } else {
             res[s].dc = malloc(3 * vbw * vbh * sizeof(int32_t));
             if (!res[s].dc) {
@@ -616,11 +629,11 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
     ret = assemble_frame(e, shape, res, max_alphabet, NULL, payload_len);
     TRACE("assemble frame (host)", t0);
 done:
-    for (size_t s = 0; s < n; s++) {
+    for (size_t s = 0; s < n; s++)
         free(res[s].dc);
-        free(res[s].lf_bits);
-    }
     free(res);
+    free(lf_info);
+    free(lf_blob);
     return ret;
 }
 
@@ -799,11 +812,11 @@ HYDRIUM_EXPORT HYDStatusCode hyd_set_suggested_icc_profile(HYDEncoder *e, const 
  * — on other GPUs of the node, or by several contexts — into one frame.  This is the same
  * assemble_frame() hyd_send_tile ends in; it touches no GPU.
  * ------------------------------------------------------------------------------------------- */
-HYDRIUM_EXPORT int hydamd_frame_from_results(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
-                                             const uint32_t *tile_xy, const int32_t *const *dc, const uint32_t *freq,
-                                             const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
-                                             const uint8_t *payload, size_t payload_len, const uint8_t *icc,
-                                             size_t icc_size, uint8_t **out, size_t *out_len, const char **err) {
+static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
+                            const uint32_t *tile_xy, const int32_t *const *dc, const HydAmdLfStream *lf, const uint32_t *freq,
+                            const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
+                            const uint8_t *payload, size_t payload_len, const uint8_t *icc, size_t icc_size, uint8_t **out,
+                            size_t *out_len, const char **err) {
     HYDEncoder *e = hyd_encoder_new();
     if (!e)
         return HYD_NOMEM;
@@ -830,7 +843,19 @@ HYDRIUM_EXPORT int hydamd_frame_from_results(const HYDImageMetadata *md, int wri
             e->sent[s].y = ty;
             e->sent[s].width = (tx + 1) * e->tile_w > W ? W - tx * e->tile_w : e->tile_w;
             e->sent[s].height = (ty + 1) * e->tile_h > H ? H - ty * e->tile_h : e->tile_h;
-            res[s].dc = (int32_t *)dc[s];
+            if (lf) { /* LF coefficients already coded (on a GPU): borrowed, like dc */
+                if (!lf[s].lengths || (!lf[s].bits && lf[s].bit_count) || lf[s].bit_count > UINT32_MAX) {
+                    ret = FAIL(e, HYD_API_ERROR, "incomplete LF stream");
+                    break;
+                }
+                memcpy(res[s].lf_lengths, lf[s].lengths, HYD_LF_CODES);
+                res[s].lf_bits = (uint8_t *)(lf[s].bits ? lf[s].bits : (const uint8_t *)"");
+                res[s].lf_alphabet = lf[s].alphabet;
+                res[s].lf_run_pairs = lf[s].run_pairs;
+                res[s].lf_bit_count = (uint32_t)lf[s].bit_count;
+            } else {
+                res[s].dc = (int32_t *)dc[s];
+            }
             memcpy(res[s].freq, freq + s * HYD_FRAME_MAX_CLUSTERS * HYD_FRAME_ALPHABET, sizeof(res[s].freq));
             memcpy(res[s].alphabet, alphabet + s * HYD_FRAME_MAX_CLUSTERS, sizeof(res[s].alphabet));
             memcpy(res[s].bits, group_bits + s * HYDAMD_GROUPS_PER_LFG, sizeof(res[s].bits));
@@ -865,6 +890,28 @@ HYDRIUM_EXPORT int hydamd_frame_from_results(const HYDImageMetadata *md, int wri
     free(res);
     hyd_encoder_destroy(e);
     return ret;
+}
+
+HYDRIUM_EXPORT int hydamd_frame_from_results(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
+                                             const uint32_t *tile_xy, const int32_t *const *dc, const uint32_t *freq,
+                                             const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
+                                             const uint8_t *payload, size_t payload_len, const uint8_t *icc,
+                                             size_t icc_size, uint8_t **out, size_t *out_len, const char **err) {
+    if (!dc)
+        return HYD_API_ERROR;
+    return frame_from_parts(md, write_header, is_last, lfg_count, tile_xy, dc, NULL, freq, alphabet, group_bits, max_alphabet,
+                            payload, payload_len, icc, icc_size, out, out_len, err);
+}
+
+HYDRIUM_EXPORT int hydamd_frame_from_streams(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
+                                             const uint32_t *tile_xy, const HydAmdLfStream *lf, const uint32_t *freq,
+                                             const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
+                                             const uint8_t *payload, size_t payload_len, const uint8_t *icc,
+                                             size_t icc_size, uint8_t **out, size_t *out_len, const char **err) {
+    if (!lf)
+        return HYD_API_ERROR;
+    return frame_from_parts(md, write_header, is_last, lfg_count, tile_xy, NULL, lf, freq, alphabet, group_bits, max_alphabet,
+                            payload, payload_len, icc, icc_size, out, out_len, err);
 }
 
 HYDRIUM_EXPORT void hydamd_free(void *p) { free(p); }

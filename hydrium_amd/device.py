@@ -18,6 +18,8 @@ MAX_CLUSTERS = 9
 ALPHABET = 128
 GROUPS_PER_LFG = 64
 K_NAMES = ("transform_tokenize", "build_tables", "rans_encode", "pack_sections", "lf_coder")
+LF_INFO_DTYPE = np.dtype([("bit_count", "<u4"), ("alphabet", "<u4"), ("run_pairs", "<u4"), ("error", "<u4"),
+                          ("offset", "<u4"), ("reserved", "<u4", (3,)), ("lengths", "u1", (384,))])
 LF_CODES = 384  # compact token space of the LF-coefficient stream (include/hydrium_amd.h HYDAMD_LF_CODES)
 
 FMT_OF_DTYPE = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.float32): 2}
@@ -71,6 +73,10 @@ def dll(path: Optional[str] = None):
         d.hydamd_frame_from_results.argtypes = [
             C.POINTER(api.HYDImageMetadata), i, i, sz, vp, C.POINTER(vp), vp, vp, vp, u, vp, sz, C.c_char_p, sz,
             C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_char_p)]
+        d.hydamd_frame_from_streams.restype = i
+        d.hydamd_frame_from_streams.argtypes = [
+            C.POINTER(api.HYDImageMetadata), i, i, sz, vp, vp, vp, vp, vp, u, C.c_char_p, sz, C.c_char_p, sz,
+            C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_char_p)]
         d.hydamd_free.argtypes = [vp]
         d.hydamd_sync.argtypes = [vp]
         d.hydamd_payload_size.restype = sz
@@ -88,6 +94,12 @@ def dll(path: Optional[str] = None):
         d.hydamd_lf_coder.argtypes = [vp]
         d.hydamd_read_lf_stream.argtypes = [vp, i, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         d.hydamd_read_lf_bits.argtypes = [vp, i, vp, sz]
+        d.hydamd_read_lf_streams.argtypes = [vp, i, i, vp]
+        d.hydamd_lf_payload_size.restype = sz
+        d.hydamd_lf_payload_size.argtypes = [vp]
+        d.hydamd_lf_payload_device.restype = vp
+        d.hydamd_lf_payload_device.argtypes = [vp]
+        d.hydamd_read_lf_payload.argtypes = [vp, vp, sz]
         d.hydamd_debug_lf_code.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         d.hydamd_profile.argtypes = [vp, i]
         d.hydamd_profile_read.argtypes = [vp, vp, vp]
@@ -303,6 +315,33 @@ class DeviceContext:
         self._ck(self.d.hydamd_read_lf_bits(self.h, slot, out.ctypes.data, (bit_count + 7) // 8))
         return out[: (bit_count + 7) // 8]
 
+    def read_lf_streams(self, count: int, first: int = 0) -> np.ndarray:
+        """Structured array of the per-slot LF stream records (bit_count, alphabet, run_pairs, error, offset, lengths)."""
+        out = np.zeros(count, LF_INFO_DTYPE)
+        self._ck(self.d.hydamd_read_lf_streams(self.h, first, count, out.ctypes.data))
+        return out
+
+    def lf_payload_size(self) -> int:
+        return int(self.d.hydamd_lf_payload_size(self.h))
+
+    def read_lf_payload(self) -> np.ndarray:
+        n = self.lf_payload_size()
+        out = np.zeros(max(n, 1), np.uint8)
+        self._ck(self.d.hydamd_read_lf_payload(self.h, out.ctypes.data, n))
+        return out[:n]
+
+    def lf_payload_tensor(self):
+        """The frame's packed LF symbol data as a CUDA uint8 tensor aliasing the context's buffer (valid after sync)."""
+        import torch
+
+        n = self.lf_payload_size()
+        ptr = int(self.d.hydamd_lf_payload_device(self.h) or 0)
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (max(n, 1),), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        return torch.as_tensor(_View(), device="cuda")[:n]
+
     def debug_lf_code(self, hist: np.ndarray):
         """Device code construction for one histogram over the compact token space -> (lengths, codes, alphabet, error)."""
         hist = np.ascontiguousarray(hist, np.uint32)
@@ -315,22 +354,38 @@ class DeviceContext:
         return lengths, codes, a.value, e.value
 
 
+class HydAmdLfStream(C.Structure):
+    _fields_ = [("lengths", C.c_void_p), ("alphabet", C.c_uint32), ("run_pairs", C.c_uint32), ("bits", C.c_void_p),
+                ("bit_count", C.c_uint64)]
+
+
 def frame_from_results(md: "api.HYDImageMetadata", tiles, dcs, freqs, alphabets, group_bits, max_alphabet: int,
-                       payload: bytes, *, write_header=True, is_last=True, icc: Optional[bytes] = None) -> bytes:
-    """hydamd_frame_from_results: codestream bytes from LF-group results in `tiles` order (host only)."""
+                       payload: bytes, *, write_header=True, is_last=True, icc: Optional[bytes] = None,
+                       lf_streams=None) -> bytes:
+    """Codestream bytes from LF-group results in `tiles` order (host only).
+
+    The LF coefficients come either as LF ints (``dcs``, hydamd_frame_from_results) or, when the GPU
+    LF coder produced them, as ``lf_streams``: one (lengths, alphabet, run_pairs, bit_count, bits)
+    tuple per LF group (hydamd_frame_from_streams)."""
     d = dll()
     n = len(tiles)
     tile_xy = np.ascontiguousarray(np.array(tiles, np.uint32).reshape(-1))
-    dc_arrays = [np.ascontiguousarray(a, np.int32) for a in dcs]
-    dcp = (C.c_void_p * n)(*[a.ctypes.data for a in dc_arrays])
     freq = np.ascontiguousarray(np.stack(freqs).astype(np.uint32))
     alpha = np.ascontiguousarray(np.stack(alphabets).astype(np.uint32))
     bits = np.ascontiguousarray(np.stack(group_bits).astype(np.uint32))
     out, out_len, err = C.c_void_p(0), C.c_size_t(0), C.c_char_p(None)
-    ret = d.hydamd_frame_from_results(C.byref(md), int(write_header), int(is_last), n, tile_xy.ctypes.data, dcp,
-                                      freq.ctypes.data, alpha.ctypes.data, bits.ctypes.data, max_alphabet, payload,
-                                      len(payload), icc, len(icc) if icc else 0, C.byref(out), C.byref(out_len),
-                                      C.byref(err))
+    tail = (freq.ctypes.data, alpha.ctypes.data, bits.ctypes.data, max_alphabet, payload, len(payload), icc,
+            len(icc) if icc else 0, C.byref(out), C.byref(out_len), C.byref(err))
+    if lf_streams is not None:
+        keep = [(np.ascontiguousarray(l, np.uint8), np.ascontiguousarray(b, np.uint8)) for l, _, _, _, b in lf_streams]
+        arr = (HydAmdLfStream * n)()
+        for i, (_, a, r, nb, _) in enumerate(lf_streams):
+            arr[i] = HydAmdLfStream(keep[i][0].ctypes.data, a, r, keep[i][1].ctypes.data if nb else None, nb)
+        ret = d.hydamd_frame_from_streams(C.byref(md), int(write_header), int(is_last), n, tile_xy.ctypes.data, arr, *tail)
+    else:
+        dc_arrays = [np.ascontiguousarray(a, np.int32) for a in dcs]
+        dcp = (C.c_void_p * n)(*[a.ctypes.data for a in dc_arrays])
+        ret = d.hydamd_frame_from_results(C.byref(md), int(write_header), int(is_last), n, tile_xy.ctypes.data, dcp, *tail)
     if ret:
         raise DeviceError(ret, (err.value or b"").decode())
     data = C.string_at(out.value, out_len.value)

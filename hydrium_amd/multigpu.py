@@ -7,8 +7,9 @@ shards, both tiny next to the pixels:
 * before the entropy stage, one integer per LF group (largest token + 1) so that every shard can
   set its running-alphabet floor (reference entropy.c:459-460: the maximum is never reset between
   LF groups);
-* after it, the shard's results: packed HF sections (the all-gather of ``sharding``), LF ints,
-  frequency tables and section sizes.  Rank 0 wraps them with ``hydamd_frame_from_results``.
+* after it, the shard's results: packed HF sections (the all-gather of ``sharding``), the LF
+  coefficient streams coded by the GPU LF coder (or LF ints when it is off), frequency tables and
+  section sizes.  Rank 0 wraps them with ``hydamd_frame_from_streams`` / ``hydamd_frame_from_results``.
 
 ``Shard`` holds one shard's state; ``encode_serial`` drives N shards one after another in a single
 process (that is what the single-GPU tests run), ``encode_distributed`` is the same choreography
@@ -62,7 +63,7 @@ class Shard:
 
     def results(self):
         """dict of this shard's results, in its LF-group order (host copies)."""
-        out = dict(tiles=[], dc=[], freq=[], alphabet=[], bits=[], payload=b"", running_max=0)
+        out = dict(tiles=[], dc=[], lf=[], freq=[], alphabet=[], bits=[], payload=b"", running_max=0)
         if not self.lf_ids:
             return out
         self.ctx.sync()
@@ -72,7 +73,11 @@ class Shard:
             freq, alpha, _, running = self.ctx.read_tables(slot)
             bits, _ = self.ctx.read_sections(slot)
             out["tiles"].append((tx, ty))
-            out["dc"].append(self.ctx.read_dc(slot, -(-w // 8), -(-h // 8)))
+            if self.ctx.lf_coder():  # LF coefficients were coded on this GPU: ship the stream, not the ints
+                lengths, alpha_lf, pairs, nbits = self.ctx.read_lf_stream(slot)
+                out["lf"].append((lengths, alpha_lf, pairs, nbits, self.ctx.read_lf_bits(slot, nbits)))
+            else:
+                out["dc"].append(self.ctx.read_dc(slot, -(-w // 8), -(-h // 8)))
             out["freq"].append(freq)
             out["alphabet"].append(alpha)
             out["bits"].append(bits)
@@ -88,10 +93,15 @@ def assemble(width: int, height: int, shard_results: Sequence[dict], linear_ligh
              icc: Optional[bytes] = None) -> bytes:
     md = api.HYDImageMetadata(width, height, linear_light, -1, -1)
     tiles = [t for r in shard_results for t in r["tiles"]]
+    dcs = [a for r in shard_results for a in r["dc"]]
+    lfs = [a for r in shard_results for a in r.get("lf", [])]
+    if lfs and dcs:
+        raise ValueError("shards must agree on where the LF coefficients are coded")
     return device.frame_from_results(
-        md, tiles, [a for r in shard_results for a in r["dc"]], [a for r in shard_results for a in r["freq"]],
+        md, tiles, dcs, [a for r in shard_results for a in r["freq"]],
         [a for r in shard_results for a in r["alphabet"]], [a for r in shard_results for a in r["bits"]],
-        max(r["running_max"] for r in shard_results), b"".join(r["payload"] for r in shard_results), icc=icc)
+        max(r["running_max"] for r in shard_results), b"".join(r["payload"] for r in shard_results), icc=icc,
+        lf_streams=lfs if lfs else None)
 
 
 def encode_serial(img_tensor, num_shards: int, dev_index: int = 0, linear_light: int = 0) -> bytes:

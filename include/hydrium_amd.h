@@ -139,6 +139,17 @@ HYDAMD_EXPORT int hydamd_read_lf_stream(HydAmdContext *ctx, int slot, uint8_t le
                                         uint32_t *run_pairs, uint32_t *bit_count);
 /* the symbol bits, LSB first; capacity >= (bit_count + 7) / 8 */
 HYDAMD_EXPORT int hydamd_read_lf_bits(HydAmdContext *ctx, int slot, uint8_t *dst, size_t capacity);
+/* The frame's LF streams in two copies instead of two per slot: the per-slot records (with the byte
+ * offset of each slot's symbol data) and the symbol data of all slots back to back, 4-byte aligned,
+ * in slot order.  hydamd_lf_payload_device() is what a multi-GPU job all-gathers. */
+typedef struct HydAmdLfInfo {
+    uint32_t bit_count, alphabet, run_pairs, error, offset, reserved[3];
+    uint8_t lengths[HYDAMD_LF_CODES];
+} HydAmdLfInfo;
+HYDAMD_EXPORT int hydamd_read_lf_streams(HydAmdContext *ctx, int first_slot, int count, HydAmdLfInfo *dst);
+HYDAMD_EXPORT size_t hydamd_lf_payload_size(HydAmdContext *ctx);
+HYDAMD_EXPORT const uint8_t *hydamd_lf_payload_device(HydAmdContext *ctx);
+HYDAMD_EXPORT int hydamd_read_lf_payload(HydAmdContext *ctx, uint8_t *dst, size_t capacity);
 /* unit-test entry: run the device's code construction on one histogram over the compact token space */
 HYDAMD_EXPORT int hydamd_debug_lf_code(HydAmdContext *ctx, const uint32_t hist[HYDAMD_LF_CODES],
                                        uint8_t lengths[HYDAMD_LF_CODES], uint32_t codes[HYDAMD_LF_CODES],
@@ -175,6 +186,19 @@ HYDAMD_EXPORT int hydamd_run_entropy(HydAmdContext *ctx, int num_slots);
  */
 HYDAMD_EXPORT int hydamd_frame_from_results(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
                                             const uint32_t *tile_xy, const int32_t *const *dc, const uint32_t *freq,
+                                            const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
+                                            const uint8_t *payload, size_t payload_len, const uint8_t *icc,
+                                            size_t icc_size, uint8_t **out, size_t *out_len, const char **err);
+/* The same with LF groups whose coefficient streams were coded on the GPU (hydamd_read_lf_stream /
+ * hydamd_read_lf_bits) instead of LF ints: what a multi-GPU job gathers when the LF coder is on. */
+typedef struct HydAmdLfStream {
+    const uint8_t *lengths;  /* [HYDAMD_LF_CODES] */
+    uint32_t alphabet, run_pairs;
+    const uint8_t *bits;     /* (bit_count + 7) / 8 bytes */
+    uint64_t bit_count;
+} HydAmdLfStream;
+HYDAMD_EXPORT int hydamd_frame_from_streams(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
+                                            const uint32_t *tile_xy, const HydAmdLfStream *lf, const uint32_t *freq,
                                             const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
                                             const uint8_t *payload, size_t payload_len, const uint8_t *icc,
                                             size_t icc_size, uint8_t **out, size_t *out_len, const char **err);

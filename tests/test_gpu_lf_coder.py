@@ -144,3 +144,28 @@ def test_api_bytes_identical_with_host_lf_coder(monkeypatch):
     monkeypatch.setenv("HYDAMD_LF_CODER", "0")
     b = api.encode_image(lib, img)
     assert a == b
+
+
+def test_packed_lf_payload_matches_per_slot_reads():
+    import torch
+
+    img = synth.make_image("photo", 2048 + 520, 2048 + 264, 8, seed=9)   # 2 x 2 LF groups of four different shapes
+    t = torch.from_numpy(img).cuda()
+    with dev.DeviceContext(0, 4) as c:
+        c.encode_image_tensor(t)
+        c.sync()
+        info = c.read_lf_streams(4)
+        blob = c.read_lf_payload()
+        on_dev = c.lf_payload_tensor().cpu().numpy()
+        np.testing.assert_array_equal(on_dev, blob)
+        end = 0
+        for s in range(4):
+            lengths, alphabet, pairs, nbits = c.read_lf_stream(s)
+            assert (int(info["bit_count"][s]), int(info["alphabet"][s]), int(info["run_pairs"][s])) == (nbits, alphabet, pairs)
+            np.testing.assert_array_equal(info["lengths"][s], lengths)
+            off = int(info["offset"][s])
+            assert off == end and off % 4 == 0
+            nbytes = (nbits + 7) // 8
+            np.testing.assert_array_equal(blob[off:off + nbytes], c.read_lf_bits(s, nbits))
+            end = off + (nbits + 31) // 32 * 4
+        assert end == len(blob)

@@ -33,6 +33,17 @@ def test_sharded_frame_equals_reference(image, shards):
         assert got == api.encode_image(refprobe.reference_library(), img)
 
 
+def test_sharded_frame_with_host_lf_coder(image, monkeypatch):
+    """LF coder off: shards ship LF ints and rank 0's host codes them (hydamd_frame_from_results);
+    on (the default, all other tests): shards ship coded LF streams (hydamd_frame_from_streams)."""
+    from hydrium_amd import multigpu
+
+    img = image("photo", 2048 + 300, 2048 + 40, 16)
+    want = multigpu.encode_serial(_cuda(img), 2)
+    monkeypatch.setenv("HYDAMD_LF_CODER", "0")
+    assert multigpu.encode_serial(_cuda(img), 3) == want
+
+
 def test_sharded_float_frame_with_growing_alphabet():
     """Out-of-gamut floats make later LF groups need a larger alphabet than earlier ones: the
     running-maximum floor that shards exchange must reproduce the single-context result."""

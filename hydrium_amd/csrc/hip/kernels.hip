@@ -982,9 +982,9 @@ constexpr int kRowWin = 28; /* 16 symbols x 46 bits = 23 words + alignment slack
  * per workgroup with the plain table (74 KB), so one CU serves an LF group's entropy stage and
  * transform workgroups of other frames still fit beside it. */
 template <int WAVES, bool DOUBLED>
-__global__ __launch_bounds__(64 * WAVES) void k_rans_rows(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
-                                                          const uint32_t *sym_count_all, const HydkTables *tabs,
-                                                          uint32_t *bitbuf_all, uint32_t *group_bits_all, int preset_bits) {
+__device__ __forceinline__ void rans_rows_body(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
+                                               const uint32_t *sym_count_all, const HydkTables *tabs, uint32_t *bitbuf_all,
+                                               uint32_t *group_bits_all, int preset_bits) {
     constexpr int kThreads = 64 * WAVES;
     constexpr int kBlocksPerLfg = HYDK_GROUPS_PER_LFG / (4 * WAVES);
     constexpr int kTableEntries = DOUBLED ? kInvEntries : kInvEntries / 2;
@@ -1150,6 +1150,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_rows(const HydkLfJob *__res
             W[cur >> 5] = carry;
         group_bits_all[G] = live ? (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u - cur : 0u;
     }
+}
+
+template <int WAVES, bool DOUBLED>
+__global__ __launch_bounds__(64 * WAVES) void k_rans_rows(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
+                                                          const uint32_t *sym_count_all, const HydkTables *tabs,
+                                                          uint32_t *bitbuf_all, uint32_t *group_bits_all, int preset_bits) {
+    rans_rows_body<WAVES, DOUBLED>(jobs, tokens_all, sym_count_all, tabs, bitbuf_all, group_bits_all, preset_bits);
+}
+
+/* The throughput form (half an LF group per workgroup), capped at 128 registers: with its 94.7 KB
+ * of LDS only one of these fits on a CU, and what decides the pipelined frame rate is how many
+ * transform workgroups (128 VGPRs, 34 KB LDS) still fit beside it — two instead of one. */
+__global__ __launch_bounds__(1024) /* launched with 512 threads; the larger bound is what makes the compiler budget 128 registers */
+void k_rans_rows_half(
+    const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all, const uint32_t *sym_count_all, const HydkTables *tabs,
+    uint32_t *bitbuf_all, uint32_t *group_bits_all, int preset_bits) {
+    rans_rows_body<8, false>(jobs, tokens_all, sym_count_all, tabs, bitbuf_all, group_bits_all, preset_bits);
 }
 
 /* ==========================================================================================
@@ -1436,7 +1453,7 @@ hipError_t launch_rans_rows(const HydkLfJob *d_jobs, const uint64_t *tokens, con
                             uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int whole_lf_group,
                             hipStream_t stream) {
     if (whole_lf_group == 2)
-        hipLaunchKernelGGL((k_rans_rows<8, false>), dim3(num_slots * 2), dim3(512), 0, stream, d_jobs, tokens, sym_count, tabs,
+        hipLaunchKernelGGL(k_rans_rows_half, dim3(num_slots * 2), dim3(512), 0, stream, d_jobs, tokens, sym_count, tabs,
                            bitbuf, group_bits, preset_bits);
     else if (whole_lf_group)
         hipLaunchKernelGGL((k_rans_rows<16, false>), dim3(num_slots), dim3(1024), 0, stream, d_jobs, tokens, sym_count, tabs,

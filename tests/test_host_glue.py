@@ -25,6 +25,20 @@ def test_one_frame_matches_reference(ref_lib, image, kind, w, h, depth):
     assert got == want
 
 
+@pytest.mark.parametrize("kind,w,h,depth", [("photo", 256, 256, 8), ("photo", 8, 8, 8), ("noise", 257, 255, 8),
+                                           ("black", 64, 64, 8), ("white", 40, 520, 16), ("photo", 2049, 130, 8)])
+def test_one_frame_from_coded_lf_streams(ref_lib, image, kind, w, h, depth):
+    """hydamd_frame_from_streams: LF coefficient streams arrive already coded (what the GPU LF coder
+    ships); the model of tests/lf_model.py stands in for the device here."""
+    img = image(kind, w, h, depth)
+    assert glue.encode_with_oracle_stages(img, coded_lf=True) == api.encode_image(ref_lib, img)
+
+
+def test_tile_mode_from_coded_lf_streams(ref_lib, image):
+    img = image("photo", 600, 520, 8)
+    assert glue.encode_with_oracle_stages(img, 0, 0, coded_lf=True) == api.encode_image(ref_lib, img, shift_x=0, shift_y=0)
+
+
 @pytest.mark.parametrize("shift", [0, 1, 2, 3])
 def test_tile_mode_matches_reference(ref_lib, image, shift):
     img = image("photo", 1000, 700, 8)

@@ -31,8 +31,8 @@
 namespace hydk {
 hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, int xmode, uint32_t *status,
                             hipStream_t stream);
-hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int num_slots,
-                         uint32_t alpha_floor, hipStream_t stream);
+hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int first_slot,
+                         int num_slots, uint32_t alpha_floor, hipStream_t stream);
 hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
                        uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int waves,
                        hipStream_t stream);
@@ -46,7 +46,9 @@ hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets,
 hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
                        int count, hipStream_t stream);
 hipError_t launch_lf_coder(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, HydkLfStream *streams,
-                           uint32_t *bits, uint32_t *packed, unsigned long long *total, int num_slots, hipStream_t stream);
+                           uint32_t *bits, int num_slots, hipStream_t stream);
+hipError_t launch_lf_gather(HydkLfStream *streams, const uint32_t *bits, uint32_t *packed, unsigned long long *total,
+                            int num_slots, hipStream_t stream);
 hipError_t launch_lf_huffman_only(const uint32_t *hist, HydkLfStream *stream_out, uint32_t *codes, hipStream_t stream);
 hipError_t launch_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, int linear_light, int xmode,
                                uint32_t *mismatches, hipStream_t stream);
@@ -132,8 +134,10 @@ struct HydAmdContext {
     uint64_t h_lf_total = 0;
     hipStream_t lf_stream = nullptr;
     hipEvent_t lf_fork = nullptr, lf_join = nullptr;
-    bool lf_pending = false;
+    bool lf_pending = false;               /* the side stream holds work the main stream has not waited for */
+    bool lf_need_gather = false;           /* LF groups were coded since the frame's LF streams were last packed */
     int lf_slots = 0;                      /* slots covered by the last LF coder run */
+    int transformed = 0, coded = 0, lf_coded = 0; /* slots of the current frame whose transform / entropy / LF kernels are enqueued */
     float *dbg_xyb = nullptr, *dbg_dct = nullptr;
     int32_t *dbg_quant = nullptr;
 
@@ -144,6 +148,10 @@ struct HydAmdContext {
     size_t staging_cap = 0;
     hipEvent_t staged[kStaging] = {nullptr, nullptr};
     int staging_next = 0;
+    /* uploads run on their own stream so that tile n + 1 is copied while tile n's transform kernel runs */
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t frame_fence = nullptr; /* recorded on the main stream at hydamd_begin_frame */
+    bool copy_needs_fence = false;
 
     /* host mirrors filled by hydamd_sync */
     uint64_t h_total = 0;
@@ -299,6 +307,7 @@ int ensure_staging(HydAmdContext *ctx, size_t tile_bytes) {
     if (tile_bytes <= ctx->staging_cap)
         return ST_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
     for (int i = 0; i < kStaging; i++) {
         if (ctx->pinned[i])
             (void)hipHostFree(ctx->pinned[i]);
@@ -404,6 +413,12 @@ void hydamd_destroy(HydAmdContext *ctx) {
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     drain_timers(ctx);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    if (ctx->frame_fence)
+        (void)hipEventDestroy(ctx->frame_fence);
     if (ctx->lf_stream) {
         (void)hipStreamSynchronize(ctx->lf_stream);
         (void)hipStreamDestroy(ctx->lf_stream);
@@ -474,6 +489,8 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     *ctx->h_lf_total_pinned = 0;
     HIP_TRY(ctx, hipMemset(ctx->lf_streams, 0, (slots + 1) * sizeof(HydkLfStream)));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lf_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->frame_fence, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_fork, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_join, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) {
@@ -653,6 +670,11 @@ int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
     ctx->preset_bits = bits; /* hyd_cllog2(num_presets), encoder.c:940 */
     ctx->results_valid = false;
     ctx->slots_finished = 0;
+    ctx->transformed = ctx->coded = ctx->lf_coded = 0;
+    ctx->lf_need_gather = false;
+    /* this frame's uploads may overwrite the staging arena only after everything queued so far has read it */
+    HIP_TRY(ctx, hipEventRecord(ctx->frame_fence, ctx->stream));
+    ctx->copy_needs_fence = true;
     /* job descriptors are uploaded asynchronously from a small pinned ring, so up to three frames
      * can be queued behind the one executing without the host touching a descriptor in flight */
     ctx->jobs_idx = (int)(ctx->frame_counter++ & 3u);
@@ -706,10 +728,46 @@ int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, const void *const 
     else
         gather_packed((float *)ctx->pinned[k], src, row_stride, pixel_stride, width, height);
     char *base = ctx->d_arena + (size_t)slot * ctx->arena_tile;
-    HIP_TRY(ctx, hipMemcpyAsync(base, ctx->pinned[k], bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->staged[k], ctx->stream));
+    if (ctx->copy_needs_fence) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->frame_fence, 0));
+        ctx->copy_needs_fence = false;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(base, ctx->pinned[k], bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->staged[k], ctx->copy_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->staged[k], 0)); /* kernels queued from here on see the tile */
     const void *dsrc[3] = {base, base + ss, base + 2 * ss};
     return record_lf_group(ctx, slot, dsrc, (ptrdiff_t)(3 * width), 3, sample_fmt, width, height, preset);
+}
+
+/* K1 for slots [first, first + count) */
+static int transform_range(HydAmdContext *ctx, int first, int count) {
+    unsigned mask = 0;
+    for (int i = first; i < first + count; i++) {
+        if (ctx->h_jobs[i].width == 0)
+            return fail(ctx, ST_API_ERROR, "an LF-group slot of this frame was never submitted");
+        mask |= 1u << ctx->h_jobs[i].fmt;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_jobs + first, ctx->h_jobs + first, (size_t)count * sizeof(HydkLfJob),
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->jobs_uploaded[ctx->jobs_idx], ctx->stream));
+    ScopedTimer timer(ctx, HYDAMD_K_TRANSFORM);
+    HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs + first, count, mask, ctx->use_luts, ctx->status, ctx->stream));
+    return ST_OK;
+}
+
+/* The LF coder's token and code kernels for slots [first, first + count), whose transform kernels
+ * are already enqueued.  It needs only the LF ints they write: forked onto its own stream so that it
+ * overlaps the HF entropy stage; join_lf brings the streams back together. */
+static int lf_range(HydAmdContext *ctx, int first, int count) {
+    HIP_TRY(ctx, hipEventRecord(ctx->lf_fork, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->lf_stream, ctx->lf_fork, 0));
+    ScopedTimer timer(ctx, HYDAMD_K_LF, ctx->lf_stream);
+    HIP_TRY(ctx, hydk::launch_lf_coder(ctx->d_jobs + first, ctx->lf_recs + (size_t)first * HYDK_LF_SYMBOLS,
+                                       ctx->lf_hist + (size_t)first * HYDK_LF_CODES, ctx->lf_streams + first,
+                                       ctx->lf_bits + (size_t)first * HYDK_LF_BITWORDS, count, ctx->lf_stream));
+    ctx->lf_pending = true;
+    ctx->lf_need_gather = true;
+    return ST_OK;
 }
 
 int hydamd_run_transform(HydAmdContext *ctx, int num_slots) {
@@ -719,38 +777,35 @@ int hydamd_run_transform(HydAmdContext *ctx, int num_slots) {
         return fail(ctx, ST_API_ERROR, "slot count out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false;
-    for (int i = 0; i < num_slots; i++)
-        if (ctx->h_jobs[i].width == 0)
-            return fail(ctx, ST_API_ERROR, "an LF-group slot of this frame was never submitted");
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_jobs, ctx->h_jobs, (size_t)num_slots * sizeof(HydkLfJob), hipMemcpyHostToDevice,
-                                ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->jobs_uploaded[ctx->jobs_idx], ctx->stream));
-    {
-        ScopedTimer timer(ctx, HYDAMD_K_TRANSFORM);
-        HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs, num_slots, ctx->fmt_mask, ctx->use_luts, ctx->status,
-                                            ctx->stream));
+    if (num_slots > ctx->transformed) {
+        const int st = transform_range(ctx, ctx->transformed, num_slots - ctx->transformed);
+        if (st != ST_OK)
+            return st;
+        ctx->transformed = num_slots;
     }
-    if (ctx->lf_on_device) {
-        /* the LF coder needs only the LF ints the transform kernel just wrote: fork it onto its own
-         * stream so it overlaps the HF entropy stage; hydamd_run_entropy / hydamd_sync join it */
-        HIP_TRY(ctx, hipEventRecord(ctx->lf_fork, ctx->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->lf_stream, ctx->lf_fork, 0));
-        {
-            ScopedTimer timer(ctx, HYDAMD_K_LF, ctx->lf_stream);
-            HIP_TRY(ctx, hydk::launch_lf_coder(ctx->d_jobs, ctx->lf_recs, ctx->lf_hist, ctx->lf_streams, ctx->lf_bits,
-                                               ctx->lf_packed, ctx->lf_total, num_slots, ctx->lf_stream));
-        }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lf_total_pinned, ctx->lf_total, sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                                    ctx->lf_stream));
-        ctx->lf_slots = num_slots;
-        HIP_TRY(ctx, hipEventRecord(ctx->lf_join, ctx->lf_stream));
-        ctx->lf_pending = true;
+    if (ctx->lf_on_device && num_slots > ctx->lf_coded) {
+        const int st = lf_range(ctx, ctx->lf_coded, num_slots - ctx->lf_coded);
+        if (st != ST_OK)
+            return st;
+        ctx->lf_coded = num_slots;
     }
     return ST_OK;
 }
 
-static int join_lf(HydAmdContext *ctx) {
+/* the frame's LF streams are packed once all of its LF groups are coded (num_slots > 0: called from
+ * the frame's closing stage); then the side stream rejoins the main one */
+static int join_lf(HydAmdContext *ctx, int num_slots) {
+    if (num_slots > 0 && ctx->lf_need_gather) {
+        HIP_TRY(ctx, hydk::launch_lf_gather(ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total, num_slots,
+                                            ctx->lf_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lf_total_pinned, ctx->lf_total, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                    ctx->lf_stream));
+        ctx->lf_slots = num_slots;
+        ctx->lf_need_gather = false;
+        ctx->lf_pending = true;
+    }
     if (ctx->lf_pending) {
+        HIP_TRY(ctx, hipEventRecord(ctx->lf_join, ctx->lf_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->lf_join, 0));
         ctx->lf_pending = false;
     }
@@ -774,31 +829,49 @@ int hydamd_set_alphabet_floor(HydAmdContext *ctx, uint32_t floor) {
     return ST_OK;
 }
 
+/* K2 + K3a for slots [first, first + count) */
+static int entropy_range(HydAmdContext *ctx, int first, int count) {
+    const size_t G = HYDK_GROUPS_PER_LFG, g0 = (size_t)first * G;
+    {
+        ScopedTimer timer(ctx, HYDAMD_K_TABLES);
+        HIP_TRY(ctx, hydk::launch_tables(ctx->hist, ctx->tables, ctx->alpha_max, ctx->nclusters, first, count,
+                                         ctx->alpha_floor, ctx->stream));
+    }
+    {
+        ScopedTimer timer(ctx, HYDAMD_K_RANS);
+        const HydkLfJob *jobs = ctx->d_jobs + first;
+        uint64_t *tokens = ctx->tokens + g0 * HYDK_TOKENS_PER_GROUP;
+        uint32_t *bitbuf = ctx->bitbuf + g0 * HYDK_BITWORDS_PER_GROUP;
+        if (ctx->rans_lanes >= 2)
+            HIP_TRY(ctx, hydk::launch_rans_rows(jobs, tokens, ctx->sym_count + g0, ctx->tables + first, bitbuf,
+                                                ctx->group_bits + g0, ctx->preset_bits, count, ctx->rans_lanes - 2,
+                                                ctx->stream));
+        else if (ctx->rans_lanes)
+            HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, tokens, ctx->sym_count + g0, ctx->tables + first,
+                                                 ctx->final_state + g0, bitbuf, ctx->group_bits + g0, ctx->preset_bits,
+                                                 count, ctx->stream));
+        else
+            HIP_TRY(ctx, hydk::launch_rans(jobs, tokens, ctx->sym_count + g0, ctx->tables + first, bitbuf,
+                                           ctx->group_bits + g0, ctx->preset_bits, count, ctx->rans_waves, ctx->stream));
+    }
+    return ST_OK;
+}
+
 int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
     if (!ctx)
         return ST_API_ERROR;
     if (num_slots < 1 || num_slots > ctx->max_slots)
         return fail(ctx, ST_API_ERROR, "slot count out of range");
+    if (num_slots > ctx->transformed)
+        return fail(ctx, ST_API_ERROR, "the entropy stage needs the transform stage of the same slots first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int count = num_slots * HYDK_GROUPS_PER_LFG;
     ctx->results_valid = false;
-    {
-        ScopedTimer timer(ctx, HYDAMD_K_TABLES);
-        HIP_TRY(ctx, hydk::launch_tables(ctx->hist, ctx->tables, ctx->alpha_max, ctx->nclusters, num_slots,
-                                         ctx->alpha_floor, ctx->stream));
-    }
-    {
-        ScopedTimer timer(ctx, HYDAMD_K_RANS);
-        if (ctx->rans_lanes >= 2)
-            HIP_TRY(ctx, hydk::launch_rans_rows(ctx->d_jobs, ctx->tokens, ctx->sym_count, ctx->tables, ctx->bitbuf,
-                                                ctx->group_bits, ctx->preset_bits, num_slots, ctx->rans_lanes - 2,
-                                                ctx->stream));
-        else if (ctx->rans_lanes)
-            HIP_TRY(ctx, hydk::launch_rans_lanes(ctx->d_jobs, ctx->tokens, ctx->sym_count, ctx->tables, ctx->final_state,
-                                                 ctx->bitbuf, ctx->group_bits, ctx->preset_bits, num_slots, ctx->stream));
-        else
-            HIP_TRY(ctx, hydk::launch_rans(ctx->d_jobs, ctx->tokens, ctx->sym_count, ctx->tables, ctx->bitbuf,
-                                           ctx->group_bits, ctx->preset_bits, num_slots, ctx->rans_waves, ctx->stream));
+    if (num_slots > ctx->coded) {
+        const int st = entropy_range(ctx, ctx->coded, num_slots - ctx->coded);
+        if (st != ST_OK)
+            return st;
+        ctx->coded = num_slots;
     }
     {
         ScopedTimer timer(ctx, HYDAMD_K_PACK);
@@ -806,7 +879,7 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
         HIP_TRY(ctx, hydk::launch_pack(ctx->bitbuf, ctx->group_bits, ctx->offsets, ctx->payload, count, ctx->stream));
     }
     {
-        const int st = join_lf(ctx);
+        const int st = join_lf(ctx, num_slots);
         if (st != ST_OK)
             return st;
     }
@@ -814,6 +887,25 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status_pinned, ctx->status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     ctx->slots_finished = num_slots;
     return ST_OK;
+}
+
+int hydamd_submit_lf_group(HydAmdContext *ctx, int slot) {
+    int st = check_slot(ctx, slot);
+    if (st != ST_OK)
+        return st;
+    if (slot != ctx->transformed)
+        return fail(ctx, ST_API_ERROR, "LF groups are submitted early in slot order, one at a time");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    /* Only the transform kernel runs early.  The rANS stage is latency-bound by its longest chain
+     * (2 ms whether it codes one LF group or sixteen) and the LF coder by its one workgroup per LF
+     * group (0.6 ms likewise): launched per LF group they would queue up sixteen deep behind the
+     * uploads (measured: 53 ms instead of 20 ms per 8K frame); they stay batched launches at
+     * hydamd_finish_frame, where the LF coder hides behind the rANS stage. */
+    st = transform_range(ctx, slot, 1);
+    if (st == ST_OK)
+        ctx->transformed = slot + 1;
+    return st;
 }
 
 int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
@@ -828,7 +920,7 @@ int hydamd_sync(HydAmdContext *ctx) {
         return ST_API_ERROR;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     {
-        const int st = join_lf(ctx);
+        const int st = join_lf(ctx, 0); /* transform stage without an entropy stage: just rejoin the side stream */
         if (st != ST_OK)
             return st;
     }

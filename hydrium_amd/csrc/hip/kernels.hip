@@ -582,9 +582,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
  * ======================================================================================== */
 __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_all, HydkTables *tabs,
                                                            const uint32_t *alpha_max_all, int nclusters,
-                                                           uint32_t alpha_floor) {
-    const uint32_t *hist = hist_all + (size_t)blockIdx.x * HYDK_MAX_CLUSTERS * HYDK_ALPHABET;
-    HydkTables *tab = tabs + blockIdx.x;
+                                                           uint32_t alpha_floor, int first_slot) {
+    const unsigned slot = (unsigned)first_slot + blockIdx.x; /* all arrays are indexed by the frame's slot */
+    const uint32_t *hist = hist_all + (size_t)slot * HYDK_MAX_CLUSTERS * HYDK_ALPHABET;
+    HydkTables *tab = tabs + slot;
     __shared__ uint32_t s_freq[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
     __shared__ uint32_t s_cutoff[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
     __shared__ uint32_t s_other[HYDK_MAX_CLUSTERS][HYDK_ALPHABET];
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
         /* the stream-wide alphabet maximum is never reset between LF groups (entropy.c:459-460,952):
          * LF group n codes with the maximum over LF groups 0..n in send order */
         uint32_t mx = alpha_floor; /* maximum over the LF groups other GPUs coded before ours */
-        for (unsigned sl = 0; sl <= blockIdx.x; sl++)
+        for (unsigned sl = 0; sl <= slot; sl++)
             mx = max(mx, alpha_max_all[sl]);
         uint32_t lg = mx > 1 ? 32 - __clz((int)(mx - 1)) : 0; /* ceil(log2(mx)) */
         s_log_alpha = max(lg, 5u);
@@ -1433,10 +1434,10 @@ hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt
     return hipGetLastError();
 }
 
-hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int num_slots,
-                         uint32_t alpha_floor, hipStream_t stream) {
+hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int first_slot,
+                         int num_slots, uint32_t alpha_floor, hipStream_t stream) {
     hipLaunchKernelGGL(k_build_tables, dim3(num_slots), dim3(kThreads), 0, stream, hist, tabs, alpha_max, nclusters,
-                       alpha_floor);
+                       alpha_floor, first_slot);
     return hipGetLastError();
 }
 

@@ -752,10 +752,17 @@ __global__ __launch_bounds__(64) void k_lf_huffman(const uint32_t *__restrict__ 
 
 namespace hydk {
 
+/* tokens + code for `num_slots` LF groups; every pointer addresses the first of them */
 hipError_t launch_lf_coder(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, HydkLfStream *streams,
-                           uint32_t *bits, uint32_t *packed, unsigned long long *total, int num_slots, hipStream_t stream) {
+                           uint32_t *bits, int num_slots, hipStream_t stream) {
     hipLaunchKernelGGL(k_lf_tokens, dim3(num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist);
     hipLaunchKernelGGL(k_lf_code, dim3(num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist, streams, bits);
+    return hipGetLastError();
+}
+
+/* once per frame, over all of its LF groups */
+hipError_t launch_lf_gather(HydkLfStream *streams, const uint32_t *bits, uint32_t *packed, unsigned long long *total,
+                            int num_slots, hipStream_t stream) {
     hipLaunchKernelGGL(k_lf_gather, dim3(num_slots), dim3(256), 0, stream, streams, bits, packed, total, num_slots);
     return hipGetLastError();
 }

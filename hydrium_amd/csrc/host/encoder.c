@@ -420,6 +420,16 @@ static int ctx_cache_on(void) {
     return on;
 }
 
+/* HYDAMD_EAGER=0: code the whole frame when its final tile arrives instead of tile by tile (A/B) */
+static int eager_on(void) {
+    static int on = -1;
+    if (on < 0) {
+        const char *v = getenv("HYDAMD_EAGER");
+        on = !(v && *v == '0');
+    }
+    return on;
+}
+
 static HydAmdContext *ctx_acquire(size_t slots, int linear, int *status) {
     HydAmdContext *c = NULL;
     pthread_mutex_lock(&g_ctx_lock);
@@ -691,6 +701,8 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
     const double tu = now_ms();
     ret = hydamd_encode_lf_group_host(e->dev, (int)slot, buffer, row_stride, pixel_stride, (int)sample_fmt, tw, th,
                                       (unsigned)l->raster_id);
+    if (!ret && eager_on()) /* code this LF group while the caller prepares / we stage the next tile */
+        ret = hydamd_submit_lf_group(e->dev, (int)slot);
     if (ret)
         return device_fail(e, ret);
     TRACE("stage + upload tile", tu);

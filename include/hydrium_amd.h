@@ -109,6 +109,12 @@ HYDAMD_EXPORT int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, cons
                                               ptrdiff_t row_stride, ptrdiff_t pixel_stride, int sample_fmt,
                                               size_t width, size_t height, unsigned preset);
 
+/* Optional: enqueue the transform stage of the LF group in `slot` right away instead of at
+ * hydamd_finish_frame (slots in order, one at a time).  hyd_send_tile uses it so that the GPU works
+ * on LF group n while the host is still staging tile n + 1; hydamd_finish_frame then runs what is
+ * left (the entropy stage and the LF coder, batched over the frame) and packs. */
+HYDAMD_EXPORT int hydamd_submit_lf_group(HydAmdContext *ctx, int slot);
+
 /* Enqueue section sizing + packing for slots [0, num_slots): byte-padded HF sections, slot-major, raster inside a slot. */
 HYDAMD_EXPORT int hydamd_finish_frame(HydAmdContext *ctx, int num_slots);
 

@@ -110,7 +110,9 @@ def main():
     ctxs = [device.DeviceContext(local, lfg, 0) for _ in range(max(1, args.streams))]
     for c in ctxs:
         c.set_rans_waves(args.rans_waves)
-        c.set_lf_coder(args.lf_coder == "on")
+        # throughput loop: the LF coder runs at the end of each context's own stream (mode 2), so that
+        # 12 frames in flight stay within the 16 hardware queues; the latency leg uses the side stream
+        c.set_lf_coder(2 if args.lf_coder == "on" else 0)
 
     pending = []  # contexts whose frame is queued but whose sections have not been exchanged yet
 
@@ -182,6 +184,8 @@ def main():
     if world == 1:
         c0 = ctxs[0]
         c0.set_rans_waves(4)
+        if args.lf_coder == "on":
+            c0.set_lf_coder(1)
         c0.encode_image_tensor(img)
         c0.sync()
         c0.profile(True)
@@ -194,6 +198,8 @@ def main():
         lk = {k: round(ms / max(n, 1), 4) for k, (ms, n) in c0.profile_read().items()}
         c0.profile(False)
         c0.set_rans_waves(args.rans_waves)
+        if args.lf_coder == "on":
+            c0.set_lf_coder(2)
         lat = {"ms_per_frame": round(tl * 1e3, 4), "Mpixel/s": round(W * H / tl / 1e6, 1), "kernel_avg_ms": lk,
                "note": "one stream, one frame at a time, rANS form 4 (one wave per group); kernels not overlapped"}
 
@@ -219,7 +225,7 @@ def main():
         hf_only = {"Mpixel/s": round(W * H * k2 / t2 / 1e6, 1), "steps": k2,
                    "note": "same loop, LF coder off: HF group sections only, LF ints left for a host coder"}
         for c in ctxs:
-            c.set_lf_coder(True)
+            c.set_lf_coder(2)
 
     if rank == 0:
         bytes_in = W * H * 3 * (args.depth // 8)
@@ -246,7 +252,7 @@ def main():
                                    "hot path device-resident RGB -> packed HF group sections "
                                    "(XYB, DCT, quantise, tokenise, ANS tables, rANS, pack)" +
                                    (" + prefix-coded LF coefficient streams" if args.lf_coder == "on" else ""),
-                       "lf_coder": "gpu" if args.lf_coder == "on" else "off",
+                       "lf_coder": "gpu, in-stream" if args.lf_coder == "on" else "off",
                        "groups": lfg * 64 if W % 2048 == 0 and H % 2048 == 0 else None, "lf_groups": lfg,
                        "streams": len(ctxs), "rans_groups_per_workgroup": args.rans_waves, "parallelism": f"{world} x (one frame per GPU)" +
                                                             (", RCCL all-gather of HF sections and LF streams" if world > 1 else "")},

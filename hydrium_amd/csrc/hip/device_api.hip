@@ -122,7 +122,7 @@ struct HydAmdContext {
     size_t payload_cap = 0;
 
     /* LF-group coder (lf_coder.hip): runs on its own stream between two events of the main one */
-    int lf_on_device = 1;
+    int lf_on_device = 1;                  /* 0 off, 1 on a side stream beside the entropy stage, 2 at the end of the main stream */
     unsigned long long *lf_recs = nullptr; /* [slots][HYDK_LF_SYMBOLS] */
     uint32_t *lf_hist = nullptr;           /* [slots + 1][HYDK_LF_CODES]; the last entry is hydamd_debug_lf_code's scratch */
     uint32_t *lf_codes = nullptr;          /* [HYDK_LF_CODES] likewise */
@@ -307,6 +307,8 @@ int ensure_staging(HydAmdContext *ctx, size_t tile_bytes) {
     if (tile_bytes <= ctx->staging_cap)
         return ST_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->copy_stream) /* created on first use: device-pointer users never need it */
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
     for (int i = 0; i < kStaging; i++) {
         if (ctx->pinned[i])
@@ -489,7 +491,6 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     *ctx->h_lf_total_pinned = 0;
     HIP_TRY(ctx, hipMemset(ctx->lf_streams, 0, (slots + 1) * sizeof(HydkLfStream)));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lf_stream, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->frame_fence, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_fork, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_join, hipEventDisableTiming));
@@ -554,7 +555,7 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
             ctx->rans_lanes = w + 1;
     }
     if (const char *env = getenv("HYDAMD_LF_CODER")) /* 0: leave the LF ints to the host coder (A/B measurements) */
-        ctx->lf_on_device = atoi(env) != 0;
+        ctx->lf_on_device = atoi(env) == 2 ? 2 : atoi(env) != 0;
     if (const char *env = getenv("HYDAMD_XYB_MODE")) { /* 0 / 1 / 2, never faster than what was proven exact */
         const int m = atoi(env);
         if (m >= ctx->best_register_mode && m <= 2)
@@ -759,13 +760,17 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
  * are already enqueued.  It needs only the LF ints they write: forked onto its own stream so that it
  * overlaps the HF entropy stage; join_lf brings the streams back together. */
 static int lf_range(HydAmdContext *ctx, int first, int count) {
-    HIP_TRY(ctx, hipEventRecord(ctx->lf_fork, ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->lf_stream, ctx->lf_fork, 0));
-    ScopedTimer timer(ctx, HYDAMD_K_LF, ctx->lf_stream);
+    const bool forked = ctx->lf_on_device == 1;
+    hipStream_t where = forked ? ctx->lf_stream : ctx->stream;
+    if (forked) {
+        HIP_TRY(ctx, hipEventRecord(ctx->lf_fork, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->lf_stream, ctx->lf_fork, 0));
+    }
+    ScopedTimer timer(ctx, HYDAMD_K_LF, where);
     HIP_TRY(ctx, hydk::launch_lf_coder(ctx->d_jobs + first, ctx->lf_recs + (size_t)first * HYDK_LF_SYMBOLS,
                                        ctx->lf_hist + (size_t)first * HYDK_LF_CODES, ctx->lf_streams + first,
-                                       ctx->lf_bits + (size_t)first * HYDK_LF_BITWORDS, count, ctx->lf_stream));
-    ctx->lf_pending = true;
+                                       ctx->lf_bits + (size_t)first * HYDK_LF_BITWORDS, count, where));
+    ctx->lf_pending = forked;
     ctx->lf_need_gather = true;
     return ST_OK;
 }
@@ -783,7 +788,7 @@ int hydamd_run_transform(HydAmdContext *ctx, int num_slots) {
             return st;
         ctx->transformed = num_slots;
     }
-    if (ctx->lf_on_device && num_slots > ctx->lf_coded) {
+    if (ctx->lf_on_device == 1 && num_slots > ctx->lf_coded) {
         const int st = lf_range(ctx, ctx->lf_coded, num_slots - ctx->lf_coded);
         if (st != ST_OK)
             return st;
@@ -795,14 +800,22 @@ int hydamd_run_transform(HydAmdContext *ctx, int num_slots) {
 /* the frame's LF streams are packed once all of its LF groups are coded (num_slots > 0: called from
  * the frame's closing stage); then the side stream rejoins the main one */
 static int join_lf(HydAmdContext *ctx, int num_slots) {
+    if (num_slots > 0 && ctx->lf_on_device == 2 && num_slots > ctx->lf_coded) {
+        /* in-stream mode: the whole LF coder runs here, behind the frame's packing kernels (no extra
+         * stream: with many frames in flight side streams alias onto the same hardware queues) */
+        const int st = lf_range(ctx, ctx->lf_coded, num_slots - ctx->lf_coded);
+        if (st != ST_OK)
+            return st;
+        ctx->lf_coded = num_slots;
+    }
     if (num_slots > 0 && ctx->lf_need_gather) {
-        HIP_TRY(ctx, hydk::launch_lf_gather(ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total, num_slots,
-                                            ctx->lf_stream));
+        hipStream_t where = ctx->lf_on_device == 1 ? ctx->lf_stream : ctx->stream;
+        HIP_TRY(ctx, hydk::launch_lf_gather(ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total, num_slots, where));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lf_total_pinned, ctx->lf_total, sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                                    ctx->lf_stream));
+                                    where));
         ctx->lf_slots = num_slots;
         ctx->lf_need_gather = false;
-        ctx->lf_pending = true;
+        ctx->lf_pending = ctx->lf_on_device == 1;
     }
     if (ctx->lf_pending) {
         HIP_TRY(ctx, hipEventRecord(ctx->lf_join, ctx->lf_stream));
@@ -1002,7 +1015,7 @@ int hydamd_read_dc(HydAmdContext *ctx, int slot, int32_t *dst, size_t vbw, size_
 int hydamd_set_lf_coder(HydAmdContext *ctx, int on_device) {
     if (!ctx)
         return ST_API_ERROR;
-    ctx->lf_on_device = on_device != 0;
+    ctx->lf_on_device = on_device == 2 ? 2 : on_device != 0;
     return ST_OK;
 }
 

@@ -297,7 +297,8 @@ class DeviceContext:
         return {K_NAMES[i]: (ms[i], n[i]) for i in range(len(K_NAMES))}
 
     # ---- LF-group coder (csrc/hip/lf_coder.hip) ----
-    def set_lf_coder(self, on_device: bool):
+    def set_lf_coder(self, on_device):
+        """False/0 off, True/1 on a side stream (lowest latency), 2 at the end of the main stream (throughput)."""
         self._ck(self.d.hydamd_set_lf_coder(self.h, int(on_device)))
 
     def lf_coder(self) -> bool:

@@ -138,6 +138,8 @@ HYDAMD_EXPORT int hydamd_read_dc(HydAmdContext *ctx, int slot, int32_t *dst, siz
 /* ---- LF-group coder: the LF-coefficient sub-stream of every submitted LF group is coded on the
  * GPU alongside the HF entropy stage (on by default; 0 leaves the LF ints to a host coder via
  * hydamd_read_dc).  Results are valid after hydamd_sync(). ---- */
+/* on_device: 0 off; 1 (default) on a side stream beside the HF entropy stage — lowest frame latency;
+ * 2 at the end of the context's own stream — no second stream per context, for many frames in flight */
 HYDAMD_EXPORT int hydamd_set_lf_coder(HydAmdContext *ctx, int on_device);
 HYDAMD_EXPORT int hydamd_lf_coder(HydAmdContext *ctx);
 /* code length per compact token, largest token + 1, number of (run, distance) pairs, bits of symbol data */

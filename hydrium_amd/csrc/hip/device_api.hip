@@ -115,7 +115,6 @@ struct HydAmdContext {
     hipEvent_t jobs_uploaded[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned frame_counter = 0;
     int jobs_idx = 0;
-    unsigned fmt_mask = 0;          /* sample formats present among the submitted LF groups */
     uint16_t *in_lut8 = nullptr, *in_lut16 = nullptr;
     float *bias_lut = nullptr;
     uint8_t *payload = nullptr;
@@ -298,7 +297,6 @@ int record_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrd
         job.dbg_dct = ctx->dbg_dct;
         job.dbg_quant = ctx->dbg_quant;
     }
-    ctx->fmt_mask |= 1u << fmt;
     ctx->results_valid = false;
     return ST_OK;
 }
@@ -685,7 +683,6 @@ int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
     HIP_TRY(ctx, hipMemsetAsync(ctx->hist, 0,
                                 (size_t)ctx->max_slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->alpha_max, 0, (size_t)ctx->max_slots * sizeof(uint32_t), ctx->stream));
-    ctx->fmt_mask = 0;
     ctx->alpha_floor = 0;
     HIP_TRY(ctx, hipMemsetAsync(ctx->status, 0, sizeof(uint32_t), ctx->stream));
     return ST_OK;

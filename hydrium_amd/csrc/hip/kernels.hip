@@ -1040,7 +1040,7 @@ __device__ __forceinline__ void rans_rows_body(const HydkLfJob *__restrict__ job
     /* 16-lane segmented emission: lane l = 0 of a row is nearest the bits already written */
     auto emit = [&](unsigned long long val, uint32_t nbits) {
         const uint32_t inc = scan16_inclusive(nbits);
-        const uint32_t total = __shfl(inc, 15, 16);
+        const uint32_t total = HYDK_DPP(inc, 0x15F, 0xF); /* row_newbcast:15 — the row's last lane to all of its lanes */
         const uint32_t newcur = cur - total;
         const uint32_t wlo = newcur >> 5, whi = (cur - 1u) >> 5;
         const uint32_t nwords = total ? whi - wlo + 1u : 0u;
@@ -1087,7 +1087,7 @@ __device__ __forceinline__ void rans_rows_body(const HydkLfJob *__restrict__ job
         const uint32_t f = valid ? (fbv & 0xFFFFu) : 1u;
         const uint32_t thr = (uint32_t)(((unsigned long long)f << 20) - 1ull);
         uint4 op;
-        op.x = DOUBLED ? (uint32_t)(-2 * (int)f) : f;
+        op.x = DOUBLED ? (uint32_t)(-2 * (int)f) : (uint32_t)(-(int)f);
         op.y = s_magic[e];
         op.z = DOUBLED ? (((lo >> 8) & 0xF) * (2u * HYDK_ANS_SLOTS) + 2u * (fbv >> 16)) * 2u
                        : (((lo >> 8) & 0xF) * (uint32_t)HYDK_ANS_SLOTS + (fbv >> 16)) * 2u;
@@ -1106,14 +1106,17 @@ __device__ __forceinline__ void rans_rows_body(const HydkLfJob *__restrict__ job
             const uint32_t at = (uint32_t)__mul24((int)q, (int)o.x) + (o.z + 2u * x);                      \
             state = (q << 12) + *(const uint16_t *)(inv_bytes + at);                                       \
         } else {                                                                                           \
-            /* q is floor(x/f) or one less: fold the remainder back below f and bump q */                  \
-            const uint32_t r0 = x - __umul24(q, o.x);                                                      \
-            const uint32_t r = min(r0, r0 - o.x);                                                          \
-            q += r0 >= o.x;                                                                                \
+            /* q is floor(x/f) or one less: both candidate remainders come straight off the          \
+             * multiply (o.x holds -f; x - f is formed in the multiply-high's shadow) */                   \
+            const uint32_t r0 = (uint32_t)(__mul24((int)q, (int)o.x) + (int)x);                            \
+            const uint32_t r1 = (uint32_t)(__mul24((int)q, (int)o.x) + (int)(x + o.x));                    \
+            const uint32_t r = min(r0, r1);                                                                \
+            q += (int)r1 >= 0;                                                                             \
             state = (q << 12) | *(const uint16_t *)(inv_bytes + o.z + 2u * r);                             \
         }                                                                                                  \
     } while (0)
-        if (__all(cnt == 16)) {
+        const bool full_round = __all(cnt == 16);
+        if (full_round) {
             /* every row of the wave has a full round: no per-step predication */
 #pragma unroll
             for (int k = 0; k < 16; k++)
@@ -1127,7 +1130,8 @@ __device__ __forceinline__ void rans_rows_body(const HydkLfJob *__restrict__ job
 #undef HYDK_ROW_STEP
         __builtin_amdgcn_wave_barrier();
         /* the state seen by step j sits in lane cnt-1-j of the row */
-        const uint32_t seen = (uint32_t)__shfl((int)trail, (cnt - 1 - l) & 15, 16);
+        const uint32_t seen = full_round ? HYDK_DPP(trail, 0x140, 0xF) /* row_mirror: lane 15 - l */
+                                         : (uint32_t)__shfl((int)trail, (cnt - 1 - l) & 15, 16);
         const uint32_t rbits = valid ? (lo >> 16) & 0x3Fu : 0u;
         const bool refill = valid && seen > thr;
         const unsigned long long residue = rec >> 32;

@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t to_u16(float x) { /* format.c:33-36 */
 
 /* XYB evaluation modes of the integer pixel path (the launcher picks the first one whose
  * register evaluation reproduces all 65536 host-built LUT entries bit for bit):
- *   0  registers, reciprocal by v_rcp_f32 + two fused correction steps (Markstein)
+ *   0  registers, reciprocal by v_rcp_f32 + one fused Newton step
  *   1  registers, IEEE division as the compiler expands it
  *   2  gathers from the uploaded LUTs */
 constexpr int kXybFastRcp = 0, kXybIeeeDiv = 1, kXybGather = 2;
@@ -128,17 +128,19 @@ template <int XMODE>
 __device__ __forceinline__ float bias_lut_eval(uint32_t i) {
     if (XMODE == kXybIeeeDiv)
         return bias_curve((float)i * kUnit16);
-    /* same operations as bias_curve (format.c:21-31) with 1.0f / z computed as a correctly rounded
-     * reciprocal: explicit fmaf() is a fused operation regardless of the contraction setting, and
-     * is used for the division only, whose IEEE result does not depend on how it is reached */
+    /* same operations as bias_curve (format.c:21-31) with 1.0f / z computed as v_rcp_f32 plus one
+     * fused Newton step: explicit fmaf() is a fused operation regardless of the contraction setting,
+     * and is used for the division only, whose IEEE result does not depend on how it is reached.
+     * That one step reproduces the IEEE quotient for every z this LUT can see is not assumed but
+     * checked: k_lut_selftest compares all 65536 entries at context creation, and a device where
+     * it fails runs the IEEE-division variant instead. */
     const float x = (float)i * kUnit16 + 0.0037930732552754493f;
     float z = __uint_as_float(0x548c39cbu - __float_as_uint(x) / 3u);
     z *= 1.5015480449f - 0.534850249f * x * z * z * z;
     z *= 1.333333985f - 0.33333333f * x * z * z * z;
     const float r0 = __builtin_amdgcn_rcpf(z);
     const float r1 = __builtin_fmaf(r0, __builtin_fmaf(-z, r0, 1.0f), r0);
-    const float r2 = __builtin_fmaf(__builtin_fmaf(-z, r1, 1.0f), r0, r1);
-    return r2 - 0.155954f;
+    return r1 - 0.155954f;
 }
 
 template <int XMODE>

@@ -75,7 +75,7 @@ HYDAMD_EXPORT void *hydamd_get_stream(HydAmdContext *ctx);
 HYDAMD_EXPORT int hydamd_uses_register_luts(HydAmdContext *ctx);
 /* Force the LUT-gather (1) or register (0) variant; for A/B measurements. */
 HYDAMD_EXPORT int hydamd_force_luts(HydAmdContext *ctx, int use_luts);
-/* XYB evaluation mode of the integer pixel path: 0 registers with v_rcp + fused correction,
+/* XYB evaluation mode of the integer pixel path: 0 registers with v_rcp + one fused Newton step,
  * 1 registers with IEEE division, 2 LUT gathers.  Only modes that reproduced all 65536 LUT entries
  * bit for bit in the creation-time self-test can be selected; the fastest such mode is the default. */
 HYDAMD_EXPORT int hydamd_xyb_mode(HydAmdContext *ctx);

@@ -239,7 +239,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(f"{dom}:{W}x{H}:u{args.depth}:{args.kind}")
+                form = f":form{args.rans_waves}" if dom == "rans_encode" else ""
+                traffic = json.load(f).get(f"{dom}{form}:{W}x{H}:u{args.depth}:{args.kind}")
         out = {
             "metric": "Mpixel/s encode (8K RGB, default q)",
             "value": round(world * W * H * args.steps / dt / 1e6, 1),

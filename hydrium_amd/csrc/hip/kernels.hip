@@ -795,6 +795,25 @@ __device__ __forceinline__ uint32_t scan64_inclusive(uint32_t v) {
 constexpr int kWinWords = 100; /* 64 symbols x 46 bits = 92 words + alignment slack */
 constexpr int kInvEntries = HYDK_MAX_CLUSTERS * 2 * HYDK_ANS_SLOTS;
 
+/* x = state > thr ? state >> 16 : state in two issue slots: the select reads the high half of the
+ * state through SDWA instead of a separate shift (every slot counts: the chain is one wave issuing
+ * in order, so an instruction off the dependency path still delays the next step) */
+__device__ __forceinline__ uint32_t rans_renorm(uint32_t state, uint32_t thr) {
+    uint32_t x;
+    asm("v_cmp_gt_u32 vcc, %1, %2\n\t"
+        "v_cndmask_b32_sdwa %0, %1, %1, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+        : "=v"(x)
+        : "v"(state), "v"(thr)
+        : "vcc");
+    return x;
+}
+/* a + b * c with 24-bit factors in one slot (the compiler prefers a multiply and a three-input add) */
+__device__ __forceinline__ uint32_t mad24(uint32_t b, uint32_t c, uint32_t a) {
+    uint32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(c), "v"(a));
+    return r;
+}
+
 /* one step of the recurrence; the symbol's operands {-2f, floor(2^32/f), table address, threshold}
  * were staged in LDS by the lane that owns it and arrive by one broadcast ds_read_b128 */
 #define HYDK_RANS_STEP(src)                                                                   \
@@ -802,12 +821,12 @@ constexpr int kInvEntries = HYDK_MAX_CLUSTERS * 2 * HYDK_ANS_SLOTS;
         const uint4 o = ops[(src)];                                                           \
         /* lane 0 <- state, lane l <- trail[l-1]: the states file past, newest in lane 0 */   \
         trail = (uint32_t)__builtin_amdgcn_update_dpp((int)state, (int)trail, 0x138, 0xF, 0xF, false); \
-        const uint32_t x = state > o.w ? state >> 16 : state;                                 \
+        const uint32_t x = rans_renorm(state, o.w);                                           \
         /* q = mulhi(x, floor(2^32/f)) is floor(x/f) or one less, so r = x - q*f < 2f; the   \
          * doubled table returns slot(r mod f) + 4096*(r >= f), which also repairs q.  The    \
          * byte address adr + 2r is formed as (adr + 2x) + q*(-2f): one op after the mulhi */  \
         const uint32_t q = __umulhi(x, o.y);                                                  \
-        const uint32_t at = (uint32_t)__mul24((int)q, (int)o.x) + (o.z + 2u * x);             \
+        const uint32_t at = mad24(q, o.x, o.z + 2u * x);                                      \
         const uint32_t ent = *(const uint16_t *)(inv_bytes + at);                             \
         state = (q << 12) + ent;                                                              \
     } while (0)
@@ -1102,16 +1121,16 @@ __device__ __forceinline__ void rans_rows_body(const HydkLfJob *__restrict__ job
     do {                                                                                                   \
         const uint4 o = ops[(k)];                                                                          \
         trail = (uint32_t)__builtin_amdgcn_update_dpp((int)state, (int)trail, 0x111, 0xF, 0xF, false);     \
-        const uint32_t x = state > o.w ? state >> 16 : state;                                              \
+        const uint32_t x = rans_renorm(state, o.w);                                                        \
         uint32_t q = __umulhi(x, o.y);                                                                     \
         if (DOUBLED) {                                                                                     \
-            const uint32_t at = (uint32_t)__mul24((int)q, (int)o.x) + (o.z + 2u * x);                      \
+            const uint32_t at = mad24(q, o.x, o.z + 2u * x);                                               \
             state = (q << 12) + *(const uint16_t *)(inv_bytes + at);                                       \
         } else {                                                                                           \
             /* q is floor(x/f) or one less: both candidate remainders come straight off the          \
              * multiply (o.x holds -f; x - f is formed in the multiply-high's shadow) */                   \
-            const uint32_t r0 = (uint32_t)(__mul24((int)q, (int)o.x) + (int)x);                            \
-            const uint32_t r1 = (uint32_t)(__mul24((int)q, (int)o.x) + (int)(x + o.x));                    \
+            const uint32_t r0 = mad24(q, o.x, x);                                                          \
+            const uint32_t r1 = mad24(q, o.x, x + o.x);                                                    \
             const uint32_t r = min(r0, r1);                                                                \
             q += (int)r1 >= 0;                                                                             \
             state = (q << 12) | *(const uint16_t *)(inv_bytes + o.z + 2u * r);                             \

@@ -115,3 +115,47 @@ def test_golden_manifest(lib, image):
         if "file" in entry:
             with open(os.path.join(GOLDEN, entry["file"]), "rb") as fh:
                 assert got == fh.read()
+
+
+def test_abandoned_frame_leaves_a_reusable_context(lib, image):
+    """An encoder destroyed half-way through a frame parks its device context (encoder.c context
+    reuse); the next encoder of the same shape must start from a clean slate."""
+    img = image("photo", 2048 + 300, 2048 + 200, 8)     # 2 x 2 LF groups
+    want, _ = _expected(img)
+    enc = api.Encoder(lib)
+    enc.check(enc.set_metadata(img.shape[1], img.shape[0]))
+    import ctypes as C
+    buf = (C.c_uint8 * (1 << 20))()
+    enc.check(enc.provide_output(buf))
+    enc.check(enc.send_tile(img, 0, 0, 2048, 2048))
+    enc.check(enc.send_tile(img, 1, 0, 2048, 2048))
+    enc.close()                                          # two of four tiles sent, kernels queued
+    other = image("noise", 2048 + 300, 2048 + 200, 8)    # same shape, different content in between
+    assert api.encode_image(lib, other) == _expected(other)[0]
+    assert api.encode_image(lib, img) == want
+
+
+def test_two_encoders_on_two_threads(lib, image):
+    """Distinct encoders may run on distinct threads (SURVEY 8b threading contract): the parked
+    context, the LF-metadata cache and the staging threads are shared process state."""
+    import threading
+
+    imgs = [image("photo", 2048 + 100, 600, 8), image("smooth", 900, 2048 + 64, 16)]
+    want = [_expected(i)[0] for i in imgs]
+    got = [None, None]
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                got[k] = api.encode_image(lib, imgs[k])
+        except Exception as e:  # noqa: BLE001 - surfaced below
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert got[0] == want[0] and got[1] == want[1]

@@ -39,9 +39,6 @@ hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const ui
 hipError_t launch_rans_rows(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
                             uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int whole_lf_group,
                             hipStream_t stream);
-hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
-                             uint32_t *final_state, uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots,
-                             hipStream_t stream);
 hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, hipStream_t stream);
 hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
                        int count, hipStream_t stream);
@@ -86,9 +83,8 @@ struct HydAmdContext {
     int best_register_mode = 2;     /* best mode that passed the bit-exactness self-test */
     int register_luts_ok = 0;
     int rans_waves = 4;             /* groups per rANS workgroup: 4 (latency) .. 16 (throughput) */
-    int rans_lanes = 0;             /* 1: lane-per-group chain kernel + parallel emit (throughput form) */
+    int rans_rows = 0;              /* 0: wave per group; 1..3: row forms 1..3 (hydamd_set_rans_waves) */
     uint32_t alpha_floor = 0;       /* running maximum alphabet of the LF groups coded before this context's */
-    uint32_t *final_state = nullptr; /* [slots][64] */
     unsigned num_presets = 1;
     int scheme = 0;
     int nclusters = 9;
@@ -434,7 +430,7 @@ void hydamd_destroy(HydAmdContext *ctx) {
         if (p)
             (void)hipFree(p);
     void *dev[] = {ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->hist, ctx->sym_count, ctx->group_bits,
-                   ctx->offsets, ctx->total, ctx->status, ctx->alpha_max, ctx->final_state, ctx->d_jobs, ctx->in_lut8, ctx->in_lut16,
+                   ctx->offsets, ctx->total, ctx->status, ctx->alpha_max, ctx->d_jobs, ctx->in_lut8, ctx->in_lut16,
                    ctx->bias_lut, ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant, ctx->d_arena};
     for (void *p : dev)
         if (p)
@@ -476,7 +472,6 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipMalloc(&ctx->total, sizeof(uint64_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->status, sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->alpha_max, slots * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->final_state, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_jobs, slots * sizeof(HydkLfJob)));
     HIP_TRY(ctx, hipMalloc(&ctx->lf_recs, slots * HYDK_LF_SYMBOLS * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc(&ctx->lf_hist, (slots + 1) * HYDK_LF_CODES * sizeof(uint32_t))); /* +1: the unit-test entry's scratch */
@@ -547,10 +542,8 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
         const int w = atoi(env);
         if (w == 4)
             ctx->rans_waves = w;
-        if (w == 64)
-            ctx->rans_lanes = 1;
         if (w >= 1 && w <= 3)
-            ctx->rans_lanes = w + 1;
+            ctx->rans_rows = w;
     }
     if (const char *env = getenv("HYDAMD_LF_CODER")) /* 0: leave the LF ints to the host coder (A/B measurements) */
         ctx->lf_on_device = atoi(env) == 2 ? 2 : atoi(env) != 0;
@@ -626,18 +619,14 @@ int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode) {
 int hydamd_set_rans_waves(HydAmdContext *ctx, int waves) {
     if (!ctx)
         return ST_API_ERROR;
-    if (waves == 64) { /* one LANE per group: 64 chains per wave */
-        ctx->rans_lanes = 1;
-        return ST_OK;
-    }
     if (waves >= 1 && waves <= 3) { /* four chains per wave, one per 16-lane row; 2: a whole LF group, 3: half of one, per workgroup */
-        ctx->rans_lanes = waves + 1;
+        ctx->rans_rows = waves;
         return ST_OK;
     }
     if (waves != 4)
-        return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group), 1/2/3 (row forms) or 64 (lane per group)");
+        return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group) or 1/2/3 (row forms)");
     ctx->rans_waves = waves;
-    ctx->rans_lanes = 0;
+    ctx->rans_rows = 0;
     return ST_OK;
 }
 
@@ -852,14 +841,10 @@ static int entropy_range(HydAmdContext *ctx, int first, int count) {
         const HydkLfJob *jobs = ctx->d_jobs + first;
         uint64_t *tokens = ctx->tokens + g0 * HYDK_TOKENS_PER_GROUP;
         uint32_t *bitbuf = ctx->bitbuf + g0 * HYDK_BITWORDS_PER_GROUP;
-        if (ctx->rans_lanes >= 2)
+        if (ctx->rans_rows)
             HIP_TRY(ctx, hydk::launch_rans_rows(jobs, tokens, ctx->sym_count + g0, ctx->tables + first, bitbuf,
-                                                ctx->group_bits + g0, ctx->preset_bits, count, ctx->rans_lanes - 2,
+                                                ctx->group_bits + g0, ctx->preset_bits, count, ctx->rans_rows - 1,
                                                 ctx->stream));
-        else if (ctx->rans_lanes)
-            HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, tokens, ctx->sym_count + g0, ctx->tables + first,
-                                                 ctx->final_state + g0, bitbuf, ctx->group_bits + g0, ctx->preset_bits,
-                                                 count, ctx->stream));
         else
             HIP_TRY(ctx, hydk::launch_rans(jobs, tokens, ctx->sym_count + g0, ctx->tables + first, bitbuf,
                                            ctx->group_bits + g0, ctx->preset_bits, count, ctx->rans_waves, ctx->stream));

@@ -1196,169 +1196,6 @@ void k_rans_rows_half(
 }
 
 /* ==========================================================================================
- * K3a, throughput form: the same recurrence with one LANE per group (64 chains per wave, one wave
- * per LF group).  A step costs about the same latency as in k_rans_encode, but the instruction
- * is issued once for 64 groups, so the entropy stage of a frame keeps only a handful of CUs
- * lightly busy and other frames' transform kernels run beside it at full speed.  The chain
- * rewrites each token record's low word as
- *       residue bit count | refill flag << 8 | (state & 0xFFFF) << 16
- * and k_rans_emit turns records into bits, wave-parallel, one wave per group.
- * ======================================================================================== */
-__global__ __launch_bounds__(64) void k_rans_chain(const HydkLfJob *__restrict__ jobs, uint64_t *tokens_all,
-                                                   const uint32_t *sym_count_all, const HydkTables *tabs,
-                                                   uint32_t *final_state_all) {
-    __shared__ uint16_t s_inv[kInvEntries];                          /* 144 KiB */
-    __shared__ uint32_t s_fb[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
-    __shared__ uint32_t s_magic[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
-
-    const int lane = threadIdx.x;
-    const int slot = blockIdx.x;
-    const int ngroups = jobs[slot].gcols * jobs[slot].grows;
-    const HydkTables *tab = tabs + slot;
-    {
-        const uint4 *src = (const uint4 *)&tab->inv[0][0];
-        uint4 *dst = (uint4 *)s_inv;
-        for (int i = lane; i < kInvEntries / 8; i += 64)
-            dst[i] = src[i];
-        for (int i = lane; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += 64) {
-            s_fb[i] = (&tab->fb[0][0])[i];
-            s_magic[i] = (&tab->magic[0][0])[i];
-        }
-    }
-    __syncthreads();
-    const unsigned char *inv_bytes = (const unsigned char *)s_inv;
-    const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + lane;
-    const int n = lane < ngroups ? (int)sym_count_all[G] : 0;
-    uint64_t *tok = tokens_all + G * HYDK_TOKENS_PER_GROUP;
-    int nmax = n;
-#pragma unroll
-    for (int d = 32; d; d >>= 1)
-        nmax = max(nmax, __shfl_xor(nmax, d));
-
-    uint32_t state = 0x130000u;
-    constexpr int kAhead = 4; /* records are fetched this many steps before they are needed */
-    uint64_t ring[kAhead];
-#pragma unroll
-    for (int k = 0; k < kAhead; k++)
-        ring[k] = n - 1 - k >= 0 ? tok[n - 1 - k] : 0ull;
-    for (int i0 = 0; i0 < nmax; i0 += kAhead) {
-#pragma unroll
-        for (int k = 0; k < kAhead; k++) {
-            const int i = i0 + k;
-            const int p = n - 1 - i;
-            const uint64_t rec = ring[k];
-            const int pn = p - kAhead;
-            ring[k] = pn >= 0 ? tok[pn] : 0ull;
-            if (p >= 0) {
-                const uint32_t lo = (uint32_t)rec;
-                const uint32_t cl = (lo >> 8) & 0xF;
-                const uint32_t e = cl * HYDK_ALPHABET + (lo & 0xFF);
-                const uint32_t fbv = s_fb[e];
-                const uint32_t mg = s_magic[e];
-                const uint32_t f = fbv & 0xFFFFu;
-                const uint32_t thr = (uint32_t)(((unsigned long long)f << 20) - 1ull);
-                const uint32_t adr = (cl * (2u * HYDK_ANS_SLOTS) + 2u * (fbv >> 16)) * 2u;
-                const bool refill = state > thr;
-                ((uint32_t *)(tok + p))[0] = ((lo >> 16) & 0x3Fu) | (refill ? 0x100u : 0u) | (state << 16);
-                const uint32_t x = refill ? state >> 16 : state;
-                const uint32_t q = __umulhi(x, mg);
-                const uint32_t at = (uint32_t)__mul24((int)q, -2 * (int)f) + (adr + 2u * x);
-                const uint32_t ent = *(const uint16_t *)(inv_bytes + at);
-                state = (q << 12) + ent;
-            }
-        }
-    }
-    if (lane < ngroups)
-        final_state_all[G] = state;
-}
-
-/* one wave per group: records (as rewritten by k_rans_chain) -> bits, filled from the buffer's end */
-__global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
-                                                        const uint32_t *sym_count_all, const uint32_t *final_state_all,
-                                                        uint32_t *bitbuf_all, uint32_t *group_bits_all, int preset_bits) {
-    __shared__ uint32_t s_win[4][kWinWords];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int slot = blockIdx.x >> 4;
-    const int g = ((blockIdx.x & 15) << 2) + wave;
-    const int ngroups = jobs[slot].gcols * jobs[slot].grows;
-    const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + g;
-    if (g >= ngroups) {
-        if (lane == 0)
-            group_bits_all[G] = 0;
-        return;
-    }
-    const uint64_t *tok = tokens_all + G * HYDK_TOKENS_PER_GROUP;
-    uint32_t *W = bitbuf_all + G * HYDK_BITWORDS_PER_GROUP;
-    uint32_t *win = s_win[wave];
-    const int n = __builtin_amdgcn_readfirstlane((int)sym_count_all[G]);
-    uint32_t cur = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u;
-    uint32_t carry = 0;
-
-    auto emit = [&](unsigned long long val, uint32_t nbits) {
-        const uint32_t inc = scan64_inclusive(nbits);
-        const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
-        if (!total)
-            return;
-        const uint32_t newcur = cur - total;
-        const uint32_t wlo = newcur >> 5, whi = (cur - 1u) >> 5;
-        const uint32_t nwords = whi - wlo + 1u;
-        for (uint32_t i = lane; i < nwords; i += 64)
-            win[i] = 0;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0 && (cur & 31u))
-            win[whi - wlo] = carry;
-        __builtin_amdgcn_wave_barrier();
-        if (nbits) {
-            const uint32_t pos = cur - inc - wlo * 32u;
-            const uint32_t w = pos >> 5, sh = pos & 31u;
-            const unsigned long long lo = val << sh;
-            const uint32_t hi = sh ? (uint32_t)(val >> (64u - sh)) : 0u;
-            if ((uint32_t)lo)
-                atomicOr(&win[w], (uint32_t)lo);
-            if ((uint32_t)(lo >> 32))
-                atomicOr(&win[w + 1], (uint32_t)(lo >> 32));
-            if (hi)
-                atomicOr(&win[w + 2], hi);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const bool low_partial = (newcur & 31u) != 0;
-        for (uint32_t i = lane + (low_partial ? 1u : 0u); i < nwords; i += 64)
-            W[wlo + i] = win[i];
-        carry = low_partial ? win[0] : 0u;
-        __builtin_amdgcn_wave_barrier();
-        cur = newcur;
-    };
-
-    for (int hi_p = n - 1; hi_p >= 0; hi_p -= 64) {
-        const int p = hi_p - lane;
-        const uint64_t rec = p >= 0 ? tok[p] : 0ull;
-        const uint32_t lo = (uint32_t)rec;
-        const uint32_t rbits = lo & 0x3Fu;
-        const bool refill = (lo & 0x100u) != 0;
-        const unsigned long long residue = rec >> 32;
-        const unsigned long long val = refill ? (residue << 16) | (lo >> 16) : residue;
-        emit(val, p >= 0 ? rbits + (refill ? 16u : 0u) : 0u);
-    }
-    {
-        unsigned long long val = 0;
-        uint32_t nb = 0;
-        if (lane == 0 && n > 0) {
-            val = final_state_all[G];
-            nb = 32;
-        } else if (lane == 1) {
-            val = jobs[slot].preset;
-            nb = (uint32_t)preset_bits;
-        }
-        emit(val, nb);
-    }
-    if (lane == 0) {
-        if (cur & 31u)
-            W[cur >> 5] = carry;
-        group_bits_all[G] = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u - cur;
-    }
-}
-
-/* ==========================================================================================
  * K3b: section sizes -> offsets (single block), then pack each section to its byte offset.
  * Sections are byte-padded with zeros, as hyd_bitwriter_flush does (bitwriter.c:144-150).
  * ======================================================================================== */
@@ -1487,15 +1324,6 @@ hipError_t launch_rans_rows(const HydkLfJob *d_jobs, const uint64_t *tokens, con
     else
         hipLaunchKernelGGL((k_rans_rows<4, true>), dim3(num_slots * 4), dim3(256), 0, stream, d_jobs, tokens, sym_count, tabs,
                            bitbuf, group_bits, preset_bits);
-    return hipGetLastError();
-}
-
-hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
-                             uint32_t *final_state, uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots,
-                             hipStream_t stream) {
-    hipLaunchKernelGGL(k_rans_chain, dim3(num_slots), dim3(64), 0, stream, d_jobs, tokens, sym_count, tabs, final_state);
-    hipLaunchKernelGGL(k_rans_emit, dim3(num_slots * 16), dim3(kThreads), 0, stream, d_jobs, tokens, sym_count, final_state,
-                       bitbuf, group_bits, preset_bits);
     return hipGetLastError();
 }
 

@@ -86,8 +86,7 @@ HYDAMD_EXPORT int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode);
  *   4   one wavefront per group, 4 groups per workgroup (default): lowest single-frame latency
  *   1   four chains per wavefront (one per 16-lane row), 16 groups per workgroup
  *   3   same, half an LF group (32 groups) per workgroup, half-size table: best when many frames are in flight
- *   2   same, a whole LF group (64 groups) per workgroup
- *   64  one lane per group, 64 chains per wavefront, followed by a parallel emit kernel */
+ *   2   same, a whole LF group (64 groups) per workgroup */
 HYDAMD_EXPORT int hydamd_set_rans_waves(HydAmdContext *ctx, int waves);
 
 /* Start a frame of `num_presets` presets (= LF groups, at most 255): clears histograms and the running alphabet. */

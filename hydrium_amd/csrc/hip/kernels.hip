@@ -10,7 +10,10 @@
  *                         (entropy.c:184-301, 943-978).
  *   k_rans_encode         one wave per group: the serial reverse rANS chain (entropy.c:1064-1159)
  *                         with wave-parallel bit emission, written back-to-front so that no
- *                         replay pass is needed.
+ *                         replay pass is needed (lowest latency of one frame).
+ *   k_rans_rows / k_rans_rows_half   the same chain, four groups per wave (one per 16-lane row):
+ *                         fewer, longer-lived workgroups that leave room for other frames'
+ *                         transform kernels (highest frame rate).
  *   k_scan_sections / k_pack_sections   byte sizes, offsets and packing of the HF sections.
  *
  * Arithmetic contract: IEEE binary32, source operation order, NO fused multiply-add — the

@@ -35,7 +35,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=240,
+                    help="frames in the timed region; with 12 in flight the last frame's 4 ms entropy-stage drain is 5 %% of 60 steps")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=8192, help="frame edge in pixels (per GPU)")
     ap.add_argument("--depth", type=int, default=16, choices=(8, 16))

@@ -123,6 +123,7 @@ def main():
         sharding.all_gather_sections(ctx.payload_tensor(), dist.group.WORLD)
         if args.lf_coder == "on":  # the coded LF streams too: the gathered frame is complete
             sharding.all_gather_sections(ctx.lf_payload_tensor(), dist.group.WORLD)
+        sharding.fence_context_stream(ctx)  # the context's next frame may not overwrite what is being gathered
 
     def step(i):
         ctx = ctxs[i % len(ctxs)]

@@ -54,6 +54,17 @@ def all_gather_sections(payload, group=None):
     return sizes, gathered.view(world, max(cap, 1))
 
 
+def fence_context_stream(ctx) -> None:
+    """Make everything queued on the context's stream from now on wait for what torch's current
+    stream holds at this point — the collectives that are still reading the context's payload
+    buffers.  (Contexts run on their own HIP streams; torch knows nothing about them.)"""
+    import torch
+
+    ev = torch.cuda.Event()
+    ev.record()
+    ev.wait(torch.cuda.ExternalStream(ctx.get_stream()))
+
+
 def concatenate(sizes: Sequence[int], gathered) -> bytes:
     """Host-side helper: the rank-ordered byte string of all sections."""
     return b"".join(bytes(gathered[r, :int(sizes[r])].cpu().numpy()) for r in range(len(sizes)))

@@ -112,8 +112,15 @@ def test_payload_tensor_and_rccl_gather_world_of_one(image):
                                 device_id=torch.device("cuda", 0))
         try:
             sizes, gathered = sharding.all_gather_sections(view)
+            lf_sizes, lf_gathered = sharding.all_gather_sections(ctx.lf_payload_tensor())
+            # the context may reuse its buffers only after the collectives have read them (bench.py exchange())
+            sharding.fence_context_stream(ctx)
+            ctx.encode_image_tensor(t)       # next frame on the same context, queued behind the fence
+            ctx.sync()
             torch.cuda.synchronize()
             assert [int(x) for x in sizes] == [len(want)]
             assert sharding.concatenate(sizes, gathered) == want
+            assert int(lf_sizes[0]) == ctx.lf_payload_size() > 0
+            assert ctx.read_payload() == want
         finally:
             dist.destroy_process_group()

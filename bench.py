@@ -120,9 +120,10 @@ def main():
     def exchange(ctx):
         """N > 1: concatenate every rank's packed sections for the frame `ctx` just coded (RCCL all-gather)."""
         ctx.sync()
-        sharding.all_gather_sections(ctx.payload_tensor(), dist.group.WORLD)
-        if args.lf_coder == "on":  # the coded LF streams too: the gathered frame is complete
-            sharding.all_gather_sections(ctx.lf_payload_tensor(), dist.group.WORLD)
+        mine = ctx.payload_tensor()
+        if args.lf_coder == "on":  # the coded LF streams travel with the HF sections: the gathered frame is complete
+            mine = torch.cat([mine, ctx.lf_payload_tensor()])
+        sharding.all_gather_sections(mine, dist.group.WORLD)
         sharding.fence_context_stream(ctx)  # the context's next frame may not overwrite what is being gathered
 
     def step(i):

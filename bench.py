@@ -47,6 +47,8 @@ def parse():
                          "per workgroup (throughput); 4 = one wave per group (lowest single-frame latency)")
     ap.add_argument("--lf-coder", default="on", choices=("on", "off"),
                     help="code the LF coefficient streams on the GPU inside the timed loop (default) or leave them out")
+    ap.add_argument("--exchange", action="store_true",
+                    help="run the multi-GPU exchange path (process group, all-gather per frame) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
     return ap.parse_args()
@@ -94,10 +96,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1 or args.exchange  # --exchange: the N > 1 code path in a world of one (self-test on one GPU)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP extension has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
+    if use_dist:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)  # only missing when --exchange is used without torchrun
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from hydrium_amd import api, device, sharding, synth
 
@@ -128,10 +133,10 @@ def main():
 
     def step(i):
         ctx = ctxs[i % len(ctxs)]
-        if world > 1 and len(pending) == len(ctxs):
+        if use_dist and len(pending) == len(ctxs):
             exchange(pending.pop(0))  # the oldest frame in flight; its context is the one reused now
         ctx.encode_image_tensor(img)
-        if world > 1:
+        if use_dist:
             pending.append(ctx)
         return ctx
 
@@ -151,7 +156,7 @@ def main():
     for c in ctxs:
         c.sync()
         c.profile(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -161,10 +166,10 @@ def main():
     for c in ctxs:
         c.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -259,7 +264,7 @@ def main():
                        "lf_coder": "gpu, in-stream" if args.lf_coder == "on" else "off",
                        "groups": lfg * 64 if W % 2048 == 0 and H % 2048 == 0 else None, "lf_groups": lfg,
                        "streams": len(ctxs), "rans_groups_per_workgroup": args.rans_waves, "parallelism": f"{world} x (one frame per GPU)" +
-                                                            (", RCCL all-gather of HF sections and LF streams" if world > 1 else "")},
+                                                            (", RCCL all-gather of HF sections and LF streams" if use_dist else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_in, "avg_launch_ms": round(dom_ms, 4)},
@@ -299,7 +304,7 @@ def main():
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -122,14 +122,29 @@ def main():
 
     pending = []  # contexts whose frame is queued but whose sections have not been exchanged yet
 
+    xt = [0.0, 0.0]  # host seconds spent waiting for the frame / issuing the exchange
+    xstate = {"seen": 0, "cap": 0}
+    xbuf = {}
+
     def exchange(ctx):
         """N > 1: concatenate every rank's packed sections for the frame `ctx` just coded (RCCL all-gather)."""
+        t_a = time.perf_counter()
         ctx.sync()
+        t_b = time.perf_counter()
+        xt[0] += t_b - t_a
         mine = ctx.payload_tensor()
         if args.lf_coder == "on":  # the coded LF streams travel with the HF sections: the gathered frame is complete
             mine = torch.cat([mine, ctx.lf_payload_tensor()])
-        sharding.all_gather_sections(mine, dist.group.WORLD)
+        # the first exchanges size the collective exactly (one host sync each); every rank sees every
+        # size, so all of them agree on the same bound for the rest of the run
+        exact = xstate["seen"] < len(ctxs)
+        sizes, _ = sharding.all_gather_sections(mine, dist.group.WORLD, None if exact else xstate["cap"],
+                                                xbuf.setdefault(id(ctx), {}))
+        if exact:
+            xstate["seen"] += 1
+            xstate["cap"] = max(xstate["cap"], int(int(sizes.max().item()) * 1.25) + 4096)
         sharding.fence_context_stream(ctx)  # the context's next frame may not overwrite what is being gathered
+        xt[1] += time.perf_counter() - t_b
 
     def step(i):
         ctx = ctxs[i % len(ctxs)]
@@ -270,6 +285,9 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_in, "avg_launch_ms": round(dom_ms, 4)},
             "kernels": kernels,
             "kernels_note": "per-launch durations in the timed region, where the streams' kernels overlap each other",
+            "exchange_host_ms_per_step": ({"wait_for_frame": round(xt[0] / args.steps * 1e3, 4),
+                                           "issue_collectives": round(xt[1] / args.steps * 1e3, 4),
+                                           "note": "includes warm-up steps' share"} if use_dist else None),
             "single_frame": lat,
             "hf_sections_only": hf_only,
             "symbols_per_pixel": round(symbols / (W * H), 4),

@@ -20,6 +20,8 @@ GROUPS_PER_LFG = 64
 K_NAMES = ("transform_tokenize", "build_tables", "rans_encode", "pack_sections", "lf_coder")
 LF_INFO_DTYPE = np.dtype([("bit_count", "<u4"), ("alphabet", "<u4"), ("run_pairs", "<u4"), ("error", "<u4"),
                           ("offset", "<u4"), ("reserved", "<u4", (3,)), ("lengths", "u1", (384,))])
+BITWORDS_PER_GROUP = (196608 * 46 + 64 + 31) // 32 + 1  # csrc/hip/hydk_common.h HYDK_BITWORDS_PER_GROUP
+LF_BITWORDS = 3 * 256 * 256 * 2 + 2                     # HYDK_LF_BITWORDS
 LF_CODES = 384  # compact token space of the LF-coefficient stream (include/hydrium_amd.h HYDAMD_LF_CODES)
 
 FMT_OF_DTYPE = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.float32): 2}
@@ -236,17 +238,24 @@ class DeviceContext:
     def payload_device_ptr(self) -> int:
         return self.d.hydamd_payload_device(self.h) or 0
 
-    def payload_tensor(self):
-        """Zero-copy torch uint8 view of the packed HF sections in HBM (valid until the next frame)."""
+    def _device_view(self, key: str, ptr: int, capacity: int):
+        """uint8 CUDA tensor aliasing `capacity` bytes at `ptr`, made once per buffer: wrapping a raw
+        pointer costs torch a pointer-attribute query (~0.5 ms), slicing the cached view nothing."""
         import torch
 
-        n = self.payload_size()
-        ptr = self.payload_device_ptr()
+        cache = self.__dict__.setdefault("_views", {})
+        hit = cache.get(key)
+        if hit is None or hit[0] != ptr:
+            class _View:
+                __cuda_array_interface__ = {"shape": (capacity,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
-        class _View:
-            __cuda_array_interface__ = {"shape": (max(n, 1),), "typestr": "|u1", "data": (ptr, False), "version": 2}
+            hit = cache[key] = (ptr, torch.as_tensor(_View(), device="cuda"))
+        return hit[1]
 
-        return torch.as_tensor(_View(), device="cuda")[:n]
+    def payload_tensor(self):
+        """Zero-copy torch uint8 view of the packed HF sections in HBM (valid until the next frame)."""
+        cap = self.max_lf_groups * GROUPS_PER_LFG * BITWORDS_PER_GROUP * 4
+        return self._device_view("payload", self.payload_device_ptr(), cap)[: self.payload_size()]
 
     def read_payload(self) -> bytes:
         n = self.payload_size()
@@ -335,13 +344,8 @@ class DeviceContext:
         """The frame's packed LF symbol data as a CUDA uint8 tensor aliasing the context's buffer (valid after sync)."""
         import torch
 
-        n = self.lf_payload_size()
-        ptr = int(self.d.hydamd_lf_payload_device(self.h) or 0)
-
-        class _View:
-            __cuda_array_interface__ = {"shape": (max(n, 1),), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-        return torch.as_tensor(_View(), device="cuda")[:n]
+        cap = self.max_lf_groups * LF_BITWORDS * 4
+        return self._device_view("lf", int(self.d.hydamd_lf_payload_device(self.h) or 0), cap)[: self.lf_payload_size()]
 
     def debug_lf_code(self, hist: np.ndarray):
         """Device code construction for one histogram over the compact token space -> (lengths, codes, alphabet, error)."""

@@ -33,25 +33,51 @@ def partition_lf_groups(num_lf_groups: int, world: int) -> List[range]:
     return out
 
 
-def all_gather_sections(payload, group=None):
+def all_gather_sections(payload, group=None, capacity=None, buffers=None):
     """Concatenate every rank's packed sections.
 
     `payload` is this rank's 1-D uint8 tensor (any length).  Returns (sizes, gathered) where
     `sizes[r]` is rank r's byte count and `gathered[r, :sizes[r]]` its bytes, on every rank.
+
+    The collective needs one common per-rank capacity.  By default it is the largest payload, which
+    costs a host synchronisation (the sizes have to come back before the second collective can be
+    shaped).  A caller that streams many frames of similar size passes `capacity` — a bound every
+    rank agrees on, e.g. 1.25 x the largest size of the first frames, which all ranks know from the
+    `sizes` they were returned — and the call stays asynchronous; `buffers` (a dict the caller
+    keeps) lets it reuse its staging tensors instead of allocating per frame.
     """
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    n = torch.tensor([payload.numel()], dtype=torch.int64, device=payload.device)
-    sizes = torch.empty(world, dtype=torch.int64, device=payload.device)
+    dev = payload.device
+    if capacity is not None:
+        # agreed capacity: ONE collective per frame, each rank's byte count rides in front of its bytes
+        cap = (max(int(capacity), 1) + 7) & ~7  # rows stay 8-byte aligned for the int64 size header
+        if payload.numel() > cap:
+            raise ValueError(f"payload of {payload.numel()} bytes exceeds the agreed capacity {cap}")
+        pitch = 8 + cap
+        if buffers is not None and buffers.get("pitch") == pitch and buffers["mine"].device == dev:
+            mine, gathered = buffers["mine"], buffers["gathered"]
+        else:
+            mine = torch.zeros(pitch, dtype=torch.uint8, device=dev)
+            gathered = torch.empty(world * pitch, dtype=torch.uint8, device=dev)
+            if buffers is not None:
+                buffers.update(pitch=pitch, mine=mine, gathered=gathered)
+        mine[:8].view(torch.int64).fill_(payload.numel())
+        mine[8:8 + payload.numel()] = payload  # bytes past the payload are whatever an earlier frame left
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+        rows = gathered.view(world, pitch)
+        return rows[:, :8].clone().view(torch.int64).view(world), rows[:, 8:]
+    n = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
+    sizes = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(sizes, n, group=group)
-    cap = int(sizes.max().item())
-    mine = torch.zeros(max(cap, 1), dtype=torch.uint8, device=payload.device)
+    cap = max(int(sizes.max().item()), 1)
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
     mine[:payload.numel()] = payload
-    gathered = torch.empty(world * max(cap, 1), dtype=torch.uint8, device=payload.device)
+    gathered = torch.empty(world * cap, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(gathered, mine, group=group)
-    return sizes, gathered.view(world, max(cap, 1))
+    return sizes, gathered.view(world, cap)
 
 
 def fence_context_stream(ctx) -> None:
@@ -60,9 +86,12 @@ def fence_context_stream(ctx) -> None:
     buffers.  (Contexts run on their own HIP streams; torch knows nothing about them.)"""
     import torch
 
+    ext = getattr(ctx, "_torch_stream", None)
+    if ext is None or ext.cuda_stream != ctx.get_stream():
+        ext = ctx._torch_stream = torch.cuda.ExternalStream(ctx.get_stream())
     ev = torch.cuda.Event()
     ev.record()
-    ev.wait(torch.cuda.ExternalStream(ctx.get_stream()))
+    ev.wait(ext)
 
 
 def concatenate(sizes: Sequence[int], gathered) -> bytes:

@@ -58,7 +58,16 @@ def _worker(rank, world, port, q):
                 chunks.append(res.stream)
         payload = torch.from_numpy(np.frombuffer(b"".join(chunks), np.uint8).copy())
         sizes, gathered = sharding.all_gather_sections(payload)
-        q.put((rank, [int(x) for x in sizes], sharding.concatenate(sizes, gathered)))
+        exact = sharding.concatenate(sizes, gathered)
+        # the streaming variant: a capacity every rank derives from the sizes it was just told, one
+        # collective per call, staging buffers reused
+        cap = int(int(sizes.max()) * 1.25) + 4096
+        bufs = {}
+        for _ in range(2):
+            s2, g2 = sharding.all_gather_sections(payload, capacity=cap, buffers=bufs)
+            assert [int(x) for x in s2] == [int(x) for x in sizes]
+            assert sharding.concatenate(s2, g2) == exact
+        q.put((rank, [int(x) for x in sizes], exact))
     finally:
         dist.destroy_process_group()
 

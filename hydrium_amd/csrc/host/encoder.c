@@ -401,26 +401,39 @@ static void drain(HYDEncoder *e) {
  *
  * Creating a context allocates its worst-case buffers (245 MB per LF-group slot) and pinned
  * staging, and destroying it gives them back: about 10 ms per image together, a third of what
- * hyd_send_tile costs for an 8192 x 8192 frame.  One idle context is therefore parked when an
- * encoder is destroyed and handed to the next encoder that needs the same shape.  Contexts that
- * saw a device error, or that are larger than 64 slots (15.7 GB), are not parked;
- * HYDAMD_CONTEXT_CACHE=0 turns the parking off.
+ * hyd_send_tile costs for an 8192 x 8192 frame.  Idle contexts are therefore parked when their
+ * encoder is destroyed and handed to the next encoder that needs the same shape (a few of them, so
+ * that several threads encoding images back to back each find one).  Contexts that saw a device
+ * error, or that are larger than 64 slots (15.7 GB), are not parked; HYDAMD_CONTEXT_CACHE=0 turns
+ * the parking off.
  * ------------------------------------------------------------------------------------------- */
+#define CTX_POOL_MAX 8
+typedef struct ParkedCtx {
+    HydAmdContext *ctx;
+    size_t slots;
+    int linear;
+    unsigned long stamp; /* larger = parked more recently */
+} ParkedCtx;
 static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
-static HydAmdContext *g_ctx;
-static size_t g_ctx_slots;
-static int g_ctx_linear;
+static ParkedCtx g_pool[CTX_POOL_MAX];
+static unsigned long g_stamp;
 
-static int ctx_cache_on(void) {
-    static int on = -1;
-    if (on < 0) {
+/* HYDAMD_CONTEXT_CACHE: how many idle contexts may stay parked (default 4, 0 = none): one per
+ * thread that encodes images back to back is what a batch job wants */
+static int ctx_pool_size(void) {
+    static int n = -1;
+    if (n < 0) {
         const char *v = getenv("HYDAMD_CONTEXT_CACHE");
-        on = !(v && *v == '0');
+        n = v && *v ? atoi(v) : 4;
+        if (n < 0)
+            n = 0;
+        if (n > CTX_POOL_MAX)
+            n = CTX_POOL_MAX;
     }
-    return on;
+    return n;
 }
 
-/* HYDAMD_EAGER=0: code the whole frame when its final tile arrives instead of tile by tile (A/B) */
+/* HYDAMD_EAGER=0: run the transform kernels when the frame's final tile arrives instead of tile by tile (A/B) */
 static int eager_on(void) {
     static int on = -1;
     if (on < 0) {
@@ -433,10 +446,11 @@ static int eager_on(void) {
 static HydAmdContext *ctx_acquire(size_t slots, int linear, int *status) {
     HydAmdContext *c = NULL;
     pthread_mutex_lock(&g_ctx_lock);
-    if (g_ctx && g_ctx_slots == slots && g_ctx_linear == linear) {
-        c = g_ctx;
-        g_ctx = NULL;
-    }
+    for (int i = 0; i < CTX_POOL_MAX && !c; i++)
+        if (g_pool[i].ctx && g_pool[i].slots == slots && g_pool[i].linear == linear) {
+            c = g_pool[i].ctx;
+            g_pool[i].ctx = NULL;
+        }
     pthread_mutex_unlock(&g_ctx_lock);
     if (c) {
         *status = HYD_OK;
@@ -446,14 +460,23 @@ static HydAmdContext *ctx_acquire(size_t slots, int linear, int *status) {
 }
 
 static void ctx_release(HydAmdContext *c, size_t slots, int linear, int healthy) {
-    if (healthy && ctx_cache_on() && slots <= 64 && hydamd_sync(c) == HYD_OK) {
+    const int cap = ctx_pool_size();
+    if (healthy && cap > 0 && slots <= 64 && hydamd_sync(c) == HYD_OK) {
         pthread_mutex_lock(&g_ctx_lock);
-        HydAmdContext *old = g_ctx; /* keep the most recent shape */
-        g_ctx = c;
-        g_ctx_slots = slots;
-        g_ctx_linear = linear;
+        int where = -1;
+        for (int i = 0; i < cap && where < 0; i++)
+            if (!g_pool[i].ctx)
+                where = i;
+        if (where < 0) { /* full: the context parked longest ago makes room */
+            where = 0;
+            for (int i = 1; i < cap; i++)
+                if (g_pool[i].stamp < g_pool[where].stamp)
+                    where = i;
+        }
+        HydAmdContext *evicted = g_pool[where].ctx;
+        g_pool[where] = (ParkedCtx){c, slots, linear, ++g_stamp};
         pthread_mutex_unlock(&g_ctx_lock);
-        c = old;
+        c = evicted;
     }
     if (c)
         hydamd_destroy(c);

@@ -131,6 +131,8 @@ struct HydAmdContext {
     hipEvent_t lf_fork = nullptr, lf_join = nullptr;
     bool lf_pending = false;               /* the side stream holds work the main stream has not waited for */
     bool lf_need_gather = false;           /* LF groups were coded since the frame's LF streams were last packed */
+    bool lf_results_valid = false;         /* hydamd_sync_lf (or hydamd_sync) has seen the packed LF streams complete */
+    hipEvent_t lf_ready = nullptr;         /* recorded behind the LF gather kernel and the copy of its byte count */
     int lf_slots = 0;                      /* slots covered by the last LF coder run */
     int transformed = 0, coded = 0, lf_coded = 0; /* slots of the current frame whose transform / entropy / LF kernels are enqueued */
     float *dbg_xyb = nullptr, *dbg_dct = nullptr;
@@ -423,6 +425,8 @@ void hydamd_destroy(HydAmdContext *ctx) {
         (void)hipEventDestroy(ctx->lf_fork);
     if (ctx->lf_join)
         (void)hipEventDestroy(ctx->lf_join);
+    if (ctx->lf_ready)
+        (void)hipEventDestroy(ctx->lf_ready);
     if (ctx->h_lf_total_pinned)
         (void)hipHostFree(ctx->h_lf_total_pinned);
     void *lfdev[] = {ctx->lf_recs, ctx->lf_hist, ctx->lf_codes, ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total};
@@ -487,6 +491,7 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->frame_fence, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_fork, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_join, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_ready, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) {
         HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_jobs_ring[i], slots * sizeof(HydkLfJob), hipHostMallocDefault));
         memset(ctx->h_jobs_ring[i], 0, slots * sizeof(HydkLfJob));
@@ -660,6 +665,8 @@ int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
     ctx->slots_finished = 0;
     ctx->transformed = ctx->coded = ctx->lf_coded = 0;
     ctx->lf_need_gather = false;
+    ctx->lf_results_valid = false;
+    ctx->lf_slots = 0;
     /* this frame's uploads may overwrite the staging arena only after everything queued so far has read it */
     HIP_TRY(ctx, hipEventRecord(ctx->frame_fence, ctx->stream));
     ctx->copy_needs_fence = true;
@@ -745,8 +752,7 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
 /* The LF coder's token and code kernels for slots [first, first + count), whose transform kernels
  * are already enqueued.  It needs only the LF ints they write: forked onto its own stream so that it
  * overlaps the HF entropy stage; join_lf brings the streams back together. */
-static int lf_range(HydAmdContext *ctx, int first, int count) {
-    const bool forked = ctx->lf_on_device == 1;
+static int lf_range(HydAmdContext *ctx, int first, int count, bool forked) {
     hipStream_t where = forked ? ctx->lf_stream : ctx->stream;
     if (forked) {
         HIP_TRY(ctx, hipEventRecord(ctx->lf_fork, ctx->stream));
@@ -756,7 +762,7 @@ static int lf_range(HydAmdContext *ctx, int first, int count) {
     HIP_TRY(ctx, hydk::launch_lf_coder(ctx->d_jobs + first, ctx->lf_recs + (size_t)first * HYDK_LF_SYMBOLS,
                                        ctx->lf_hist + (size_t)first * HYDK_LF_CODES, ctx->lf_streams + first,
                                        ctx->lf_bits + (size_t)first * HYDK_LF_BITWORDS, count, where));
-    ctx->lf_pending = forked;
+    ctx->lf_pending = ctx->lf_pending || forked;
     ctx->lf_need_gather = true;
     return ST_OK;
 }
@@ -775,7 +781,7 @@ int hydamd_run_transform(HydAmdContext *ctx, int num_slots) {
         ctx->transformed = num_slots;
     }
     if (ctx->lf_on_device == 1 && num_slots > ctx->lf_coded) {
-        const int st = lf_range(ctx, ctx->lf_coded, num_slots - ctx->lf_coded);
+        const int st = lf_range(ctx, ctx->lf_coded, num_slots - ctx->lf_coded, true);
         if (st != ST_OK)
             return st;
         ctx->lf_coded = num_slots;
@@ -789,19 +795,19 @@ static int join_lf(HydAmdContext *ctx, int num_slots) {
     if (num_slots > 0 && ctx->lf_on_device == 2 && num_slots > ctx->lf_coded) {
         /* in-stream mode: the whole LF coder runs here, behind the frame's packing kernels (no extra
          * stream: with many frames in flight side streams alias onto the same hardware queues) */
-        const int st = lf_range(ctx, ctx->lf_coded, num_slots - ctx->lf_coded);
+        const int st = lf_range(ctx, ctx->lf_coded, num_slots - ctx->lf_coded, false);
         if (st != ST_OK)
             return st;
         ctx->lf_coded = num_slots;
     }
     if (num_slots > 0 && ctx->lf_need_gather) {
-        hipStream_t where = ctx->lf_on_device == 1 ? ctx->lf_stream : ctx->stream;
+        hipStream_t where = ctx->lf_pending ? ctx->lf_stream : ctx->stream;
         HIP_TRY(ctx, hydk::launch_lf_gather(ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total, num_slots, where));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lf_total_pinned, ctx->lf_total, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                     where));
+        HIP_TRY(ctx, hipEventRecord(ctx->lf_ready, where));
         ctx->lf_slots = num_slots;
         ctx->lf_need_gather = false;
-        ctx->lf_pending = ctx->lf_on_device == 1;
     }
     if (ctx->lf_pending) {
         HIP_TRY(ctx, hipEventRecord(ctx->lf_join, ctx->lf_stream));
@@ -903,6 +909,36 @@ int hydamd_submit_lf_group(HydAmdContext *ctx, int slot) {
     return st;
 }
 
+int hydamd_run_lf_coder(HydAmdContext *ctx, int num_slots, int last) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (!ctx->lf_on_device)
+        return fail(ctx, ST_API_ERROR, "the LF coder is off");
+    if (num_slots < 1 || num_slots > ctx->transformed)
+        return fail(ctx, ST_API_ERROR, "the LF coder needs the transform stage of the same slots first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->results_valid = false;
+    if (num_slots > ctx->lf_coded) {
+        const int st = lf_range(ctx, ctx->lf_coded, num_slots - ctx->lf_coded, false);
+        if (st != ST_OK)
+            return st;
+        ctx->lf_coded = num_slots;
+    }
+    return last ? join_lf(ctx, num_slots) : ST_OK;
+}
+
+int hydamd_sync_lf(HydAmdContext *ctx) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (!ctx->lf_on_device || ctx->lf_need_gather || ctx->lf_slots == 0)
+        return fail(ctx, ST_API_ERROR, "no finished LF coder run to wait for");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->lf_ready));
+    ctx->h_lf_total = *ctx->h_lf_total_pinned;
+    ctx->lf_results_valid = true;
+    return ST_OK;
+}
+
 int hydamd_finish_frame(HydAmdContext *ctx, int num_slots) {
     int st = hydamd_run_transform(ctx, num_slots);
     if (st != ST_OK)
@@ -923,6 +959,7 @@ int hydamd_sync(HydAmdContext *ctx) {
     drain_timers(ctx);
     ctx->h_total = *ctx->h_total_pinned;
     ctx->h_lf_total = *ctx->h_lf_total_pinned;
+    ctx->lf_results_valid = ctx->lf_on_device && !ctx->lf_need_gather && ctx->lf_slots > 0;
     ctx->h_status = *ctx->h_status_pinned;
     if (ctx->h_status & 1u)
         return fail(ctx, ST_API_ERROR, "Invalid NaN Float");
@@ -1008,7 +1045,7 @@ int hydamd_read_lf_stream(HydAmdContext *ctx, int slot, uint8_t lengths[HYDAMD_L
     int st = check_slot(ctx, slot);
     if (st != ST_OK)
         return st;
-    if (!ctx->lf_on_device || !ctx->results_valid)
+    if (!ctx->lf_on_device || !ctx->lf_results_valid)
         return fail(ctx, ST_API_ERROR, "no device-coded LF stream: the LF coder is off or the frame was not synchronised");
     HydkLfStream h;
     HIP_TRY(ctx, hipMemcpy(&h, ctx->lf_streams + slot, sizeof(h), hipMemcpyDeviceToHost));
@@ -1028,7 +1065,7 @@ int hydamd_read_lf_bits(HydAmdContext *ctx, int slot, uint8_t *dst, size_t capac
     int st = check_slot(ctx, slot);
     if (st != ST_OK)
         return st;
-    if (!ctx->lf_on_device || !ctx->results_valid)
+    if (!ctx->lf_on_device || !ctx->lf_results_valid)
         return fail(ctx, ST_API_ERROR, "no device-coded LF stream: the LF coder is off or the frame was not synchronised");
     if (capacity > (size_t)HYDK_LF_BITWORDS * sizeof(uint32_t))
         return fail(ctx, ST_API_ERROR, "LF bit request too large");
@@ -1038,13 +1075,13 @@ int hydamd_read_lf_bits(HydAmdContext *ctx, int slot, uint8_t *dst, size_t capac
 }
 
 size_t hydamd_lf_payload_size(HydAmdContext *ctx) {
-    return ctx && ctx->results_valid && ctx->lf_on_device ? (size_t)ctx->h_lf_total : 0;
+    return ctx && ctx->lf_results_valid && ctx->lf_on_device ? (size_t)ctx->h_lf_total : 0;
 }
 
 const uint8_t *hydamd_lf_payload_device(HydAmdContext *ctx) { return ctx ? (const uint8_t *)ctx->lf_packed : nullptr; }
 
 int hydamd_read_lf_payload(HydAmdContext *ctx, uint8_t *dst, size_t capacity) {
-    if (!ctx || !ctx->lf_on_device || !ctx->results_valid)
+    if (!ctx || !ctx->lf_on_device || !ctx->lf_results_valid)
         return fail(ctx, ST_API_ERROR, "no device-coded LF stream: the LF coder is off or the frame was not synchronised");
     if (capacity < ctx->h_lf_total)
         return fail(ctx, ST_API_ERROR, "LF payload buffer too small");
@@ -1054,7 +1091,7 @@ int hydamd_read_lf_payload(HydAmdContext *ctx, uint8_t *dst, size_t capacity) {
 }
 
 int hydamd_read_lf_streams(HydAmdContext *ctx, int first_slot, int count, HydAmdLfInfo *dst) {
-    if (!ctx || !ctx->lf_on_device || !ctx->results_valid)
+    if (!ctx || !ctx->lf_on_device || !ctx->lf_results_valid)
         return fail(ctx, ST_API_ERROR, "no device-coded LF stream: the LF coder is off or the frame was not synchronised");
     if (first_slot < 0 || count < 1 || first_slot + count > ctx->lf_slots)
         return fail(ctx, ST_API_ERROR, "LF-group slot range out of bounds");

@@ -231,7 +231,7 @@ static int device_fail(HYDEncoder *e, int code);
 /* payload == NULL: the packed HF sections are still on the device (e->dev) and are copied straight
  * into the output stream */
 static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgResult *res, unsigned max_alphabet,
-                          const uint8_t *payload, size_t payload_len) {
+                          const uint8_t *payload, size_t payload_len, HydBits *lf_prebuilt) {
     uint8_t *fetched = NULL;
     const size_t fg = ((shape->frame_width + 255) >> 8) * ((shape->frame_height + 255) >> 8);
     const int multi = fg > 1;
@@ -260,7 +260,12 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
     double t0 = now_ms();
     hyd_write_lf_global(&body);
     CLOSE_SECTION();
-    if (multi && shape->lfg_count > 1) {
+    if (multi && lf_prebuilt) { /* coded while the GPU was still busy with the entropy stage (finish_frame) */
+        for (size_t s = 0; s < shape->lfg_count; s++) {
+            hb_append_bytes(&body, lf_prebuilt[s].data, lf_prebuilt[s].len);
+            CLOSE_SECTION();
+        }
+    } else if (multi && shape->lfg_count > 1) {
         HydBits *lf = calloc(shape->lfg_count, sizeof(HydBits));
         if (!lf) {
             ret = FAIL(e, HYD_NOMEM, "out of memory");
@@ -597,38 +602,53 @@ static int device_fail(HYDEncoder *e, int code) {
 /* read back everything the frame assembler needs and write the frame */
 static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
     const size_t n = shape->lfg_count;
+    const size_t fg = ((shape->frame_width + 255) >> 8) * ((shape->frame_height + 255) >> 8);
+    const int lf_on_gpu = hydamd_lf_coder(e->dev);
+    /* With more than one group the LF groups are byte-aligned sections of their own: the LF coder is
+     * then put in front of the entropy stage, so that its streams can be read back and wrapped
+     * into sections on the host while the (2 ms, latency-bound) entropy stage is still running. */
+    const int early_lf = lf_on_gpu && fg > 1;
     double t0 = now_ms();
-    int ret = hydamd_finish_frame(e->dev, (int)n);
+    int ret = 0;
+    if (early_lf)
+        ret = hydamd_run_lf_coder(e->dev, (int)n, 1);
     if (!ret)
-        ret = hydamd_sync(e->dev);
+        ret = hydamd_finish_frame(e->dev, (int)n);
     if (ret)
         return device_fail(e, ret);
-    TRACE("GPU hot path (finish+sync)", t0);
-    t0 = now_ms();
     LfgResult *res = calloc(n, sizeof(LfgResult));
-    if (!res)
-        return FAIL(e, HYD_NOMEM, "out of memory");
-    unsigned max_alphabet = 0;
-    const size_t payload_len = hydamd_payload_size(e->dev);
+    HydBits *lf_sections = NULL;
     HydAmdLfInfo *lf_info = NULL;
     uint8_t *lf_blob = NULL;
     size_t lf_len = 0;
-    if (hydamd_lf_coder(e->dev)) { /* two copies bring every LF group's coded coefficient stream */
+    unsigned max_alphabet = 0;
+    size_t payload_len = 0;
+    if (!res)
+        return FAIL(e, HYD_NOMEM, "out of memory");
+    if (early_lf) {
+        ret = hydamd_sync_lf(e->dev);
+        TRACE("LF coder done", t0);
+    } else {
+        ret = hydamd_sync(e->dev);
+        TRACE("GPU hot path (finish+sync)", t0);
+    }
+    if (ret) {
+        ret = device_fail(e, ret);
+        goto done;
+    }
+    t0 = now_ms();
+    if (lf_on_gpu) { /* two copies bring every LF group's coded coefficient stream */
         lf_len = hydamd_lf_payload_size(e->dev);
         lf_info = malloc(n * sizeof(HydAmdLfInfo));
         lf_blob = malloc(lf_len ? lf_len : 1);
         if (!lf_info || !lf_blob) {
-            ret = HYD_NOMEM;
-        } else {
-            ret = hydamd_read_lf_streams(e->dev, 0, (int)n, lf_info);
-            if (!ret)
-                ret = hydamd_read_lf_payload(e->dev, lf_blob, lf_len);
+            ret = FAIL(e, HYD_NOMEM, "out of memory");
+            goto done;
         }
-    }
-    for (size_t s = 0; s < n && !ret; s++) {
-        const size_t vbw = (shape->lfg[s].width + 7) >> 3, vbh = (shape->lfg[s].height + 7) >> 3;
-        uint32_t log_alpha = 0, running = 0;
-        if (lf_info) { /* the LF coefficients were coded on the GPU: records and symbol data are already here */
+        ret = hydamd_read_lf_streams(e->dev, 0, (int)n, lf_info);
+        if (!ret)
+            ret = hydamd_read_lf_payload(e->dev, lf_blob, lf_len);
+        for (size_t s = 0; s < n && !ret; s++) {
             if ((size_t)lf_info[s].offset + (((size_t)lf_info[s].bit_count + 7) >> 3) > lf_len) {
                 ret = HYD_INTERNAL_ERROR;
                 break;
@@ -638,7 +658,36 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
             res[s].lf_run_pairs = lf_info[s].run_pairs;
             res[s].lf_bit_count = lf_info[s].bit_count;
             res[s].lf_bits = lf_blob + lf_info[s].offset; /* borrowed from lf_blob */
-        } else {
+        }
+        if (ret) {
+            ret = device_fail(e, ret);
+            goto done;
+        }
+    }
+    if (early_lf) {
+        lf_sections = calloc(n, sizeof(HydBits));
+        if (!lf_sections) {
+            ret = FAIL(e, HYD_NOMEM, "out of memory");
+            goto done;
+        }
+        ret = code_lf_groups_parallel(e, shape, res, lf_sections);
+        TRACE("LF group sections (beside the entropy stage)", t0);
+        if (ret)
+            goto done;
+        t0 = now_ms();
+        ret = hydamd_sync(e->dev);
+        TRACE("entropy stage done", t0);
+        if (ret) {
+            ret = device_fail(e, ret);
+            goto done;
+        }
+        t0 = now_ms();
+    }
+    payload_len = hydamd_payload_size(e->dev);
+    for (size_t s = 0; s < n && !ret; s++) {
+        const size_t vbw = (shape->lfg[s].width + 7) >> 3, vbh = (shape->lfg[s].height + 7) >> 3;
+        uint32_t log_alpha = 0, running = 0;
+        if (!lf_on_gpu) {
             res[s].dc = malloc(3 * vbw * vbh * sizeof(int32_t));
             if (!res[s].dc) {
                 ret = HYD_NOMEM;
@@ -659,11 +708,15 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
     }
     TRACE("read back results", t0);
     t0 = now_ms();
-    ret = assemble_frame(e, shape, res, max_alphabet, NULL, payload_len);
+    ret = assemble_frame(e, shape, res, max_alphabet, NULL, payload_len, lf_sections);
     TRACE("assemble frame (host)", t0);
 done:
-    for (size_t s = 0; s < n; s++)
+    for (size_t s = 0; s < n; s++) {
         free(res[s].dc);
+        if (lf_sections)
+            hb_free(&lf_sections[s]);
+    }
+    free(lf_sections);
     free(res);
     free(lf_info);
     free(lf_blob);
@@ -724,8 +777,13 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
     const double tu = now_ms();
     ret = hydamd_encode_lf_group_host(e->dev, (int)slot, buffer, row_stride, pixel_stride, (int)sample_fmt, tw, th,
                                       (unsigned)l->raster_id);
-    if (!ret && eager_on()) /* code this LF group while the caller prepares / we stage the next tile */
+    if (!ret && eager_on()) { /* work on this LF group while the caller prepares / we stage the next tile */
         ret = hydamd_submit_lf_group(e->dev, (int)slot);
+        /* and every fourth tile the LF coder for the four just transformed: a launch of it takes
+         * 0.6 ms whether it codes one LF group or sixteen, four tiles take 2 ms to stage */
+        if (!ret && e->one_frame && (slot & 3) == 3 && hydamd_lf_coder(e->dev))
+            ret = hydamd_run_lf_coder(e->dev, (int)slot + 1, 0);
+    }
     if (ret)
         return device_fail(e, ret);
     TRACE("stage + upload tile", tu);
@@ -909,7 +967,7 @@ static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is
         shape.lfg_count = lfg_count;
         shape.lfg = e->sent;
         shape.is_last = is_last;
-        ret = assemble_frame(e, &shape, res, max_alphabet, payload, payload_len);
+        ret = assemble_frame(e, &shape, res, max_alphabet, payload, payload_len, NULL);
     }
     if (!ret) {
         *out = malloc(e->stream.len ? e->stream.len : 1);

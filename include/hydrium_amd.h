@@ -114,6 +114,14 @@ HYDAMD_EXPORT int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, cons
  * left (the entropy stage and the LF coder, batched over the frame) and packs. */
 HYDAMD_EXPORT int hydamd_submit_lf_group(HydAmdContext *ctx, int slot);
 
+/* Optional: enqueue the LF coder for the slots not yet LF-coded below `num_slots` right here in the
+ * context's stream (their transform stage must be enqueued); with `last` != 0 the frame's LF streams
+ * are also packed, and hydamd_sync_lf() then waits for just that — so a caller can read the LF streams
+ * (hydamd_read_lf_streams / hydamd_read_lf_payload) and build the LF sections on the host while
+ * the entropy stage enqueued behind it is still running.  hyd_send_tile does. */
+HYDAMD_EXPORT int hydamd_run_lf_coder(HydAmdContext *ctx, int num_slots, int last);
+HYDAMD_EXPORT int hydamd_sync_lf(HydAmdContext *ctx);
+
 /* Enqueue section sizing + packing for slots [0, num_slots): byte-padded HF sections, slot-major, raster inside a slot. */
 HYDAMD_EXPORT int hydamd_finish_frame(HydAmdContext *ctx, int num_slots);
 

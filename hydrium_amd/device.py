@@ -92,6 +92,9 @@ def dll(path: Optional[str] = None):
         d.hydamd_read_symbol_counts.argtypes = [vp, i, vp]
         d.hydamd_read_tokens.argtypes = [vp, i, i, vp, sz]
         d.hydamd_read_debug_plane.argtypes = [vp, i, vp, sz, sz]
+        d.hydamd_submit_lf_group.argtypes = [vp, i]
+        d.hydamd_run_lf_coder.argtypes = [vp, i, i]
+        d.hydamd_sync_lf.argtypes = [vp]
         d.hydamd_set_lf_coder.argtypes = [vp, i]
         d.hydamd_lf_coder.argtypes = [vp]
         d.hydamd_read_lf_stream.argtypes = [vp, i, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -304,6 +307,18 @@ class DeviceContext:
         n = (C.c_uint64 * len(K_NAMES))()
         self._ck(self.d.hydamd_profile_read(self.h, ms, n))
         return {K_NAMES[i]: (ms[i], n[i]) for i in range(len(K_NAMES))}
+
+    def submit_lf_group(self, slot: int):
+        """Enqueue the transform stage of the LF group in `slot` now (slots in order) instead of at finish_frame."""
+        self._ck(self.d.hydamd_submit_lf_group(self.h, slot))
+
+    def run_lf_coder(self, num_slots: int, last: bool):
+        """Enqueue the LF coder for the transformed slots below `num_slots` in the context's stream;
+        `last` also packs the frame's LF streams so that sync_lf() can wait for just them."""
+        self._ck(self.d.hydamd_run_lf_coder(self.h, num_slots, int(last)))
+
+    def sync_lf(self):
+        self._ck(self.d.hydamd_sync_lf(self.h))
 
     # ---- LF-group coder (csrc/hip/lf_coder.hip) ----
     def set_lf_coder(self, on_device):

@@ -169,3 +169,36 @@ def test_packed_lf_payload_matches_per_slot_reads():
             np.testing.assert_array_equal(blob[off:off + nbytes], c.read_lf_bits(s, nbits))
             end = off + (nbits + 31) // 32 * 4
         assert end == len(blob)
+
+
+def test_early_lf_streams_equal_the_batched_ones():
+    """hyd_send_tile's schedule at the device level: transform stages tile by tile, the LF coder in
+    two instalments in front of the entropy stage, its streams read after sync_lf() while the entropy
+    stage is still queued — same LF streams and same HF sections as the one-shot finish_frame."""
+    import torch
+
+    img = synth.make_image("photo", 2048 + 520, 2048 + 264, 16, seed=21)   # 2 x 2 LF groups
+    t = torch.from_numpy(img.view(np.int16)).cuda()
+    with dev.DeviceContext(0, 4) as c:
+        c.encode_image_tensor(t)
+        c.sync()
+        want_info, want_blob, want_payload = c.read_lf_streams(4), c.read_lf_payload(), c.read_payload()
+
+        h, w, _ = img.shape
+        c.begin_frame(4)
+        for slot in range(4):
+            x0, y0 = (slot % 2) * 2048, (slot // 2) * 2048
+            p = t.data_ptr() + (y0 * w + x0) * 3 * 2
+            c.encode_lf_group(slot, [p, p + 2, p + 4], 3 * w, 3, 1, min(2048, w - x0), min(2048, h - y0), slot)
+            c.submit_lf_group(slot)
+            if slot == 1:
+                c.run_lf_coder(2, False)
+        c.run_lf_coder(4, True)
+        c.finish_frame(4)
+        c.sync_lf()
+        info, blob = c.read_lf_streams(4), c.read_lf_payload()
+        c.sync()
+        assert c.read_payload() == want_payload
+    for k in ("bit_count", "alphabet", "run_pairs", "offset", "lengths"):
+        np.testing.assert_array_equal(info[k], want_info[k])
+    np.testing.assert_array_equal(blob, want_blob)

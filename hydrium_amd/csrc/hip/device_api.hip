@@ -20,6 +20,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -365,30 +368,94 @@ int stage_threads() {
     return n;
 }
 
+/* Persistent helpers for the staging gather.  A tile takes a quarter of a millisecond to copy once
+ * the rows are spread over a few cores — less than it costs to start the threads each time — so the
+ * helpers are started once and parked on a condition variable.  One gather runs at a time (a second
+ * encoder thread that finds the helpers busy copies its tile alone). */
+class StagePool {
+  public:
+    /* run fn(part) for part = 0 .. parts-1, part 0 on the calling thread; false if the pool is busy */
+    template <typename Fn>
+    bool run(int parts, Fn &&fn) {
+        std::unique_lock<std::mutex> owner(busy_, std::try_to_lock);
+        if (!owner.owns_lock())
+            return false;
+        ensure_workers(parts - 1);
+        const int helpers = parts - 1 < (int)workers_.size() ? parts - 1 : (int)workers_.size();
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = [&fn](int part) { fn(part); };
+            parts_ = helpers + 1;
+            pending_ = helpers;
+            generation_++;
+        }
+        cv_work_.notify_all();
+        fn(0);
+        for (int part = helpers + 1; part < parts; part++) /* helpers that could not be started */
+            fn(part);
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+        return true;
+    }
+
+  private:
+    void ensure_workers(int want) {
+        while ((int)workers_.size() < want) {
+            const int id = (int)workers_.size() + 1;
+            try {
+                workers_.emplace_back([this, id] { loop(id); });
+                workers_.back().detach(); /* parked for the life of the process */
+            } catch (...) {
+                break;
+            }
+        }
+    }
+    void loop(int id) {
+        unsigned seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return generation_ != seen; });
+            seen = generation_;
+            if (id < parts_) {
+                auto job = job_;
+                lk.unlock();
+                job(id);
+                lk.lock();
+                if (--pending_ == 0)
+                    cv_done_.notify_all();
+            }
+        }
+    }
+    std::mutex busy_, m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> workers_;
+    std::function<void(int)> job_;
+    unsigned generation_ = 0;
+    int parts_ = 0, pending_ = 0;
+};
+
+StagePool &stage_pool() {
+    static StagePool *pool = new StagePool(); /* never destroyed: its detached helpers outlive main() */
+    return *pool;
+}
+
 template <typename T>
 void gather_packed(T *dst, const void *const src[3], ptrdiff_t row_stride, ptrdiff_t pixel_stride, size_t w, size_t h) {
     size_t threads = (size_t)stage_threads();
     if (threads > h / 64)
         threads = h / 64 ? h / 64 : 1; /* at least 64 rows each */
-    if (threads <= 1) {
-        gather_rows(dst, src, row_stride, pixel_stride, w, 0, h);
-        return;
+    if (threads > 1) {
+        const size_t per = (h + threads - 1) / threads;
+        const bool done = stage_pool().run((int)threads, [&](int part) {
+            const size_t y0 = (size_t)part * per, y1 = y0 + per < h ? y0 + per : h;
+            if (y0 < h)
+                gather_rows(dst, src, row_stride, pixel_stride, w, y0, y1);
+        });
+        if (done)
+            return;
     }
-    std::vector<std::thread> pool;
-    const size_t per = (h + threads - 1) / threads;
-    for (size_t t = 1; t < threads; t++) {
-        const size_t y0 = t * per, y1 = y0 + per < h ? y0 + per : h;
-        if (y0 >= h)
-            break;
-        try {
-            pool.emplace_back(gather_rows<T>, dst, src, row_stride, pixel_stride, w, y0, y1);
-        } catch (...) { /* no thread to be had: this one copies the share itself */
-            gather_rows(dst, src, row_stride, pixel_stride, w, y0, y1);
-        }
-    }
-    gather_rows(dst, src, row_stride, pixel_stride, w, 0, per < h ? per : h);
-    for (std::thread &th : pool)
-        th.join();
+    gather_rows(dst, src, row_stride, pixel_stride, w, 0, h);
 }
 
 } // namespace

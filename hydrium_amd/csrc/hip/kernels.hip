@@ -33,7 +33,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kS0Block = 72;            /* floats per block in the row-pass buffer: 64 + 8 pad -> conflict-free column reads */
 constexpr int kS0Chan = 32 * kS0Block;  /* floats per channel */
-constexpr int kQPitch = 65;             /* ints per (block, channel) row of the quantised buffer */
 constexpr int kDbgPitch = 2048;
 
 /* |cos| magnitudes of the scaled DCT-II as the reference spells them (encoder.c:32-40):

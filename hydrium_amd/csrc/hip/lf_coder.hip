@@ -314,7 +314,7 @@ __device__ __forceinline__ void lf_tokens_phase(const HydkLfJob &job, const LfSh
  * The map is monotonic, so "ascending slot order" (the reference's visiting order, which decides
  * ties between merged nodes) is ascending compact order.
  * ======================================================================================== */
-constexpr int kRunLo = 768, kMergedLo = 896, kSlots = 1280;
+constexpr int kRunLo = 768, kMergedLo = 896; /* compact slots run up to 896 + 384 = 1280 < 2048 (11 bits of the entry meta) */
 constexpr int kMaxDepth = 15;
 
 __device__ __forceinline__ int lf_compact(int slot, int n) {

@@ -159,3 +159,34 @@ def test_two_encoders_on_two_threads(lib, image):
         t.join()
     assert not errs, errs
     assert got[0] == want[0] and got[1] == want[1]
+
+
+def test_random_shapes_and_modes(lib):
+    """Seeded sweep over ragged sizes, sample types, layouts and tile shifts (the host-pointer path has
+    per-tile kernel launches, early LF runs every fourth tile and staging helpers: many seams)."""
+    from hydrium_amd import synth
+
+    rng = np.random.default_rng(20260928)
+    kinds = ["photo", "smooth", "noise", "ramp", "black"]
+    for case in range(28):
+        w = int(rng.choice([rng.integers(1, 40), rng.integers(200, 700), rng.integers(2040, 2600), rng.integers(4090, 4300)]))
+        h = int(rng.choice([rng.integers(1, 40), rng.integers(200, 700), rng.integers(2040, 2200)]))
+        depth = int(rng.choice([8, 16, 32]))
+        kind = kinds[int(rng.integers(len(kinds)))]
+        if depth == 32:
+            w, h = min(w, 600), min(h, 600)
+            img = synth.make_image_f32(kind, w, h, seed=case)
+        else:
+            img = synth.make_image(kind, w, h, depth, seed=case)
+        kw = {}
+        mode = int(rng.integers(4))
+        if mode == 1 and max(w, h) <= 2600:
+            s = int(rng.integers(0, 4))
+            kw = dict(shift_x=s, shift_y=int(rng.integers(0, 4)))
+        elif mode == 2:
+            kw = dict(layout="planar")
+        elif mode == 3 and depth != 32:
+            kw = dict(layout="flipped")
+        want, _ = _expected(img, **kw)
+        got = api.encode_image(lib, img, **kw)
+        assert got == want, (case, kind, w, h, depth, kw)

@@ -569,8 +569,7 @@ __device__ __forceinline__ void lf_huffman_wave(const uint32_t *hist, uint32_t *
 
 /* ==========================================================================================
  * phase 3 (all 1024 threads): per-value bit strings -> prefix sum -> LDS window -> coalesced flush.
- * Two barriers per pass: two bit windows alternate (one is flushed and the other cleared while the
- * next pass's records are already on their way).
+ * Two barriers per pass and one 30 KB window (the next pass's records are already on their way).
  * ======================================================================================== */
 constexpr int kPackWords = (31 + kScanSpan * 59) / 32 + 2;
 
@@ -588,12 +587,13 @@ __device__ __forceinline__ void lf_fetch_recs(const LfShape &sh, const unsigned 
 }
 
 __device__ __forceinline__ uint32_t lf_pack_phase(const LfShape &sh, const unsigned long long *__restrict__ recs,
-                                                  const uint32_t *s_code, uint32_t *s_bits2 /* [2][kPackWords] */,
+                                                  const uint32_t *s_code, uint32_t *s_bits /* [kPackWords] */,
                                                   uint32_t (*s_wsum)[kLfThreads / 64], uint32_t *__restrict__ out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t gbits = 0; /* bits written so far (uniform) */
-    for (int w = tid; w < 2 * kPackWords; w += kLfThreads)
-        s_bits2[w] = 0;
+    uint32_t carry = 0; /* thread 0 only: the bits already placed in the word at gbits >> 5 */
+    for (int w = tid; w < kPackWords; w += kLfThreads)
+        s_bits[w] = 0;
     unsigned long long next[4];
     lf_fetch_recs(sh, recs, tid * 4, next);
     int buf = 0;
@@ -603,7 +603,6 @@ __device__ __forceinline__ uint32_t lf_pack_phase(const LfShape &sh, const unsig
         for (int j = 0; j < 4; j++)
             rec[j] = next[j];
         lf_fetch_recs(sh, recs, tb + kScanSpan + tid * 4, next);
-        uint32_t *s_bits = s_bits2 + buf * kPackWords, *s_other = s_bits2 + (buf ^ 1) * kPackWords;
 
         unsigned long long val[4];
         uint32_t len[4], mine = 0;
@@ -632,7 +631,7 @@ __device__ __forceinline__ uint32_t lf_pack_phase(const LfShape &sh, const unsig
         const uint32_t inc = wave_incl_sum(mine);
         if (lane == 63)
             s_wsum[buf][wave] = inc;
-        __syncthreads(); /* also: the other pass's flush and this window's clearing are complete */
+        __syncthreads(); /* also: the previous pass has flushed and cleared the window */
         uint32_t pos = (gbits & 31u) + inc - mine, total = 0;
         for (int w = 0; w < kLfThreads / 64; w++) {
             const uint32_t t = s_wsum[buf][w];
@@ -656,18 +655,24 @@ __device__ __forceinline__ uint32_t lf_pack_phase(const LfShape &sh, const unsig
             pos += len[j];
         }
         __syncthreads();
-        /* whole words go out; the partly filled last word opens the other window, which is cleared otherwise */
+        /* Whole words go out and are cleared by the thread that stored them.  The partly filled last
+         * word (index `full`) belongs to thread 0 alone: it keeps its bits in a register until they
+         * are ORed into the first word of the next pass, so the window needs no second copy and no
+         * third barrier. */
         const uint32_t end = (gbits & 31u) + total, full = end >> 5;
         uint32_t *dst = out + (gbits >> 5);
-        const uint32_t carry = s_bits[full];
-        for (uint32_t w = tid; w < full; w += kLfThreads)
-            dst[w] = s_bits[w];
-        for (int w = tid; w < kPackWords; w += kLfThreads)
-            s_other[w] = w ? 0u : carry;
+        for (uint32_t w = tid; w < full; w += kLfThreads) {
+            dst[w] = s_bits[w] | (w ? 0u : carry);
+            s_bits[w] = 0;
+        }
+        if (tid == 0) {
+            carry = s_bits[full] | (full ? 0u : carry);
+            s_bits[full] = 0;
+        }
         gbits += total;
-        if (tb + kScanSpan >= sh.n && tid == 0 && (gbits & 31u))
-            out[gbits >> 5] = carry;
     }
+    if (tid == 0 && (gbits & 31u))
+        out[gbits >> 5] = carry;
     return gbits;
 }
 
@@ -696,13 +701,14 @@ __global__ __launch_bounds__(kLfThreads) void k_lf_tokens(const HydkLfJob *__res
         hist_all[(size_t)slot * HYDK_LF_CODES + i] = s_hist[i];
 }
 
-__global__ __launch_bounds__(kLfThreads) void k_lf_code(const HydkLfJob *__restrict__ jobs,
+__global__ __launch_bounds__(kLfThreads, 2) /* <= 64 registers: two transform workgroups fit beside it */
+void k_lf_code(const HydkLfJob *__restrict__ jobs,
                                                         const unsigned long long *__restrict__ recs_all,
                                                         const uint32_t *__restrict__ hist_all, HydkLfStream *__restrict__ streams,
                                                         uint32_t *__restrict__ bits_all) {
     const int slot = blockIdx.x, tid = threadIdx.x;
     const LfShape sh = lf_shape(jobs[slot]);
-    __shared__ uint32_t s_bits[2 * kPackWords];
+    __shared__ uint32_t s_bits[kPackWords];
     __shared__ uint32_t s_code[HYDK_LF_CODES];
     __shared__ uint32_t s_wsum[2][kLfThreads / 64];
     __shared__ LfHuffScratch s_huff;

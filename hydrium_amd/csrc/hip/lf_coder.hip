@@ -121,33 +121,19 @@ __device__ __forceinline__ void wave_sync() {
 
 /* ==========================================================================================
  * phase 1 (all 1024 threads): residuals -> run structure -> records + token histogram in LDS.
- * Thread t owns window positions 4t .. 4t+3.  Two barriers per pass: the LF ints of the next pass
- * are fetched while this one is processed, values stay in registers, run starts and wave totals
- * are double-buffered.
+ * Thread t owns window positions 4t .. 4t+3.  Three barriers per pass, everything they exchange is
+ * double-buffered; the LF ints of the next pass are fetched while this one is processed.
  * ======================================================================================== */
 struct LfTokenScratch {
-    int wtot[2][kLfThreads / 64];
-};
-
-struct LfWindow {
-    uint32_t v[4];   /* the thread's four values */
-    uint32_t before; /* the value in front of v[0]; fetched by lane 0 of each wave only */
+    int wtot[2][kLfThreads / 64];       /* per wave: last run head inside it (absolute index) or -1 */
+    uint32_t lastv[2][kLfThreads / 64]; /* per wave: its last value (the next wave's lane 0 compares against it) */
+    uint32_t tailv[2];                  /* the value at the last position this pass decides */
 };
 
 /* value of the stream at plane c, block (y, x): pack_signed(lf - clamped_gradient(w, n, nw)),
  * encoder.c:574-594, in 32-bit wrap-around arithmetic (as the reference's int32 code behaves on the
- * targets it runs on); four unconditional loads with edge-clamped indices */
-__device__ __forceinline__ uint32_t lf_residual_at(const int32_t *dc, int c, int y, int x) {
-    const int idx = c * kPlane + y * HYDK_DC_PITCH + x;
-    const int iw = x ? idx - 1 : y ? idx - HYDK_DC_PITCH : idx;
-    const int in = y ? idx - HYDK_DC_PITCH : iw;
-    const int inw = x && y ? idx - HYDK_DC_PITCH - 1 : iw;
-    const int32_t cur = dc[idx];
-    int32_t w = dc[iw];
-    int32_t n = dc[in];
-    int32_t nw = dc[inw];
-    if (!(x | y)) /* top-left block: all three neighbours count as 0 */
-        w = n = nw = 0;
+ * targets it runs on) */
+__device__ __forceinline__ uint32_t lf_predict(int32_t cur, int32_t w, int32_t n, int32_t nw) {
     const int32_t lo = w < n ? w : n, hi = w < n ? n : w;
     int32_t pred = (int32_t)((uint32_t)w + (uint32_t)n - (uint32_t)nw);
     pred = pred < lo ? lo : pred > hi ? hi : pred;
@@ -155,35 +141,48 @@ __device__ __forceinline__ uint32_t lf_residual_at(const int32_t *dc, int c, int
     return (d << 1) ^ (0u - (d >> 31));
 }
 
-/* the thread's four consecutive values from stream position i0 on: one division, then stepping
- * (measured: a branch-free variant with all twenty loads in flight is slower — the phase is bound by
- * instruction issue on its one CU, not by load latency) */
-__device__ __forceinline__ void lf_fetch(const int32_t *dc, const LfShape &sh, int i0, int lane, LfWindow &w) {
+__device__ __forceinline__ uint32_t lf_residual_at(const int32_t *dc, int c, int y, int x) {
+    const int idx = c * kPlane + y * HYDK_DC_PITCH + x;
+    const int iw = x ? idx - 1 : y ? idx - HYDK_DC_PITCH : idx;
+    const int in = y ? idx - HYDK_DC_PITCH : iw;
+    const int inw = x && y ? idx - HYDK_DC_PITCH - 1 : iw;
+    const int32_t cur = dc[idx];
+    int32_t w = dc[iw], n = dc[in], nw = dc[inw];
+    if (!(x | y)) /* top-left block: all three neighbours count as 0 */
+        w = n = nw = 0;
+    return lf_predict(cur, w, n, nw);
+}
+
+/* the thread's four consecutive values from stream position i0 on.  The usual case — all four in one
+ * block row — shares its neighbours: ten loads instead of sixteen, no per-value address arithmetic. */
+__device__ __forceinline__ void lf_fetch(const int32_t *dc, const LfShape &sh, int i0, uint32_t (&v)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; j++)
-        w.v[j] = 0;
-    w.before = 0;
-    if (i0 > sh.n)
+        v[j] = 0;
+    if (i0 >= sh.n)
         return;
-    int visit = (i0 >= sh.blocks) + (i0 >= 2 * sh.blocks) + (i0 >= 3 * sh.blocks);
+    int visit = (i0 >= sh.blocks) + (i0 >= 2 * sh.blocks);
     const int rem = i0 - visit * sh.blocks;
     int y = rem / sh.vbw, x = rem - y * sh.vbw;
-    const int vbh = sh.blocks / sh.vbw;
-    if (lane == 0 && i0 > 0) { /* position i0 - 1 */
-        int pv = visit, py = y, px = x - 1;
-        if (px < 0) {
-            px = sh.vbw - 1;
-            if (--py < 0) {
-                py = vbh - 1;
-                pv--;
-            }
-        }
-        w.before = lf_residual_at(dc, pv < 2 ? 1 - pv : 2, py, px);
+    if (x + 3 < sh.vbw) { /* same row, hence same channel and inside the stream */
+        const int c = visit < 2 ? 1 - visit : 2; /* Y, X, B */
+        const int32_t *row = dc + c * kPlane + y * HYDK_DC_PITCH + x;
+        const int32_t *up = y ? row - HYDK_DC_PITCH : row;
+        const int32_t c0 = row[0], c1 = row[1], c2 = row[2], c3 = row[3];
+        const int32_t u0 = up[0], u1 = up[1], u2 = up[2], u3 = up[3];
+        const int32_t left = row[x ? -1 : 0], upleft = up[x ? -1 : 0];
+        const int32_t w0 = x ? left : y ? u0 : 0;
+        v[0] = lf_predict(c0, w0, y ? u0 : w0, y && x ? upleft : w0);
+        v[1] = lf_predict(c1, c0, y ? u1 : c0, y ? u0 : c0);
+        v[2] = lf_predict(c2, c1, y ? u2 : c1, y ? u1 : c1);
+        v[3] = lf_predict(c3, c2, y ? u3 : c2, y ? u2 : c2);
+        return;
     }
+    const int vbh = sh.blocks / sh.vbw;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (visit < 3)
-            w.v[j] = lf_residual_at(dc, visit < 2 ? 1 - visit : 2, y, x);
+            v[j] = lf_residual_at(dc, visit < 2 ? 1 - visit : 2, y, x);
         if (++x == sh.vbw) {
             x = 0;
             if (++y == vbh) {
@@ -203,29 +202,37 @@ __device__ __forceinline__ void lf_tokens_phase(const HydkLfJob &job, const LfSh
     for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads)
         s_hist[i] = 0;
 
-    LfWindow next;
-    lf_fetch(dc, sh, q0, lane, next);
-    int carry = 0; /* run start of the position in front of the window (position 0 is a head, so unused at first) */
+    uint32_t next[4];
+    lf_fetch(dc, sh, q0, next);
+    int carry = 0;      /* run start of the position in front of the window (position 0 is a head, so unused at first) */
+    uint32_t tailv = 0; /* its value */
     int buf = 0;
     for (int tb = 0; tb < sh.n; tb += kEmitSpan, buf ^= 1) {
-        const LfWindow cur = next;
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            v[j] = next[j];
         if (tb + kEmitSpan < sh.n)
-            lf_fetch(dc, sh, tb + kEmitSpan + q0, lane, next);
+            lf_fetch(dc, sh, tb + kEmitSpan + q0, next);
         int *s_rs = s_rs2 + buf * kScanSpan;
+        if (lane == 63)
+            S.lastv[buf][wave] = v[3];
+        if (q0 + 3 == kEmitSpan - 1)
+            S.tailv[buf] = v[3];
+        __syncthreads();
 
         /* start of the run each position belongs to (absolute index): max-scan of run heads */
-        uint32_t prev = LF_DPP_KEEP(cur.v[3], 0x138, 0xF); /* wave_shr:1 — the previous lane's last value */
+        uint32_t prev = LF_DPP_KEEP(v[3], 0x138, 0xF); /* wave_shr:1 — the previous lane's last value */
         if (lane == 0)
-            prev = cur.before;
+            prev = wave ? S.lastv[buf][wave - 1] : tailv;
         int rs[4];
         int last = -1;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int i = tb + q0 + j;
-            if (i == 0 || i >= sh.n || cur.v[j] != prev)
-                last = i;
+            last = (i == 0 || i >= sh.n || v[j] != prev) ? i : last;
             rs[j] = last;
-            prev = cur.v[j];
+            prev = v[j];
         }
         const int inc = wave_incl_max(last);
         if (lane == 63)
@@ -238,65 +245,66 @@ __device__ __forceinline__ void lf_tokens_phase(const HydkLfJob &job, const LfSh
         }
         {
             int excl = (int)LF_DPP_KEEP(inc, 0x138, 0xF);
-            if (lane == 0)
-                excl = -1;
+            excl = lane ? excl : -1;
             pre = pre > excl ? pre : excl;
         }
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            if (rs[j] < 0)
-                rs[j] = pre;
+            rs[j] = rs[j] < 0 ? pre : rs[j];
         *(int4 *)&s_rs[q0] = make_int4(rs[0], rs[1], rs[2], rs[3]);
         __syncthreads();
         carry = s_rs[kEmitSpan - 1];
+        tailv = S.tailv[buf];
 
-        /* what each position sends */
-        unsigned long long out[4];
-        bool store = false;
+        /* what each position sends, without divergent control flow: offset c inside the run's current
+         * 128-chunk; "same4" = the chunk has a fifth value, i.e. more than 3 repeats behind its first */
+        const int last_q = sh.n - 1 - tb; /* window-relative index of the stream's last value */
+        uint32_t lit[4], r[4];
+        bool need[4], any_need = false;
+        int s4v[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int q = q0 + j, i = tb + q;
-            out[j] = 0;
-            if (q >= kEmitSpan || i >= sh.n)
-                continue;
-            store = true;
-            const int c = (i - rs[j]) & 127; /* offset inside the run's current 128-chunk */
-            uint32_t lit = 0, r = 0;
-            if (c <= 3) {
-                const int s4 = q - c + 4; /* fifth value of the chunk, window-relative */
-                const bool same4 = tb + s4 < sh.n && s_rs[s4] == rs[j];
-                if (c == 0) {
-                    lit = 1;
-                    if (same4) { /* more than 3 repeats: how many, up to 127 */
-                        int lo = s4, hi = q + 127;
-                        if (hi > sh.n - 1 - tb)
-                            hi = sh.n - 1 - tb;
-                        while (lo < hi) {
-                            const int mid = (lo + hi + 1) >> 1;
-                            if (s_rs[mid] == rs[j])
-                                lo = mid;
-                            else
-                                hi = mid - 1;
-                        }
-                        r = (uint32_t)(lo - q);
-                    }
-                } else {
-                    lit = !same4;
+            const int q = q0 + j;
+            const bool valid = q < kEmitSpan && q <= last_q;
+            const int c = (tb + q - rs[j]) & 127;
+            const int s4 = q - c + 4;
+            const bool same4 = c <= 3 && s4 <= last_q && s_rs[s4 < kScanSpan ? s4 : kScanSpan - 1] == rs[j];
+            lit[j] = valid && (c == 0 || (c <= 3 && !same4));
+            need[j] = valid && c == 0 && same4;
+            r[j] = 0;
+            s4v[j] = s4;
+            any_need |= need[j];
+        }
+        if (__any(any_need)) { /* some chunk head has a run behind it: how long, up to 127 (7 halvings) */
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int q = q0 + j;
+                int lo = need[j] ? s4v[j] : 0, hi = q + 127 < last_q ? q + 127 : last_q;
+                hi = need[j] ? hi : 0;
+#pragma unroll
+                for (int it = 0; it < 7; it++) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    const bool in_run = s_rs[mid] == rs[j];
+                    lo = in_run ? mid : lo;
+                    hi = in_run ? hi : mid - 1;
                 }
+                r[j] = need[j] ? (uint32_t)(lo - q) : 0u;
             }
-            out[j] = LF_REC(cur.v[j], lit, r);
-            if (lit) {
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (lit[j]) {
                 uint32_t token, nb, res;
-                lf_hybrid(cur.v[j], token, nb, res);
+                lf_hybrid(v[j], token, nb, res);
                 atomicAdd(&s_hist[token], 1u);
             }
-            if (r)
-                atomicAdd(&s_hist[256u + r - 3u], 1u);
+            if (r[j])
+                atomicAdd(&s_hist[256u + r[j] - 3u], 1u);
         }
-        if (store) { /* a thread's four records are 32 contiguous bytes; the tail of the stream is padded, never read */
+        if (q0 < kEmitSpan && q0 <= last_q) { /* a thread's four records are 32 contiguous bytes; the tail of the stream is padded, never read */
             ulonglong2 *dst = (ulonglong2 *)(recs + tb + q0);
-            dst[0] = make_ulonglong2(out[0], out[1]);
-            dst[1] = make_ulonglong2(out[2], out[3]);
+            dst[0] = make_ulonglong2(q0 + 0 <= last_q ? LF_REC(v[0], lit[0], r[0]) : 0ull, q0 + 1 <= last_q ? LF_REC(v[1], lit[1], r[1]) : 0ull);
+            dst[1] = make_ulonglong2(q0 + 2 <= last_q ? LF_REC(v[2], lit[2], r[2]) : 0ull, q0 + 3 <= last_q ? LF_REC(v[3], lit[3], r[3]) : 0ull);
         }
     }
     __syncthreads();

@@ -30,8 +30,8 @@
  *
  * k_lf_tokens is the first phase, k_lf_code the other two (see the note above the kernels).
  *
- * The work is small (<= 196608 values per 4.2 Mpx LF group, 9.6 M wave-instructions per 8K frame
- * against the transform kernel's 370 M); it exists so that a frame's sections are complete on the
+ * The work is small (<= 196608 values per 4.2 Mpx LF group, 7.2 M wave-instructions per 8K frame
+ * against the transform kernel's 363 M); it exists so that a frame's sections are complete on the
  * device and the host's per-frame serial work disappears.  device_api.hip runs the kernels either on
  * a side stream beside the HF entropy stage (one frame at a time: hidden behind it) or at the end
  * of the context's own stream (many frames in flight: costs ~7 % of the frame rate, two thirds of

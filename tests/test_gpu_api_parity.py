@@ -190,3 +190,15 @@ def test_random_shapes_and_modes(lib):
         want, _ = _expected(img, **kw)
         got = api.encode_image(lib, img, **kw)
         assert got == want, (case, kind, w, h, depth, kw)
+
+
+def test_worst_case_content_full_lf_groups(lib):
+    """Uniform noise is the format's worst case (2.9 symbols and 14.5 bits per pixel): token buffers,
+    bit buffers and the LF coder's records run close to their hard maxima in full 2048-pixel LF groups."""
+    from hydrium_amd import synth
+
+    img = synth.make_image("noise", 4096, 4096, 8)
+    want, _ = _expected(img)
+    got = api.encode_image(lib, img)
+    assert len(got) > 28_000_000
+    assert got == want

@@ -122,7 +122,9 @@ HYDAMD_EXPORT int hydamd_submit_lf_group(HydAmdContext *ctx, int slot);
 HYDAMD_EXPORT int hydamd_run_lf_coder(HydAmdContext *ctx, int num_slots, int last);
 HYDAMD_EXPORT int hydamd_sync_lf(HydAmdContext *ctx);
 
-/* Enqueue section sizing + packing for slots [0, num_slots): byte-padded HF sections, slot-major, raster inside a slot. */
+/* Enqueue whatever of the hot path is still outstanding for slots [0, num_slots) — transform stage,
+ * LF coder, ANS tables, rANS — and the packing of the HF sections: byte-padded, slot-major, raster
+ * inside a slot.  Asynchronous. */
 HYDAMD_EXPORT int hydamd_finish_frame(HydAmdContext *ctx, int num_slots);
 
 /* Block until everything enqueued so far has run; reports device-side failures (non-finite float

@@ -47,6 +47,8 @@ def parse():
                          "per workgroup (throughput); 4 = one wave per group (lowest single-frame latency)")
     ap.add_argument("--lf-coder", default="on", choices=("on", "off"),
                     help="code the LF coefficient streams on the GPU inside the timed loop (default) or leave them out")
+    ap.add_argument("--collective", default="gather", choices=("gather", "all-gather"),
+                    help="N > 1: bring each frame's sections to rank 0 only (default) or to every rank")
     ap.add_argument("--exchange", action="store_true",
                     help="run the multi-GPU exchange path (process group, all-gather per frame) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,11 +140,14 @@ def main():
         # the first exchanges size the collective exactly (one host sync each); every rank sees every
         # size, so all of them agree on the same bound for the rest of the run
         exact = xstate["seen"] < len(ctxs)
-        sizes, _ = sharding.all_gather_sections(mine, dist.group.WORLD, None if exact else xstate["cap"],
-                                                xbuf.setdefault(id(ctx), {}))
         if exact:
+            sizes, _ = sharding.all_gather_sections(mine, dist.group.WORLD)
             xstate["seen"] += 1
             xstate["cap"] = max(xstate["cap"], int(int(sizes.max().item()) * 1.25) + 4096)
+        elif args.collective == "gather":  # to the assembling rank only: one chunk per xGMI link, nothing redundant
+            sharding.gather_sections(mine, xstate["cap"], 0, dist.group.WORLD, xbuf.setdefault(id(ctx), {}))
+        else:
+            sharding.all_gather_sections(mine, dist.group.WORLD, xstate["cap"], xbuf.setdefault(id(ctx), {}))
         sharding.fence_context_stream(ctx)  # the context's next frame may not overwrite what is being gathered
         xt[1] += time.perf_counter() - t_b
 
@@ -279,7 +284,7 @@ def main():
                        "lf_coder": "gpu, in-stream" if args.lf_coder == "on" else "off",
                        "groups": lfg * 64 if W % 2048 == 0 and H % 2048 == 0 else None, "lf_groups": lfg,
                        "streams": len(ctxs), "rans_groups_per_workgroup": args.rans_waves, "parallelism": f"{world} x (one frame per GPU)" +
-                                                            (", RCCL all-gather of HF sections and LF streams" if use_dist else "")},
+                                                            (f", RCCL {args.collective} of HF sections and LF streams" if use_dist else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_in, "avg_launch_ms": round(dom_ms, 4)},

@@ -80,6 +80,41 @@ def all_gather_sections(payload, group=None, capacity=None, buffers=None):
     return sizes, gathered.view(world, cap)
 
 
+def gather_sections(payload, capacity, dst=0, group=None, buffers=None):
+    """Bring every rank's packed sections to ONE rank — the one that assembles the frame.
+
+    On a point-to-point fabric (xGMI: one link per peer) this is the cheap shape of the exchange: each
+    rank sends its ~10 MB once, the assembling rank receives world - 1 chunks over world - 1 different
+    links, and nobody receives data it has no use for (an all-gather moves world times as much).
+    `capacity` is the agreed per-rank bound (see all_gather_sections); each rank's byte count rides in
+    front of its bytes.  Returns (sizes, rows) on rank `dst`, (None, None) elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = payload.device
+    cap = (max(int(capacity), 1) + 7) & ~7
+    if payload.numel() > cap:
+        raise ValueError(f"payload of {payload.numel()} bytes exceeds the agreed capacity {cap}")
+    pitch = 8 + cap
+    if buffers is not None and buffers.get("gpitch") == pitch and buffers["gmine"].device == dev:
+        mine, gathered = buffers["gmine"], buffers["ggathered"]
+    else:
+        mine = torch.zeros(pitch, dtype=torch.uint8, device=dev)
+        gathered = torch.empty(world * pitch, dtype=torch.uint8, device=dev) if rank == dst else None
+        if buffers is not None:
+            buffers.update(gpitch=pitch, gmine=mine, ggathered=gathered)
+    mine[:8].view(torch.int64).fill_(payload.numel())
+    mine[8:8 + payload.numel()] = payload
+    if rank == dst:
+        rows = gathered.view(world, pitch)
+        dist.gather(mine, gather_list=[rows[r] for r in range(world)], dst=dst, group=group)
+        return rows[:, :8].clone().view(torch.int64).view(world), rows[:, 8:]
+    dist.gather(mine, gather_list=None, dst=dst, group=group)
+    return None, None
+
+
 def fence_context_stream(ctx) -> None:
     """Make everything queued on the context's stream from now on wait for what torch's current
     stream holds at this point — the collectives that are still reading the context's payload

@@ -67,6 +67,13 @@ def _worker(rank, world, port, q):
             s2, g2 = sharding.all_gather_sections(payload, capacity=cap, buffers=bufs)
             assert [int(x) for x in s2] == [int(x) for x in sizes]
             assert sharding.concatenate(s2, g2) == exact
+        # and the point-to-point shape: everything to the assembling rank only
+        s3, g3 = sharding.gather_sections(payload, cap, dst=0, buffers=bufs)
+        if rank == 0:
+            assert [int(x) for x in s3] == [int(x) for x in sizes]
+            assert sharding.concatenate(s3, g3) == exact
+        else:
+            assert s3 is None and g3 is None
         q.put((rank, [int(x) for x in sizes], exact))
     finally:
         dist.destroy_process_group()

@@ -25,7 +25,8 @@ HYD_INTERNAL_ERROR = -15
 HYD_UINT8, HYD_UINT16, HYD_FLOAT32 = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "lib", "libhydrium.so.0")
+# HYDAMD_LIB: another build of the same library (probe builds of scripts/probe_k1_phases.py); never a fallback
+DEFAULT_LIB = os.environ.get("HYDAMD_LIB") or os.path.join(_HERE, "lib", "libhydrium.so.0")
 
 
 class HYDImageMetadata(C.Structure):

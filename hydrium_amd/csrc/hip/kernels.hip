@@ -231,6 +231,39 @@ struct SampleOf<HYDK_FMT_F32> {
 
 } /* namespace */
 
+/* Probe builds only (-DHYDK_PHASE_TIMERS, scripts/probe_k1_phases.py): s_memtime ticks each wave of K1
+ * spends in each phase, summed over the launch.  Never compiled into the product library. */
+#ifdef HYDK_PHASE_TIMERS
+__device__ unsigned long long g_phase_ticks[8];
+#define HYDK_PHASE_INIT() long long ph_prev = __builtin_readcyclecounter(); unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define HYDK_PHASE_MARK(i)                                      \
+    do {                                                        \
+        __builtin_amdgcn_sched_barrier(0);                      \
+        const long long ph_now = __builtin_readcyclecounter();  \
+        ph_acc[i] += (unsigned long long)(ph_now - ph_prev);    \
+        ph_prev = ph_now;                                       \
+        __builtin_amdgcn_sched_barrier(0);                      \
+    } while (0)
+#define HYDK_PHASE_FLUSH()                                      \
+    do {                                                        \
+        if ((threadIdx.x & 63) == 0)                            \
+            for (int ph_i = 0; ph_i < 8; ph_i++)                \
+                atomicAdd(&g_phase_ticks[ph_i], ph_acc[ph_i]);  \
+    } while (0)
+extern "C" __attribute__((visibility("default"))) int hydamd_debug_phase_ticks(unsigned long long out[8], int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_ticks), sizeof(unsigned long long) * 8);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -15;
+}
+#else
+#define HYDK_PHASE_INIT()
+#define HYDK_PHASE_MARK(i)
+#define HYDK_PHASE_FLUSH()
+#endif
+
 /* ==========================================================================================
  * K1: fused transform + tokenise.  grid = 64 group slots per LF group x LF groups of the frame,
  * block = 256 threads (4 waves); one 256x256 group per workgroup, walked as 32 strips of 8 rows.
@@ -326,7 +359,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
     uint32_t goff = 0;
     unsigned long long zero_tokens = 0; /* six 10-bit counters: zero-valued coefficient tokens per cluster */
     bool bad_sample = false;
+    HYDK_PHASE_INIT();
     __syncthreads();
+    HYDK_PHASE_MARK(7);
 
     for (int s = 0; s < gbh; s++) {
         /* ---------------- phase A: 8 px of one block row -> XYB -> row DCT ---------------- */
@@ -398,6 +433,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
                     d[(size_t)2 * kDbgPitch * kDbgPitch + i] = bv[i];
                 }
             }
+            HYDK_PHASE_MARK(0);
             float o[8];
             float *dst = s_rowpass + ab * kS0Block + ar * 8;
             dct8(xv, o);
@@ -413,7 +449,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
             for (int k = 0; k < 8; k++)
                 dst[2 * kS0Chan + k] = o[k];
         }
+        HYDK_PHASE_MARK(1);
         __syncthreads();
+        HYDK_PHASE_MARK(2);
 
         /* ---------------- phase B: column DCT, quantise, LF ints, non-zero bitmaps ---------------- */
         int q[3][8];
@@ -471,7 +509,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
                 }
             }
         }
+        HYDK_PHASE_MARK(3);
         __syncthreads();
+        HYDK_PHASE_MARK(4);
 
         /* ---------------- phase C1: offsets of the 96 emission slots ---------------- */
         if (wave == 0) {
@@ -493,6 +533,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
                 s_off[96] = total0 + inc1;
         }
         __syncthreads();
+        HYDK_PHASE_MARK(5);
 
         /* ---------------- phase C2: every thread emits the symbols of its own coefficients ---------------- */
         if (cb < gbw) {
@@ -550,6 +591,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
             }
         }
         goff += s_off[96];
+        HYDK_PHASE_MARK(6);
         /* no barrier here: s_off is rewritten only after the next strip's two barriers, s_cnt
          * after its first, s_rowpass is last read before this strip's second barrier */
     }
@@ -579,6 +621,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
         job.sym_count[g] = goff;
     if (FMT == HYDK_FMT_F32 && bad_sample)
         atomicOr(status, 1u);
+    HYDK_PHASE_MARK(7);
+    HYDK_PHASE_FLUSH();
 }
 
 /* ==========================================================================================

@@ -27,7 +27,16 @@
  *   - non-finite float samples yield HYD_API_ERROR "Invalid NaN Float" (the reference sets the
  *     message but drops the status, format.c:172-174) — reported when the frame is finished;
  *   - output never lands in caller memory beyond the provided length (bitwriter.c:42-51 would
- *     realloc() the caller's buffer).
+ *     realloc() the caller's buffer);
+ *   - hyd_send_tile returns HYD_NEED_MORE_OUTPUT when coded bytes are still pending, as the public
+ *     header documents (libhydrium.h:222-226); the reference's hyd_send_tile drops the status of its
+ *     closing hyd_flush and always says HYD_OK (libhydrium.c:193-202), so a caller written to the
+ *     documented protocol would truncate its file there;
+ *   - a one-frame tile sent twice is rejected with HYD_API_ERROR (the reference codes a corrupt
+ *     frame: both copies land in the TOC permutation, encoder.c:241-325);
+ *   - ICC profiles with the 'SGI ' or 'SUNW' platform signature: position 41 takes the default
+ *     prediction, as a decoder must (it learns byte 41 only there); the reference indexes
+ *     "I "[i - 42] with i = 41 (libhydrium.c:219-224), 4 GB past the literal, and crashes.
  */
 #define _POSIX_C_SOURCE 200809L /* clock_gettime under -std=c99 */
 #include <pthread.h>
@@ -76,6 +85,7 @@ struct HYDEncoder {
     size_t icc_size;
 
     HydFrameLfg *sent; /* [lfg_per_frame] in send order */
+    uint8_t *sent_mask; /* [lfg_per_frame] by raster id: one-frame tiles already received */
     HydAmdContext *dev;
     size_t dev_slots;  /* shape the context was created for */
     int dev_linear;
@@ -248,11 +258,19 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
         goto done;
     }
     size_t k = 0, mark = 0;
+    int overflow = 0; /* more sections than the frame geometry has TOC entries: inconsistent LF-group list */
+#define PUSH_SIZE(v)                       \
+    do {                                   \
+        if (k < toc_n)                     \
+            sizes[k++] = (v);              \
+        else                               \
+            overflow = 1;                  \
+    } while (0)
 #define CLOSE_SECTION()                    \
     do {                                   \
         if (multi) {                       \
             hb_align(&body);               \
-            sizes[k++] = body.len - mark;  \
+            PUSH_SIZE(body.len - mark);    \
             mark = body.len;               \
         }                                  \
     } while (0)
@@ -311,8 +329,8 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
          * it follows the body, so only its sizes are needed here */
         for (size_t s = 0; s < shape->lfg_count; s++) {
             const size_t ng = ((shape->lfg[s].width + 255) >> 8) * ((shape->lfg[s].height + 255) >> 8);
-            for (size_t g = 0; g < ng; g++)
-                sizes[k++] = (res[s].bits[g] + 7u) >> 3;
+            for (size_t g = 0; g < ng && g < HYDAMD_GROUPS_PER_LFG; g++)
+                PUSH_SIZE((res[s].bits[g] + 7u) >> 3);
         }
     } else {
         /* a single-group frame is one bit-contiguous section (encoder.c:837-850,968-981 guards) */
@@ -333,8 +351,8 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
     }
     hb_align(&body);
     if (!multi)
-        sizes[k++] = body.len;
-    if (k != toc_n || body.failed) {
+        PUSH_SIZE(body.len);
+    if (overflow || k != toc_n || body.failed) {
         ret = FAIL(e, body.failed ? HYD_NOMEM : HYD_INTERNAL_ERROR, "frame assembly inconsistency");
         goto done;
     }
@@ -362,6 +380,7 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
 done:
     free(fetched);
 #undef CLOSE_SECTION
+#undef PUSH_SIZE
     free(sizes);
     free(freq);
     free(alpha);
@@ -509,6 +528,7 @@ HYDRIUM_EXPORT HYDStatusCode hyd_encoder_destroy(HYDEncoder *e) {
     hb_free(&e->stream);
     free(e->icc);
     free(e->sent);
+    free(e->sent_mask);
     free(e);
     return HYD_OK;
 }
@@ -540,8 +560,10 @@ HYDRIUM_EXPORT HYDStatusCode hyd_set_metadata(HYDEncoder *e, const HYDImageMetad
     if (e->lfg_per_frame > HYDAMD_MAX_LF_GROUPS || e->lfg_per_frame == 128)
         return FAIL(e, HYD_API_ERROR, "one frame cannot hold 128 or more than 255 LF groups; use tile mode");
     free(e->sent);
+    free(e->sent_mask);
     e->sent = calloc(e->lfg_per_frame, sizeof(HydFrameLfg));
-    if (!e->sent)
+    e->sent_mask = calloc(e->lfg_per_frame, 1);
+    if (!e->sent || !e->sent_mask)
         return FAIL(e, HYD_NOMEM, "out of memory");
     if (e->dev) { /* metadata changed: the device context is rebuilt lazily */
         ctx_release(e->dev, e->dev_slots, e->dev_linear, !e->dev_failed);
@@ -737,6 +759,8 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
         return FAIL(e, HYD_API_ERROR, "tile out of bounds");
     if (e->one_frame && (e->frame_done || e->tiles_sent >= e->lfg_per_frame))
         return FAIL(e, HYD_API_ERROR, "the final tile of this image was already sent");
+    if (e->one_frame && e->sent_mask[(size_t)tile_y * e->lfg_count_x + tile_x])
+        return FAIL(e, HYD_API_ERROR, "this tile was already sent");
     const size_t tw = ((size_t)tile_x + 1) * e->tile_w > W ? W - tile_x * e->tile_w : e->tile_w;
     const size_t th = ((size_t)tile_y + 1) * e->tile_h > H ? H - tile_y * e->tile_h : e->tile_h;
     e->last_tile = is_last < 0 ? ((size_t)tile_x + 1) * e->tile_w >= W && ((size_t)tile_y + 1) * e->tile_h >= H : !!is_last;
@@ -789,10 +813,11 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
     TRACE("stage + upload tile", tu);
 
     if (e->one_frame) {
+        e->sent_mask[l->raster_id] = 1;
         e->tiles_sent++;
         if (!e->last_tile) {
             drain(e);
-            return HYD_OK;
+            return HYD_OK; /* nothing of the frame exists yet; hyd_flush is a no-op here too (libhydrium.c:148-149) */
         }
         if (e->tiles_sent != e->lfg_per_frame)
             return FAIL(e, HYD_API_ERROR, "one-frame mode needs every tile before the final one");
@@ -815,8 +840,12 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
         return ret;
     if (e->one_frame)
         e->frame_done = 1;
+    /* the reference ends the tile with hyd_flush (encoder.c:1008): its error when no buffer is on loan
+     * reaches the caller (libhydrium.c:193-195); HYD_NEED_MORE_OUTPUT is what the header documents */
+    if (!e->out)
+        return FAIL(e, HYD_API_ERROR, "buffer was never provided");
     drain(e);
-    return HYD_OK;
+    return e->stream_pos < e->stream.len ? HYD_NEED_MORE_OUTPUT : HYD_OK;
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -839,9 +868,11 @@ static uint8_t icc_header_guess(const uint8_t *icc, uint32_t icc_size, unsigned 
             return (uint8_t)"PPL"[i - 41];
         if (icc[40] == 'M')
             return (uint8_t)"SFT"[i - 41];
-        if (icc[40] == 'S' && icc[41] == 'G')
+        /* 'SGI ' / 'SUNW': bytes 42 and 43 are predicted from byte 41, which a decoder has only once it
+         * has decoded position 41 — so position 41 itself takes the default prediction below */
+        if (i >= 42 && icc[40] == 'S' && icc[41] == 'G')
             return (uint8_t)"I "[i - 42];
-        if (icc[40] == 'S' && icc[41] == 'U')
+        if (i >= 42 && icc[40] == 'S' && icc[41] == 'U')
             return (uint8_t)"NW"[i - 42];
     }
     switch (i) {
@@ -932,6 +963,11 @@ static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is
                 break;
             }
             e->sent[s].raster_id = e->one_frame ? ty * e->lfg_count_x + tx : 0;
+            if (e->sent_mask[e->sent[s].raster_id]) {
+                ret = FAIL(e, HYD_API_ERROR, "an LF group appears twice in the frame description");
+                break;
+            }
+            e->sent_mask[e->sent[s].raster_id] = 1;
             e->sent[s].x = tx;
             e->sent[s].y = ty;
             e->sent[s].width = (tx + 1) * e->tile_w > W ? W - tx * e->tile_w : e->tile_w;
@@ -1041,6 +1077,26 @@ static int hydt_take(HydBits *b, int ret, uint8_t **out, size_t *out_len) {
         }
     }
     hb_free(b);
+    return ret;
+}
+
+/* the pre-mangled ICC profile hyd_set_suggested_icc_profile keeps (what the file header then entropy-codes) */
+HYDT_EXPORT int hydt_icc_mangled(const uint8_t *icc, size_t icc_size, uint8_t **out, size_t *out_len) {
+    HYDEncoder *e = hyd_encoder_new();
+    if (!e)
+        return HYD_NOMEM;
+    e->one_frame = 1;
+    int ret = hyd_set_suggested_icc_profile(e, icc, icc_size);
+    if (!ret) {
+        *out = malloc(e->icc_size ? e->icc_size : 1);
+        if (*out) {
+            memcpy(*out, e->icc, e->icc_size);
+            *out_len = e->icc_size;
+        } else {
+            ret = HYD_NOMEM;
+        }
+    }
+    hyd_encoder_destroy(e);
     return ret;
 }
 

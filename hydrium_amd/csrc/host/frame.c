@@ -139,6 +139,7 @@ size_t hyd_toc_entries(const HydFrameShape *shape) {
 static int toc_lehmer(const HydFrameShape *shape, size_t n, uint32_t **lehmer_out) {
     const size_t fgx = groups_of(shape->frame_width);
     size_t *where = malloc(n * sizeof(size_t)); /* logical section -> physical position */
+    const size_t unset = (size_t)-1;
     uint32_t *tree = calloc(n + 1, sizeof(uint32_t));
     uint32_t *lehmer = malloc(n * sizeof(uint32_t));
     if (!where || !tree || !lehmer) {
@@ -147,17 +148,37 @@ static int toc_lehmer(const HydFrameShape *shape, size_t n, uint32_t **lehmer_ou
         free(lehmer);
         return ST_NOMEM;
     }
+    /* every logical section must be claimed exactly once: a frame description with a repeated or
+     * out-of-range LF group would otherwise index past the arrays below */
+    int bad = 0;
     size_t pos = 0;
-    where[0] = pos++; /* LFGlobal */
-    for (size_t s = 0; s < shape->lfg_count; s++)
-        where[1 + shape->lfg[s].raster_id] = pos++; /* LF groups in send order */
-    where[1 + shape->lfg_count] = pos++;            /* HFGlobal */
-    for (size_t s = 0; s < shape->lfg_count; s++) {
+    for (size_t i = 0; i < n; i++)
+        where[i] = unset;
+#define HYD_CLAIM(logical)                                        \
+    do {                                                          \
+        const size_t at_ = (logical);                             \
+        if (at_ >= n || where[at_] != unset || pos >= n)          \
+            bad = 1;                                              \
+        else                                                      \
+            where[at_] = pos++;                                   \
+    } while (0)
+    HYD_CLAIM(0); /* LFGlobal */
+    for (size_t s = 0; s < shape->lfg_count && !bad; s++)
+        HYD_CLAIM(1 + shape->lfg[s].raster_id); /* LF groups in send order */
+    HYD_CLAIM(1 + shape->lfg_count);            /* HFGlobal */
+    for (size_t s = 0; s < shape->lfg_count && !bad; s++) {
         const HydFrameLfg *l = &shape->lfg[s];
         const size_t gcx = groups_of(l->width), gcy = groups_of(l->height);
         const size_t gx0 = shape->one_frame ? l->x << 3 : 0, gy0 = shape->one_frame ? l->y << 3 : 0;
-        for (size_t g = 0; g < gcx * gcy; g++)
-            where[2 + shape->lfg_count + (gy0 + g / gcx) * fgx + gx0 + g % gcx] = pos++;
+        for (size_t g = 0; g < gcx * gcy && !bad; g++)
+            HYD_CLAIM(2 + shape->lfg_count + (gy0 + g / gcx) * fgx + gx0 + g % gcx);
+    }
+#undef HYD_CLAIM
+    if (bad || pos != n) {
+        free(where);
+        free(tree);
+        free(lehmer);
+        return ST_API;
     }
     /* lehmer[i] = how many not-yet-used positions are smaller than where[i] */
     for (size_t i = 1; i <= n; i++) {

@@ -202,3 +202,64 @@ def test_worst_case_content_full_lf_groups(lib):
     got = api.encode_image(lib, img)
     assert len(got) > 28_000_000
     assert got == want
+
+
+def _encode_documented_protocol(lib, img, out_buf_size, shift=-1):
+    """The call pattern libhydrium.h documents for hyd_send_tile (reference libhydrium.h:222-226):
+    flush ONLY while the previous call said HYD_NEED_MORE_OUTPUT.  (The reference's own hyd_send_tile
+    never says so — it drops its closing flush's status, libhydrium.c:193-202 — so this client is only
+    correct against an implementation that honours the header.)"""
+    import ctypes as C
+
+    h, w, _ = img.shape
+    tw, th = api.tile_dims(w, h, shift, shift)
+    out = bytearray()
+    with api.Encoder(lib) as enc:
+        enc.check(enc.set_metadata(w, h, 0, shift, shift))
+        buf = (C.c_uint8 * out_buf_size)()
+        enc.check(enc.provide_output(buf))
+        for ty in range(-(-h // th)):
+            for tx in range(-(-w // tw)):
+                ret = enc.check(enc.send_tile(img, tx, ty, tw, th))
+                while ret == api.HYD_NEED_MORE_OUTPUT:
+                    code, n = enc.release_output()
+                    enc.check(code)
+                    out += C.string_at(buf, n)
+                    enc.check(enc.provide_output(buf))
+                    ret = enc.check(enc.flush())
+        code, n = enc.release_output()
+        enc.check(code)
+        out += C.string_at(buf, n)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("shift,size", [(-1, 64), (-1, 4096), (0, 64), (0, 1 << 20)])
+def test_send_tile_reports_pending_output_as_documented(lib, image, shift, size):
+    img = image("photo", 600, 520, 8)
+    want, _ = _expected(img, shift_x=shift, shift_y=shift)
+    assert _encode_documented_protocol(lib, img, size, shift) == want
+
+
+def test_final_tile_without_an_output_buffer_is_an_api_error(lib, image):
+    """reference: hyd_encode_xyb_buffer ends in hyd_flush, whose "buffer was never provided" error
+    reaches the caller of hyd_send_tile (encoder.c:1008, libhydrium.c:149-152,193-195)"""
+    img = image("photo", 64, 64, 8)
+    with api.Encoder(lib) as enc:
+        enc.check(enc.set_metadata(64, 64))
+        assert enc.send_tile(img, 0, 0, 2048, 2048) == api.HYD_API_ERROR
+        assert enc.error_message() == "buffer was never provided"
+
+
+def test_a_tile_sent_twice_is_rejected(lib, image):
+    import ctypes as C
+
+    img = image("photo", 2100, 16, 8)
+    with api.Encoder(lib) as enc:
+        enc.check(enc.set_metadata(2100, 16))
+        buf = (C.c_uint8 * 65536)()
+        enc.check(enc.provide_output(buf))
+        assert enc.send_tile(img, 0, 0, 2048, 2048, is_last=0) == api.HYD_OK
+        assert enc.send_tile(img, 0, 0, 2048, 2048, is_last=1) == api.HYD_API_ERROR
+        assert enc.error_message() == "this tile was already sent"
+        # the encoder is still usable: the missing tile completes the frame
+        enc.check(enc.send_tile(img, 1, 0, 2048, 2048, is_last=1))

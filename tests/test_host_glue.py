@@ -89,3 +89,95 @@ def test_survey_anchor_md5(image):
     """SURVEY.md Appendix C anchor that needs no reference build."""
     got = glue.encode_with_oracle_stages(image("photo", 256, 256, 8))
     assert (len(got), hashlib.md5(got).hexdigest()) == (12426, "469f79d37f5802edda18da52ff8dc889")
+
+
+def test_repeated_lf_group_is_rejected_not_overrun(image):
+    """the same LF group twice in a frame description used to write past the TOC arrays."""
+    img = image("photo", 2100, 16, 8)
+    with pytest.raises(RuntimeError, match="-14"):
+        glue.encode_with_oracle_stages(img, order=[(0, 0), (0, 0)])
+    with pytest.raises(RuntimeError, match="-14"):
+        glue.encode_with_oracle_stages(img, order=[(1, 0), (1, 0)])
+
+
+def _icc_unmangle(m: bytes) -> bytes:
+    """Decoder side of the JPEG XL ICC transform for the streams hyd_set_suggested_icc_profile makes
+    (header prediction, empty tag list, one 'copy the rest' command), written from the decoder's point
+    of view: position i is predicted from bytes < i only."""
+    def varint(buf, pos):
+        v = shift = 0
+        while True:
+            b = buf[pos]
+            pos += 1
+            v |= (b & 127) << shift
+            shift += 7
+            if not b & 128:
+                return v, pos
+    size, pos = varint(m, 0)
+    csize, pos = varint(m, pos)
+    cmds = m[pos:pos + csize]
+    data = m[pos + csize:]
+    head = min(size, 128)
+    out = bytearray()
+    for i in range(head):
+        p = 0
+        if i < 4:
+            p = (size >> (8 * (3 - i))) & 255
+        elif i == 8:
+            p = 4
+        elif 12 <= i < 24:
+            p = b"mntrRGB XYZ "[i - 12]
+        elif 36 <= i < 40:
+            p = b"acsp"[i - 36]
+        elif 41 <= i < 44 and out[40] == ord("A"):
+            p = b"APPL"[i - 40]
+        elif 41 <= i < 44 and out[40] == ord("M"):
+            p = b"MSFT"[i - 40]
+        elif 42 <= i < 44 and out[40] == ord("S") and out[41] == ord("G"):
+            p = b"SGI "[i - 40]
+        elif 42 <= i < 44 and out[40] == ord("S") and out[41] == ord("U"):
+            p = b"SUNW"[i - 40]
+        elif i == 70:
+            p = 246
+        elif i == 71:
+            p = 214
+        elif i == 73:
+            p = 1
+        elif i == 78:
+            p = 211
+        elif i == 79:
+            p = 45
+        elif 80 <= i < 84:
+            p = out[i - 76]
+        out.append((data[i] + p) & 255)
+    if size > 128:
+        tags, cp = varint(cmds, 0)  # empty tag list
+        assert tags == 0 and cmds[cp] == 1  # command 1: copy
+        cnt, cp = varint(cmds, cp + 1)
+        assert cnt == size - 128 and cp == len(cmds)
+        out += data[head:head + cnt]
+    return bytes(out)
+
+
+@pytest.mark.parametrize("platform", [b"APPL", b"MSFT", b"SGI ", b"SUNW", b"SXYZ", b"\0\0\0\0"])
+@pytest.mark.parametrize("size", [60, 128, 400])
+def test_icc_transform_is_decodable_for_every_platform_signature(platform, size):
+    """'SGI ' / 'SUNW' profiles crashed (the reference's "I "[i - 42] with i = 41)."""
+    import ctypes as C
+
+    rng = np.random.default_rng(11)
+    icc = bytearray(rng.integers(0, 256, size, dtype=np.uint8).tobytes())
+    icc[0:4] = size.to_bytes(4, "big")
+    if size >= 44:
+        icc[36:40] = b"acsp"
+        icc[40:44] = platform
+    if glue._d is None:
+        glue._d = glue._lib()
+    d = glue._d
+    d.hydt_icc_mangled.restype = C.c_int
+    d.hydt_icc_mangled.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    out, n = C.c_void_p(0), C.c_size_t(0)
+    assert d.hydt_icc_mangled(bytes(icc), len(icc), C.byref(out), C.byref(n)) == 0
+    mangled = bytes((C.c_uint8 * n.value).from_address(out.value))
+    d.hydt_free(out)
+    assert _icc_unmangle(mangled) == bytes(icc)

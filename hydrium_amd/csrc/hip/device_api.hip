@@ -42,6 +42,9 @@ hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const ui
 hipError_t launch_rans_rows(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
                             uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int whole_lf_group,
                             hipStream_t stream);
+hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
+                             uint16_t *aux, uint16_t *flags, uint32_t *final_state, uint32_t *bitbuf, uint32_t *group_bits,
+                             int preset_bits, int nclusters, int num_slots, hipStream_t stream);
 hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, hipStream_t stream);
 hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
                        int count, hipStream_t stream);
@@ -87,6 +90,7 @@ struct HydAmdContext {
     int register_luts_ok = 0;
     int rans_waves = 4;             /* groups per rANS workgroup: 4 (latency) .. 16 (throughput) */
     int rans_rows = 0;              /* 0: wave per group; 1..3: row forms 1..3 (hydamd_set_rans_waves) */
+    int rans_lanes = 0;             /* 1: lane per group (form 5); float frames still take the wave form */
     uint32_t alpha_floor = 0;       /* running maximum alphabet of the LF groups coded before this context's */
     unsigned num_presets = 1;
     int scheme = 0;
@@ -99,6 +103,9 @@ struct HydAmdContext {
     /* device memory */
     uint64_t *tokens = nullptr;     /* [slots][64][TOKENS_PER_GROUP] */
     uint32_t *bitbuf = nullptr;     /* [slots][64][BITWORDS_PER_GROUP] */
+    uint16_t *rans_aux = nullptr;   /* [slots][64][TOKENS_PER_GROUP] lane form: the 16 bits a refill at each symbol sends */
+    uint16_t *rans_flags = nullptr; /* [slots][64][TOKENS_PER_GROUP / 16] lane form: one refill flag per symbol */
+    uint32_t *rans_final = nullptr; /* [slots][64] lane form: final states */
     HydkTables *tables = nullptr;   /* [slots] */
     int32_t *dc = nullptr;          /* [slots][3][256][256] */
     uint32_t *hist = nullptr;       /* [slots][9][128] */
@@ -138,6 +145,7 @@ struct HydAmdContext {
     hipEvent_t lf_ready = nullptr;         /* recorded behind the LF gather kernel and the copy of its byte count */
     int lf_slots = 0;                      /* slots covered by the last LF coder run */
     int transformed = 0, coded = 0, lf_coded = 0; /* slots of the current frame whose transform / entropy / LF kernels are enqueued */
+    int host_staged = 0;                   /* slots [0, host_staged) of the current frame have pixels in the staging arena */
     float *dbg_xyb = nullptr, *dbg_dct = nullptr;
     int32_t *dbg_quant = nullptr;
 
@@ -302,9 +310,19 @@ int record_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrd
     return ST_OK;
 }
 
+int transform_pending_host_slots(HydAmdContext *ctx);
+
 int ensure_staging(HydAmdContext *ctx, size_t tile_bytes) {
     if (tile_bytes <= ctx->staging_cap)
         return ST_OK;
+    /* The arena is about to be replaced (a later tile of the frame has a wider sample type than the
+     * first: the reference lets sample_fmt vary per tile).  Tiles already uploaded but not yet
+     * transformed (HYDAMD_EAGER=0) would lose their pixels: run their transform kernels first. */
+    {
+        const int st = transform_pending_host_slots(ctx);
+        if (st != ST_OK)
+            return st;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->copy_stream) /* created on first use: device-pointer users never need it */
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -500,7 +518,7 @@ void hydamd_destroy(HydAmdContext *ctx) {
     for (void *p : lfdev)
         if (p)
             (void)hipFree(p);
-    void *dev[] = {ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->hist, ctx->sym_count, ctx->group_bits,
+    void *dev[] = {ctx->rans_aux, ctx->rans_flags, ctx->rans_final, ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->hist, ctx->sym_count, ctx->group_bits,
                    ctx->offsets, ctx->total, ctx->status, ctx->alpha_max, ctx->d_jobs, ctx->in_lut8, ctx->in_lut16,
                    ctx->bias_lut, ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant, ctx->d_arena};
     for (void *p : dev)
@@ -534,6 +552,9 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     ctx->stream = ctx->own_stream;
     HIP_TRY(ctx, hipMalloc(&ctx->tokens, slots * G * HYDK_TOKENS_PER_GROUP * sizeof(uint64_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->bitbuf, slots * G * HYDK_BITWORDS_PER_GROUP * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->rans_aux, slots * G * HYDK_TOKENS_PER_GROUP * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->rans_flags, slots * G * (HYDK_TOKENS_PER_GROUP / 16) * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->rans_final, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->tables, slots * sizeof(HydkTables)));
     HIP_TRY(ctx, hipMalloc(&ctx->dc, slots * 3 * HYDK_DC_PITCH * HYDK_DC_PITCH * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->hist, slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t)));
@@ -616,6 +637,8 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
             ctx->rans_waves = w;
         if (w >= 1 && w <= 3)
             ctx->rans_rows = w;
+        if (w == 5)
+            ctx->rans_lanes = 1;
     }
     if (const char *env = getenv("HYDAMD_LF_CODER")) /* 0: leave the LF ints to the host coder (A/B measurements) */
         ctx->lf_on_device = atoi(env) == 2 ? 2 : atoi(env) != 0;
@@ -693,12 +716,19 @@ int hydamd_set_rans_waves(HydAmdContext *ctx, int waves) {
         return ST_API_ERROR;
     if (waves >= 1 && waves <= 3) { /* four chains per wave, one per 16-lane row; 2: a whole LF group, 3: half of one, per workgroup */
         ctx->rans_rows = waves;
+        ctx->rans_lanes = 0;
+        return ST_OK;
+    }
+    if (waves == 5) { /* one lane per group: a wavefront per LF group walks its 64 chains, bits are written by a second kernel */
+        ctx->rans_lanes = 1;
+        ctx->rans_rows = 0;
         return ST_OK;
     }
     if (waves != 4)
-        return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group) or 1/2/3 (row forms)");
+        return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group), 1/2/3 (row forms) or 5 (lane per group)");
     ctx->rans_waves = waves;
     ctx->rans_rows = 0;
+    ctx->rans_lanes = 0;
     return ST_OK;
 }
 
@@ -731,6 +761,7 @@ int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
     ctx->results_valid = false;
     ctx->slots_finished = 0;
     ctx->transformed = ctx->coded = ctx->lf_coded = 0;
+    ctx->host_staged = 0;
     ctx->lf_need_gather = false;
     ctx->lf_results_valid = false;
     ctx->lf_slots = 0;
@@ -797,7 +828,10 @@ int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, const void *const 
     HIP_TRY(ctx, hipEventRecord(ctx->staged[k], ctx->copy_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->staged[k], 0)); /* kernels queued from here on see the tile */
     const void *dsrc[3] = {base, base + ss, base + 2 * ss};
-    return record_lf_group(ctx, slot, dsrc, (ptrdiff_t)(3 * width), 3, sample_fmt, width, height, preset);
+    st = record_lf_group(ctx, slot, dsrc, (ptrdiff_t)(3 * width), 3, sample_fmt, width, height, preset);
+    if (st == ST_OK && slot + 1 > ctx->host_staged)
+        ctx->host_staged = slot + 1;
+    return st;
 }
 
 /* K1 for slots [first, first + count) */
@@ -815,6 +849,17 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
     HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs + first, count, mask, ctx->use_luts, ctx->status, ctx->stream));
     return ST_OK;
 }
+
+namespace {
+int transform_pending_host_slots(HydAmdContext *ctx) {
+    if (ctx->host_staged <= ctx->transformed)
+        return ST_OK;
+    const int st = transform_range(ctx, ctx->transformed, ctx->host_staged - ctx->transformed);
+    if (st == ST_OK)
+        ctx->transformed = ctx->host_staged;
+    return st;
+}
+} // namespace
 
 /* The LF coder's token and code kernels for slots [first, first + count), whose transform kernels
  * are already enqueued.  It needs only the LF ints they write: forked onto its own stream so that it
@@ -914,7 +959,16 @@ static int entropy_range(HydAmdContext *ctx, int first, int count) {
         const HydkLfJob *jobs = ctx->d_jobs + first;
         uint64_t *tokens = ctx->tokens + g0 * HYDK_TOKENS_PER_GROUP;
         uint32_t *bitbuf = ctx->bitbuf + g0 * HYDK_BITWORDS_PER_GROUP;
-        if (ctx->rans_rows)
+        bool any_float = false; /* 8-byte records: only the wave and row forms read them */
+        for (int i = first; i < first + count; i++)
+            any_float = any_float || ctx->h_jobs[i].fmt == HYDK_FMT_F32;
+        if (ctx->rans_lanes && !any_float)
+            HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, tokens, ctx->sym_count + g0, ctx->tables + first,
+                                                 ctx->rans_aux + g0 * HYDK_TOKENS_PER_GROUP,
+                                                 ctx->rans_flags + g0 * (HYDK_TOKENS_PER_GROUP / 16), ctx->rans_final + g0,
+                                                 bitbuf, ctx->group_bits + g0, ctx->preset_bits, ctx->nclusters, count,
+                                                 ctx->stream));
+        else if (ctx->rans_rows)
             HIP_TRY(ctx, hydk::launch_rans_rows(jobs, tokens, ctx->sym_count + g0, ctx->tables + first, bitbuf,
                                                 ctx->group_bits + g0, ctx->preset_bits, count, ctx->rans_rows - 1,
                                                 ctx->stream));
@@ -981,10 +1035,16 @@ int hydamd_run_lf_coder(HydAmdContext *ctx, int num_slots, int last) {
         return ST_API_ERROR;
     if (!ctx->lf_on_device)
         return fail(ctx, ST_API_ERROR, "the LF coder is off");
-    if (num_slots < 1 || num_slots > ctx->transformed)
-        return fail(ctx, ST_API_ERROR, "the LF coder needs the transform stage of the same slots first");
+    if (num_slots < 1 || num_slots > ctx->max_slots)
+        return fail(ctx, ST_API_ERROR, "slot count out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false;
+    if (num_slots > ctx->transformed) { /* the LF coder reads the LF ints the transform stage writes */
+        const int st = transform_range(ctx, ctx->transformed, num_slots - ctx->transformed);
+        if (st != ST_OK)
+            return st;
+        ctx->transformed = num_slots;
+    }
     if (num_slots > ctx->lf_coded) {
         const int st = lf_range(ctx, ctx->lf_coded, num_slots - ctx->lf_coded, false);
         if (st != ST_OK)
@@ -1209,7 +1269,15 @@ int hydamd_read_tokens(HydAmdContext *ctx, int slot, int group, uint64_t *dst, s
     if (group < 0 || group >= HYDK_GROUPS_PER_LFG || capacity > HYDK_TOKENS_PER_GROUP)
         return fail(ctx, ST_API_ERROR, "group or capacity out of range");
     const uint64_t *src = ctx->tokens + ((size_t)slot * HYDK_GROUPS_PER_LFG + group) * HYDK_TOKENS_PER_GROUP;
-    HIP_TRY(ctx, hipMemcpy(dst, src, capacity * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (ctx->h_jobs[slot].fmt == HYDK_FMT_F32) {
+        HIP_TRY(ctx, hipMemcpy(dst, src, capacity * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        return ST_OK;
+    }
+    /* integer input: 4-byte records on the device, widened to the documented form here */
+    std::vector<uint32_t> narrow(capacity);
+    HIP_TRY(ctx, hipMemcpy(narrow.data(), src, capacity * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < capacity; i++)
+        dst[i] = ((uint64_t)(narrow[i] >> 16) << 32) | HYDK_REC32_TO_LO(narrow[i]);
     return ST_OK;
 }
 

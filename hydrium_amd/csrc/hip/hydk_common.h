@@ -28,6 +28,12 @@
 /* Token record (8 bytes) written by the transform kernel and read by the rANS kernel:
  *   lo: bits 0-7 token, 8-11 preset-local cluster, 16-21 residue bit count;  hi: residue bits. */
 #define HYDK_REC_LO(token, cluster, rbits) ((uint32_t)(token) | ((uint32_t)(cluster) << 8) | ((uint32_t)(rbits) << 16))
+/* Integer sample formats bound every quantised coefficient below 2^13 (K1), so their record fits 4 bytes:
+ *   bits 0-6 token, 7-10 preset-local cluster, 11-15 residue bit count, 16-31 residue bits.
+ * HYDK_REC32_TO_LO turns one back into the lo word of the 8-byte form. */
+#define HYDK_REC32(token, cluster, rbits, residue) \
+    ((uint32_t)(token) | ((uint32_t)(cluster) << 7) | ((uint32_t)(rbits) << 11) | ((uint32_t)(residue) << 16))
+#define HYDK_REC32_TO_LO(r) (((r) & 0x7Fu) | ((((r) >> 7) & 0xFu) << 8) | ((((r) >> 11) & 0x1Fu) << 16))
 
 /* Per-LF-group ANS coding tables produced by the table kernel, consumed by the rANS kernel. */
 typedef struct HydkTables {
@@ -64,7 +70,7 @@ typedef struct HydkLfJob {
     const uint16_t *in_lut8;   /* 256 entries   */
     const uint16_t *in_lut16;  /* 65536 entries */
     const float *bias_lut;     /* 65536 entries */
-    uint64_t *tokens;        /* [groups][HYDK_TOKENS_PER_GROUP] */
+    void *tokens;            /* [groups][HYDK_TOKENS_PER_GROUP] records of 8 bytes (float input) or 4 (integer input) at an 8-byte group pitch */
     uint32_t *sym_count;     /* [groups] */
     uint32_t *hist;          /* [HYDK_MAX_CLUSTERS][HYDK_ALPHABET], zeroed before launch */
     uint32_t *alpha_max;     /* [1] largest token + 1 over this LF group's symbols, zeroed before launch */

@@ -278,6 +278,45 @@ extern "C" __attribute__((visibility("default"))) int hydamd_debug_phase_ticks(u
  * Token order inside a group is block raster, channels Y, X, B (encoder.c:707-745), which the
  * strip order + prefix sum reproduces.  The next strip's pixels are in flight during B and C.
  * ======================================================================================== */
+/* inclusive prefix sums in registers (DPP), no LDS round trips */
+#define HYDK_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xF, false))
+__device__ __forceinline__ uint32_t scan16_inclusive(uint32_t v) { /* within each 16-lane row */
+    v += HYDK_DPP(v, 0x111, 0xF); /* row_shr:1 */
+    v += HYDK_DPP(v, 0x112, 0xF); /* row_shr:2 */
+    v += HYDK_DPP(v, 0x114, 0xF); /* row_shr:4 */
+    v += HYDK_DPP(v, 0x118, 0xF); /* row_shr:8 */
+    return v;
+}
+__device__ __forceinline__ uint32_t scan64_inclusive(uint32_t v) {
+    v = scan16_inclusive(v);
+    v += HYDK_DPP(v, 0x142, 0xA); /* row_bcast:15 into rows 1 and 3 */
+    v += HYDK_DPP(v, 0x143, 0xC); /* row_bcast:31 into rows 2 and 3 */
+    return v;
+}
+
+/* OR of a 32-bit value over the 8 lanes of a varblock's thread group, in three DPP steps: the two
+ * quad permutes complete each quad, row_half_mirror (lane i <-> 7 - i inside each half row) then
+ * pairs every lane with one of the other quad */
+__device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  /* quad_perm:[1,0,3,2] */
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);  /* quad_perm:[2,3,0,1] */
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); /* row_half_mirror */
+    return v;
+}
+
+/* Token records.  Integer input: |quantised coefficient| <= 0.42 * 1969 * 5 < 2^13 (XYB is bounded by the
+ * bias LUT's range and the scaled DCT has unit gain), so token < 64, residue < 2^13 and one record fits
+ * 32 bits: token | cluster << 7 | residue bit count << 11 | residue << 16.  Float input has no such
+ * bound and keeps the 8-byte record: lo = token | cluster << 8 | bit count << 16, hi = residue. */
+template <int FMT>
+__device__ __forceinline__ void store_record(void *tok, uint32_t at, uint32_t token, uint32_t cluster, uint32_t rbits,
+                                             uint32_t residue) {
+    if (FMT == HYDK_FMT_F32)
+        ((uint64_t *)tok)[at] = ((uint64_t)residue << 32) | HYDK_REC_LO(token, cluster, rbits);
+    else
+        ((uint32_t *)tok)[at] = HYDK_REC32(token, cluster, rbits, residue);
+}
+
 template <int FMT, int XMODE>
 __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
     typedef typename SampleOf<FMT>::type sample_t;
@@ -289,15 +328,20 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
     if ((int)(blockIdx.x & 63) >= job.gcols * job.grows)
         return;
 
-    __shared__ float s_rowpass[3 * kS0Chan];          /* [c][block][y][kh], 27.0 KiB */
-    __shared__ uint32_t s_cnt[96];                    /* symbols per emission slot e = 3*block + visit */
-    __shared__ uint32_t s_off[97];                    /* their exclusive prefix sums + strip total */
-    __shared__ uint32_t s_hist[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
+    /* [c][block][kv][kh]: row-pass output, overwritten in place by the quantised coefficients, 27.0 KiB */
+    __shared__ float s_rowpass[3 * kS0Chan];
+    __shared__ uint32_t s_btot[32];                   /* symbols of each varblock of the strip (three channels) */
+    __shared__ uint32_t s_boff[4][33];                /* per wave: their exclusive prefix sums + strip total */
+    /* integer input cannot produce a token above 35 (see store_record): half the histogram suffices,
+     * which is what lets two of these workgroups fit beside an entropy-stage workgroup */
+    constexpr int kHistW = FMT == HYDK_FMT_F32 ? HYDK_ALPHABET : HYDK_ALPHABET / 2;
+    __shared__ uint32_t s_hist[HYDK_MAX_CLUSTERS * kHistW];
     __shared__ uint16_t s_lut8[256];
     __shared__ uint8_t s_nnz3[64];                    /* coefficient-count context offset (encoder.c:60-66) mod 3 */
-    __shared__ uint8_t s_fc3[64];                     /* frequency context of zig-zag position j (encoder.c:53-58) mod 3 */
-    __shared__ uint8_t s_zz[64];                      /* zig-zag index of coefficient (kv, kh) at [kv*8 + kh] */
-    __shared__ float s_wq[3 * 64];                    /* quantisation weight by channel and zig-zag index */
+    __shared__ uint8_t s_jinfo[64][2];                /* zig-zag position j -> {natural index kv*8+kh, frequency context (encoder.c:53-58) mod 3} */
+    __shared__ unsigned long long s_below[64];        /* bits 0..j-1 */
+    __shared__ unsigned long long s_nibmask[8][2][16]; /* [kh][kv nibble][4 non-zero flags] -> their zig-zag bits */
+    __shared__ float s_wq[3 * 64];                    /* quantisation weight by channel and natural index */
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -308,24 +352,31 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
     const int gw = min(256, job.width - px0), gh = min(256, job.height - py0);
     const int gbw = (gw + 7) >> 3, gbh = (gh + 7) >> 3;
 
-    for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads)
+    for (int i = t; i < HYDK_MAX_CLUSTERS * kHistW; i += kThreads)
         s_hist[i] = 0;
     if (FMT == HYDK_FMT_U8)
         s_lut8[t] = job.in_lut8[t];
     if (t < 64) {
+        /* t as a natural index (kv, kh): where it sits in zig-zag order; t as a zig-zag position: its contexts */
         const int j = t;
         s_nnz3[t] = kNnzCtx[t] % 3;
-        s_fc3[t] = (uint8_t)((j < 2 ? 0 : j < 16 ? j - 1 : j < 32 ? 15 + ((j - 16) >> 1) : 23 + ((j - 32) >> 2)) % 3);
-        s_zz[t] = kZigzag[t >> 3][t & 7];
+        s_jinfo[kZigzag[t >> 3][t & 7]][0] = (uint8_t)t;
+        s_jinfo[t][1] = (uint8_t)((j < 2 ? 0 : j < 16 ? j - 1 : j < 32 ? 15 + ((j - 16) >> 1) : 23 + ((j - 32) >> 2)) % 3);
+        s_below[t] = (1ull << t) - 1ull;
     }
     if (t < 192)
-        s_wq[t] = (float)kQuantWeight[t >> 6][t & 63];
-    if (t < 96)
-        s_cnt[t] = 0;
+        s_wq[t] = (float)kQuantWeight[t >> 6][kZigzag[(t >> 3) & 7][t & 7]];
+    {
+        /* thread = (kh, half, pattern): OR of the zig-zag bits of coefficients (4*half + b, kh), b in pattern */
+        const int kh_ = t >> 5, half = (t >> 4) & 1, pat = t & 15;
+        unsigned long long m = 0;
+        for (int b = 0; b < 4; b++)
+            if (pat >> b & 1)
+                m |= 1ull << kZigzag[4 * half + b][kh_];
+        s_nibmask[kh_][half][pat] = m;
+    }
 
-    /* column / token phases: thread (block cb, horizontal frequency kh) owns the coefficients
-     * (kv, kh), kv = 0..7, whose zig-zag indices are s_zz[kv*8 + kh]; the small per-coefficient
-     * constants live in LDS rather than in 40 registers, which buys a third wave per SIMD */
+    /* column / token phases: thread (block cb, horizontal frequency kh) */
     const int cb = t >> 3, kh = t & 7;
     /* first cluster holding coefficient contexts, by scheme (encoder.c:862-901) */
     const int coef_cl_lo = job.scheme == 0 ? 3 : job.scheme == 3 ? 0 : 1;
@@ -355,7 +406,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
     };
     prefetch(0);
 
-    uint64_t *const tok = job.tokens + (size_t)g * HYDK_TOKENS_PER_GROUP;
+    void *const tok = (char *)job.tokens + (size_t)g * HYDK_TOKENS_PER_GROUP * sizeof(uint64_t);
     uint32_t goff = 0;
     unsigned long long zero_tokens = 0; /* six 10-bit counters: zero-valued coefficient tokens per cluster */
     bool bad_sample = false;
@@ -453,14 +504,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
         __syncthreads();
         HYDK_PHASE_MARK(2);
 
-        /* ---------------- phase B: column DCT, quantise, LF ints, non-zero bitmaps ---------------- */
-        int q[3][8];
-        unsigned long long msk[3];
+        /* ---------------- phase B: column DCT, quantise (in place in LDS), LF ints, non-zero bitmaps ---------------- */
+        unsigned long long msk[3] = {0, 0, 0}; /* per channel X, Y, B: non-zero coefficients by zig-zag position */
         if (cb < gbw) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 float col[8], v[8];
-                const float *src = s_rowpass + c * kS0Chan + cb * kS0Block + kh;
+                float *src = s_rowpass + c * kS0Chan + cb * kS0Block + kh;
 #pragma unroll
                 for (int n = 0; n < 8; n++)
                     col[n] = src[n * 8];
@@ -474,142 +524,131 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
                     for (int kv = 0; kv < 8; kv++)
                         d[kv] = v[kv];
                 }
-                unsigned long long m = 0;
+                uint32_t pat = 0; /* bit kv: coefficient (kv, kh) is non-zero */
+                int q[8];
 #pragma unroll
                 for (int kv = 0; kv < 8; kv++) {
-                    const int j = s_zz[kv * 8 + kh];
                     /* encoder.c:808-811: trunc((coef * weight) * 5); +-1 is the dead zone */
-                    int qq = (int)(v[kv] * s_wq[c * 64 + j] * 5.0f);
-                    if (qq > -2 && qq < 2)
-                        qq = 0;
-                    if (kv == 0 && kh == 0)
-                        qq = 0; /* the DC slot is coded by the LF path */
-                    q[c][kv] = qq;
-                    m |= (unsigned long long)(qq != 0) << j;
+                    int qq = (int)(v[kv] * s_wq[c * 64 + kv * 8 + kh] * 5.0f);
+                    const bool nz = (uint32_t)(qq + 1) > 2u && !(kv == 0 && kh == 0); /* the DC slot is coded by the LF path */
+                    qq = nz ? qq : 0;
+                    q[kv] = qq;
+                    pat |= (nz ? 1u : 0u) << kv;
+                    /* the thread's own column: nobody else reads or writes these eight words */
+                    ((int *)src)[kv * 8] = qq;
                 }
                 if (job.dbg_quant) {
                     int32_t *d = job.dbg_quant + (size_t)c * kDbgPitch * kDbgPitch +
                                  (size_t)(py0 + s * 8 + kh) * kDbgPitch + px0 + cb * 8;
 #pragma unroll
                     for (int kv = 0; kv < 8; kv++)
-                        d[kv] = q[c][kv];
+                        d[kv] = q[kv];
                 }
-                m |= __shfl_xor(m, 1);
-                m |= __shfl_xor(m, 2);
-                m |= __shfl_xor(m, 4);
-                msk[c] = m;
-                if (kh == 0) {
-                    /* emission slot: visit order Y, X, B (encoder.c:712); symbols = count symbol +
-                     * coefficients up to the last non-zero one */
-                    const int visit = c == 1 ? 0 : c == 0 ? 1 : 2;
-                    s_cnt[cb * 3 + visit] = 1u + (m ? 63u - (uint32_t)__clzll(m) : 0u);
-                    /* LF int: trunc(dc * shift[c]) (encoder.c:573,582) */
+                const unsigned long long mine = s_nibmask[kh][0][pat & 15u] | s_nibmask[kh][1][pat >> 4];
+                const uint32_t lo = or_reduce8((uint32_t)mine), hi = or_reduce8((uint32_t)(mine >> 32));
+                msk[c] = ((unsigned long long)hi << 32) | lo;
+                if (kh == 0) /* LF int: trunc(dc * shift[c]) (encoder.c:573,582) */
                     job.dc[(size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH + (size_t)((py0 >> 3) + s) * HYDK_DC_PITCH +
                            (px0 >> 3) + cb] = (int32_t)(v[0] * kLfShift[c]);
-                }
             }
         }
+        /* symbols per channel: the count symbol + coefficients up to the last non-zero one; visit order
+         * Y, X, B (encoder.c:712) */
+        const uint32_t nY = 1u + (msk[1] ? 63u - (uint32_t)__clzll(msk[1]) : 0u);
+        const uint32_t nX = 1u + (msk[0] ? 63u - (uint32_t)__clzll(msk[0]) : 0u);
+        const uint32_t nB = 1u + (msk[2] ? 63u - (uint32_t)__clzll(msk[2]) : 0u);
+        const uint32_t nblock = cb < gbw ? nY + nX + nB : 0u;
+        if (kh == 0)
+            s_btot[cb] = nblock;
         HYDK_PHASE_MARK(3);
         __syncthreads();
         HYDK_PHASE_MARK(4);
 
-        /* ---------------- phase C1: offsets of the 96 emission slots ---------------- */
-        if (wave == 0) {
-            const uint32_t c0 = s_cnt[lane], c1 = lane < 32 ? s_cnt[64 + lane] : 0u;
-            uint32_t inc0 = c0, inc1 = c1;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t a = __shfl_up(inc0, d), b2 = __shfl_up(inc1, d);
-                if (lane >= d) {
-                    inc0 += a;
-                    inc1 += b2;
-                }
-            }
-            const uint32_t total0 = __shfl(inc0, 63);
-            s_off[lane] = inc0 - c0;
-            if (lane < 32)
-                s_off[64 + lane] = total0 + inc1 - c1;
-            if (lane == 31)
-                s_off[96] = total0 + inc1;
+        /* ---------------- phase C1: every wave prefix-sums the 32 block totals for itself ---------------- */
+        {
+            const uint32_t mine = s_btot[lane & 31];
+            uint32_t inc = scan16_inclusive(mine);
+            inc += HYDK_DPP(inc, 0x142, 0xA); /* row_bcast:15: rows 1 and 3 add the total of the row before */
+            s_boff[wave][(lane & 31) + 1] = inc;
+            if (lane == 0)
+                s_boff[wave][0] = 0;
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
+        const uint32_t boff = s_boff[wave][cb], strip_total = s_boff[wave][32];
         HYDK_PHASE_MARK(5);
 
-        /* ---------------- phase C2: every thread emits the symbols of its own coefficients ---------------- */
-        if (cb < gbw) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const int visit = c == 1 ? 0 : c == 0 ? 1 : 2;
-                const unsigned long long m = msk[c];
-                const int nz_total = __popcll(m);
-                const int jlast = m ? 63 - __clzll(m) : 0;
-                uint64_t *const dst = tok + goff + s_off[cb * 3 + visit];
-#pragma unroll
-                for (int kv = 0; kv < 8; kv++) {
-                    const int j = s_zz[kv * 8 + kh];
-                    if (j > jlast)
-                        continue;
-                    uint32_t value;
-                    int cluster;
-                    if (kv == 0 && kh == 0) {
-                        /* j == 0: the non-zero count.  Its context only matters through the cluster, which
-                         * depends on the visit index alone in every scheme (encoder.c:715,865-869,882,895,900) */
-                        value = (uint32_t)nz_total;
-                        cluster = job.scheme == 0 ? visit : 0;
+        /* ---------------- phase C2: the block's symbols, dealt round-robin to its eight threads ---------------- */
+        {
+            const uint32_t tY = (uint32_t)__popcll(msk[1]), tX = (uint32_t)__popcll(msk[0]), tB = (uint32_t)__popcll(msk[2]);
+            const uint32_t first = goff + boff;
+            for (uint32_t i = (uint32_t)kh; i < nblock; i += 8u) {
+                /* i-th symbol of the block: which channel, which zig-zag position */
+                const bool inX = i >= nY, inB = i >= nY + nX;
+                const int visit = (int)inX + (int)inB;
+                const uint32_t j = i - (inX ? nY : 0u) - (inB ? nX : 0u);
+                const unsigned long long m = inB ? msk[2] : inX ? msk[0] : msk[1];
+                const uint32_t nz_total = inB ? tB : inX ? tX : tY;
+                const int plane = inB ? 2 * kS0Chan : inX ? 0 : kS0Chan;
+                uint32_t value;
+                int cluster;
+                if (j == 0) {
+                    /* the non-zero count.  Its context only matters through the cluster, which
+                     * depends on the visit index alone in every scheme (encoder.c:715,865-869,882,895,900) */
+                    value = nz_total;
+                    cluster = job.scheme == 0 ? visit : 0;
+                } else {
+                    const uint32_t nat = s_jinfo[j][0];
+                    value = pack_signed(((const int *)s_rowpass)[plane + cb * kS0Block + (int)nat]);
+                    /* non-zeros still to come before this coefficient (encoder.c:732,738) */
+                    const uint32_t remaining = nz_total - (uint32_t)__popcll(m & s_below[j]);
+                    const int prev = j == 1 ? (nz_total <= 4) : (int)((m >> (j - 1)) & 1ull);
+                    /* context - 111 = 458*visit + prev + 2*(nnz_ctx[remaining] + freq_ctx[j]) (encoder.c:724,731-732);
+                     * scheme 0 needs it mod 6 = prev + 2*((visit + nnz_ctx + freq_ctx) mod 3), the others mod 2 = prev */
+                    if (job.scheme == 0) {
+                        const int u = visit + (int)s_nnz3[remaining & 63] + (int)s_jinfo[j][1]; /* 0..6 */
+                        cluster = 3 + prev + 2 * (u - 3 * ((u * 11) >> 5));
                     } else {
-                        value = pack_signed(q[c][kv]);
-                        /* non-zeros still to come before this coefficient (encoder.c:732,738) */
-                        const int remaining = nz_total - __popcll(m & ((1ull << j) - 1ull));
-                        const int prev = j == 1 ? (nz_total <= 4) : (int)((m >> (j - 1)) & 1ull);
-                        /* context - 111 = 458*visit + prev + 2*(nnz_ctx[remaining] + freq_ctx[j]) (encoder.c:724,731-732);
-                         * scheme 0 needs it mod 6 = prev + 2*((visit + nnz_ctx + freq_ctx) mod 3), the others mod 2 = prev */
-                        if (job.scheme == 0) {
-                            const int u = visit + (int)s_nnz3[remaining & 63] + (int)s_fc3[j]; /* 0..6 */
-                            cluster = 3 + prev + 2 * (u - 3 * ((u * 11) >> 5));
-                        } else {
-                            cluster = job.scheme == 1 ? 1 + prev : job.scheme == 2 ? 1 : 0;
-                        }
+                        cluster = job.scheme == 1 ? 1 + prev : job.scheme == 2 ? 1 : 0;
                     }
-                    /* hybrid-uint split, config (4,1,0) (entropy.c:427-444) */
-                    uint32_t token, rbits, residue;
-                    if (value < 16) {
-                        token = value;
-                        rbits = 0;
-                        residue = 0;
-                    } else {
-                        const int n = 30 - __clz((int)value); /* floor(log2) - 1 */
-                        rbits = (uint32_t)n;
-                        residue = value & ((1u << n) - 1u);
-                        token = 16u + (((uint32_t)(n - 3) << 1) | ((value >> n) & 1u));
-                    }
-                    dst[j] = ((uint64_t)residue << 32) | HYDK_REC_LO(token, cluster, rbits);
-                    if (token == 0 && !(kv == 0 && kh == 0))
-                        zero_tokens += 1ull << (10 * (cluster - coef_cl_lo)); /* at most 24 x 32 per thread and group */
-                    else
-                        atomicAdd(&s_hist[cluster * HYDK_ALPHABET + token], 1u);
                 }
+                /* hybrid-uint split, config (4,1,0) (entropy.c:427-444) */
+                uint32_t token, rbits, residue;
+                if (value < 16) {
+                    token = value;
+                    rbits = 0;
+                    residue = 0;
+                } else {
+                    const int n = 30 - __clz((int)value); /* floor(log2) - 1 */
+                    rbits = (uint32_t)n;
+                    residue = value & ((1u << n) - 1u);
+                    token = 16u + (((uint32_t)(n - 3) << 1) | ((value >> n) & 1u));
+                }
+                store_record<FMT>(tok, first + i, token, (uint32_t)cluster, rbits, residue);
+                if (token == 0 && j != 0)
+                    zero_tokens += 1ull << (10 * (cluster - coef_cl_lo)); /* at most 24 x 32 per thread and group */
+                else
+                    atomicAdd(&s_hist[cluster * kHistW + (int)min(token, (uint32_t)kHistW - 1u)], 1u);
             }
         }
-        goff += s_off[96];
+        goff += strip_total;
         HYDK_PHASE_MARK(6);
-        /* no barrier here: s_off is rewritten only after the next strip's two barriers, s_cnt
-         * after its first, s_rowpass is last read before this strip's second barrier */
+        /* the next strip's row pass overwrites the coefficients this strip's token phase reads */
+        __syncthreads();
     }
-    __syncthreads();
 
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         const uint32_t n0 = (uint32_t)(zero_tokens >> (10 * k)) & 1023u;
         if (n0)
-            atomicAdd(&s_hist[(coef_cl_lo + k) * HYDK_ALPHABET], n0);
+            atomicAdd(&s_hist[(coef_cl_lo + k) * kHistW], n0);
     }
     __syncthreads();
     uint32_t top_token = 0;
-    for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads) {
+    for (int i = t; i < HYDK_MAX_CLUSTERS * kHistW; i += kThreads) {
         const uint32_t v = s_hist[i];
         if (v) {
-            atomicAdd(&job.hist[i], v);
-            top_token = max(top_token, (uint32_t)(i % HYDK_ALPHABET) + 1u);
+            atomicAdd(&job.hist[(i / kHistW) * HYDK_ALPHABET + i % kHistW], v);
+            top_token = max(top_token, (uint32_t)(i % kHistW) + 1u);
         }
     }
 #pragma unroll
@@ -807,22 +846,6 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
     }
 }
 
-/* inclusive prefix sums in registers (DPP), no LDS round trips */
-#define HYDK_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xF, false))
-__device__ __forceinline__ uint32_t scan16_inclusive(uint32_t v) { /* within each 16-lane row */
-    v += HYDK_DPP(v, 0x111, 0xF); /* row_shr:1 */
-    v += HYDK_DPP(v, 0x112, 0xF); /* row_shr:2 */
-    v += HYDK_DPP(v, 0x114, 0xF); /* row_shr:4 */
-    v += HYDK_DPP(v, 0x118, 0xF); /* row_shr:8 */
-    return v;
-}
-__device__ __forceinline__ uint32_t scan64_inclusive(uint32_t v) {
-    v = scan16_inclusive(v);
-    v += HYDK_DPP(v, 0x142, 0xA); /* row_bcast:15 into rows 1 and 3 */
-    v += HYDK_DPP(v, 0x143, 0xC); /* row_bcast:31 into rows 2 and 3 */
-    return v;
-}
-
 /* ==========================================================================================
  * K3a: reverse rANS.  One wave per group, 4 groups of one LF group per workgroup (they share the
  * preset's tables in LDS).  The state -> state recurrence is strictly serial per group
@@ -839,6 +862,22 @@ __device__ __forceinline__ uint32_t scan64_inclusive(uint32_t v) {
  * grid = 16 x LF groups, block = 256.
  * ======================================================================================== */
 constexpr int kWinWords = 100; /* 64 symbols x 46 bits = 92 words + alignment slack */
+
+/* record p of a group in the 8-byte form {lo = token | cluster << 8 | bit count << 16, hi = residue},
+ * whichever form K1 wrote (hydk_common.h); p < 0 reads nothing */
+__device__ __forceinline__ uint2 load_record(const void *tok, int p, bool wide) {
+    uint2 r = {0u, 0u};
+    if (p >= 0) {
+        if (wide) {
+            r = ((const uint2 *)tok)[p];
+        } else {
+            const uint32_t v = ((const uint32_t *)tok)[p];
+            r.x = HYDK_REC32_TO_LO(v);
+            r.y = v >> 16;
+        }
+    }
+    return r;
+}
 constexpr int kInvEntries = HYDK_MAX_CLUSTERS * 2 * HYDK_ANS_SLOTS;
 
 /* x = state > thr ? state >> 16 : state in two issue slots: the select reads the high half of the
@@ -920,6 +959,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
 
     const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + g;
     const uint64_t *tok = tokens_all + G * HYDK_TOKENS_PER_GROUP;
+    const bool wide = jobs[slot].fmt == HYDK_FMT_F32;
     uint32_t *W = bitbuf_all + G * HYDK_BITWORDS_PER_GROUP;
     uint32_t *win = s_win[wave];
     uint4 *ops = s_ops[wave];
@@ -972,14 +1012,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
         cur = newcur;
     };
 
-    uint64_t rec_next = n - 1 - lane >= 0 ? tok[n - 1 - lane] : 0ull;
+    uint2 rec_next = load_record(tok, n - 1 - lane, wide);
     for (int hi_p = n - 1; hi_p >= 0; hi_p -= 64) {
         /* lane l owns symbol p = hi_p - l; the walk visits lanes 0, 1, 2, ... */
         const int p = hi_p - lane;
         const bool valid = p >= 0;
-        const uint64_t rec = rec_next;
-        rec_next = p - 64 >= 0 ? tok[p - 64] : 0ull; /* the next chunk's records travel during this chunk's walk */
-        const uint32_t lo = (uint32_t)rec;
+        const uint2 rec = rec_next;
+        rec_next = load_record(tok, p - 64, wide); /* the next chunk's records travel during this chunk's walk */
+        const uint32_t lo = rec.x;
         const uint32_t e = ((lo >> 8) & 0xF) * HYDK_ALPHABET + (lo & 0xFF);
         const uint32_t fbv = s_fb[e];
         const uint32_t f = valid ? (fbv & 0xFFFFu) : 1u;
@@ -1010,7 +1050,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
         /* refill p is written just before residue p (entropy.c:1134-1147), i.e. prepended after it */
         const uint32_t rbits = valid ? (lo >> 16) & 0x3Fu : 0u;
         const bool refill = valid && seen > thr;
-        const unsigned long long residue = rec >> 32;
+        const unsigned long long residue = rec.y;
         const unsigned long long val = refill ? (residue << 16) | (seen & 0xFFFFu) : residue;
         emit(val, rbits + (refill ? 16u : 0u));
     }
@@ -1089,6 +1129,7 @@ __device__ __forceinline__ void rans_rows_body(const HydkLfJob *__restrict__ job
     const bool live = g < ngroups;
     const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + g;
     const uint64_t *tok = tokens_all + G * HYDK_TOKENS_PER_GROUP;
+    const bool wide = jobs[slot].fmt == HYDK_FMT_F32;
     uint32_t *W = bitbuf_all + G * HYDK_BITWORDS_PER_GROUP;
     uint32_t *win = s_win[wave][row];
     uint4 *ops = s_ops[wave][row];
@@ -1139,16 +1180,15 @@ __device__ __forceinline__ void rans_rows_body(const HydkLfJob *__restrict__ job
         cur = newcur;
     };
 
-    uint64_t rec_next = n - 1 - l >= 0 ? tok[n - 1 - l] : 0ull;
+    uint2 rec_next = load_record(tok, n - 1 - l, wide);
     for (int base = 0; base < nmax; base += 16) {
         /* lane l of a row owns symbol p = (n - 1 - base) - l, walked at step l */
         const int hi_p = n - 1 - base;
         const int p = hi_p - l;
         const bool valid = p >= 0;
-        const uint64_t rec = rec_next;
-        const int pn = p - 16;
-        rec_next = pn >= 0 ? tok[pn] : 0ull; /* next round's records are in flight during this round's walk */
-        const uint32_t lo = (uint32_t)rec;
+        const uint2 rec = rec_next;
+        rec_next = load_record(tok, p - 16, wide); /* next round's records are in flight during this round's walk */
+        const uint32_t lo = rec.x;
         const uint32_t e = ((lo >> 8) & 0xF) * HYDK_ALPHABET + (lo & 0xFF);
         const uint32_t fbv = s_fb[e];
         const uint32_t f = valid ? (fbv & 0xFFFFu) : 1u;
@@ -1201,7 +1241,7 @@ __device__ __forceinline__ void rans_rows_body(const HydkLfJob *__restrict__ job
                                          : (uint32_t)__shfl((int)trail, (cnt - 1 - l) & 15, 16);
         const uint32_t rbits = valid ? (lo >> 16) & 0x3Fu : 0u;
         const bool refill = valid && seen > thr;
-        const unsigned long long residue = rec >> 32;
+        const unsigned long long residue = rec.y;
         const unsigned long long val = refill ? (residue << 16) | (seen & 0xFFFFu) : residue;
         emit(val, valid ? rbits + (refill ? 16u : 0u) : 0u);
     }
@@ -1239,6 +1279,231 @@ void k_rans_rows_half(
     const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all, const uint32_t *sym_count_all, const HydkTables *tabs,
     uint32_t *bitbuf_all, uint32_t *group_bits_all, int preset_bits) {
     rans_rows_body<8, false>(jobs, tokens_all, sym_count_all, tabs, bitbuf_all, group_bits_all, preset_bits);
+}
+
+/* ==========================================================================================
+ * K3a, throughput form: one LANE per group.  A wavefront carries the 64 chains of one LF group, so
+ * every instruction of the serial walk advances 64 groups and the entropy stage of a frame is a
+ * handful of wavefronts (one per LF group) instead of hundreds: ~0.3 instructions per symbol where
+ * the row forms need 4.5.  The chain only records what the bit writer needs — the 16 bits each
+ * refill would send and a flag — and k_rans_emit turns records into bits, wave-parallel.
+ *
+ * Memory shape: every lane streams its own group.  A round is 16 symbols, aligned to the START of
+ * the group's token array, so a lane reads one aligned 64-byte line of 4-byte records per round and
+ * writes one 32-byte sector of refill words (its 16 u16) — whole sectors, no transposition.  The
+ * round that holds the end of the stream is partial and comes first for every lane (lanes start
+ * together from their own ends and finish at different times).
+ * Integer sample formats only (4-byte records); float frames use k_rans_encode.
+ * grid = LF groups, block = 64.
+ * ======================================================================================== */
+struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs besides the state */
+    uint32_t thr;   /* (f << 20) - 1: renormalise when state > thr (entropy.c:1092) */
+    uint32_t magic; /* floor(2^32 / f) */
+    uint32_t negf;  /* -f */
+    uint32_t tab2;  /* byte offset of the symbol's slot list in s_inv: 2 * (cluster * 4096 + base) */
+};
+
+__global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
+                                                   const uint32_t *sym_count_all, const HydkTables *tabs,
+                                                   uint16_t *aux_all, uint16_t *flags_all, uint32_t *final_state_all,
+                                                   int nclusters) {
+    __shared__ uint16_t s_inv[kInvEntries / 2];                       /* plain inverse slot table, 72 KiB */
+    __shared__ uint4 s_ops[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];        /* 18 KiB */
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x;
+    const int ngroups = jobs[slot].gcols * jobs[slot].grows;
+    const HydkTables *tab = tabs + slot;
+    {
+        const uint4 *src = (const uint4 *)&tab->inv1[0][0];
+        uint4 *dst = (uint4 *)s_inv;
+        for (int i = lane; i < nclusters * HYDK_ANS_SLOTS / 8; i += 64)
+            dst[i] = src[i];
+        for (int i = lane; i < nclusters * HYDK_ALPHABET; i += 64) {
+            const uint32_t fbv = (&tab->fb[0][0])[i], f = fbv & 0xFFFFu;
+            uint4 o;
+            o.x = f ? (f << 20) - 1u : 0xFFFFFFFFu;
+            o.y = (&tab->magic[0][0])[i];
+            o.z = 0u - f;
+            o.w = 2u * ((uint32_t)(i / HYDK_ALPHABET) * HYDK_ANS_SLOTS + (fbv >> 16));
+            s_ops[i] = o;
+        }
+    }
+    __syncthreads();
+    const unsigned char *inv_bytes = (const unsigned char *)s_inv;
+    const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + lane;
+    const int n = lane < ngroups ? (int)sym_count_all[G] : 0;
+    const uint4 *tok = (const uint4 *)(tokens_all + G * HYDK_TOKENS_PER_GROUP); /* 4-byte records, 4 per uint4 */
+    uint4 *aux = (uint4 *)(aux_all + G * HYDK_TOKENS_PER_GROUP);                 /* u16 per symbol, 8 per uint4 */
+    uint16_t *flags = flags_all + G * (HYDK_TOKENS_PER_GROUP / 16);
+    int rj = ((n + 15) >> 4) - 1; /* this lane's current round = 16-symbol chunk index; -1: nothing (left) to do */
+    int rounds = rj + 1;
+#pragma unroll
+    for (int d = 32; d; d >>= 1)
+        rounds = max(rounds, __shfl_xor(rounds, d));
+    rounds = __builtin_amdgcn_readfirstlane(rounds);
+    const int first_count = n - 16 * rj; /* symbols in the lane's first (partial) round: 1..16 */
+
+    uint32_t state;
+    asm volatile("v_mov_b32 %0, 0x130000" : "=v"(state));
+    uint4 nx[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        nx[q] = rj >= 0 ? tok[rj * 4 + q] : uint4{0, 0, 0, 0};
+
+/* one symbol: record `rec` (position `pos` of the round, walked from 15 down to 0); PRED: the step
+ * only counts if VALID (first round of a lane) */
+#define HYDK_LANE_STEP(rec, pos, PRED, VALID)                                                                    \
+    do {                                                                                                         \
+        const uint4 o = s_ops[(PRED) && !(VALID) ? 0u : (rec) & 0x7FFu]; /* beyond the stream's end: stale bytes */ \
+        uint32_t x;                                                                                              \
+        /* refill test, renormalised state, and the flag shifted into the round's flag word */                  \
+        asm("v_cmp_gt_u32 vcc, %2, %3\n\t"                                                                       \
+            "v_cndmask_b32_sdwa %0, %2, %2, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
+            "v_addc_co_u32 %1, vcc, %1, %1, vcc"                                                                 \
+            : "=&v"(x), "+v"(fl)                                                                                 \
+            : "v"(state), "v"((PRED) && !(VALID) ? 0xFFFFFFFFu : o.x)                                            \
+            : "vcc");                                                                                            \
+        if ((pos) & 1) /* the walk goes down: the odd position of a pair comes first */                          \
+            w16[(pos) >> 1] = state << 16;                                                                       \
+        else                                                                                                     \
+            w16[(pos) >> 1] |= state & 0xFFFFu;                                                                  \
+        uint32_t q = __umulhi(x, o.y);                                                                           \
+        /* q is floor(x / f) or one less: both candidate remainders, the smaller (unsigned) is x mod f */        \
+        const uint32_t r0 = mad24(q, o.z, x);                                                                    \
+        const uint32_t r1 = r0 + o.z;                                                                            \
+        const uint32_t r = min(r0, r1);                                                                          \
+        q += (int)r1 >= 0;                                                                                       \
+        const uint32_t nstate = (q << 12) | *(const uint16_t *)(inv_bytes + o.w + 2u * r);                       \
+        state = (PRED) && !(VALID) ? state : nstate;                                                             \
+    } while (0)
+
+    for (int it = 0; it < rounds; it++) {
+        uint4 cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            cur[q] = nx[q];
+        const int rjn = rj - 1;
+        if (rjn >= 0) { /* the next round's line travels during this round's walk */
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                nx[q] = tok[rjn * 4 + q];
+        }
+        if (rj >= 0) {
+            uint32_t fl = 0;
+            uint32_t w16[8];
+            const uint32_t recs[16] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w,
+                                       cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w};
+            if (it == 0) {
+#pragma unroll
+                for (int pos = 15; pos >= 0; pos--)
+                    HYDK_LANE_STEP(recs[pos], pos, true, pos < first_count);
+            } else {
+#pragma unroll
+                for (int pos = 15; pos >= 0; pos--)
+                    HYDK_LANE_STEP(recs[pos], pos, false, true);
+            }
+            aux[rj * 2] = uint4{w16[0], w16[1], w16[2], w16[3]};
+            aux[rj * 2 + 1] = uint4{w16[4], w16[5], w16[6], w16[7]};
+            flags[rj] = (uint16_t)fl; /* bit (p mod 16): symbol p refills */
+        }
+        rj = rjn;
+    }
+#undef HYDK_LANE_STEP
+    if (lane < ngroups)
+        final_state_all[G] = state;
+}
+
+/* one wave per group: records + the chain's refill words -> bits, filled from the buffer's end
+ * (the emission half of k_rans_encode).  grid = 16 x LF groups, block = 256. */
+__global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
+                                                        const uint32_t *sym_count_all, const uint16_t *aux_all,
+                                                        const uint16_t *flags_all, const uint32_t *final_state_all,
+                                                        uint32_t *bitbuf_all, uint32_t *group_bits_all, int preset_bits) {
+    __shared__ uint32_t s_win[4][kWinWords];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int slot = blockIdx.x >> 4;
+    const int g = ((blockIdx.x & 15) << 2) + wave;
+    const int ngroups = jobs[slot].gcols * jobs[slot].grows;
+    const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + g;
+    if (g >= ngroups) {
+        if (lane == 0)
+            group_bits_all[G] = 0;
+        return;
+    }
+    const uint32_t *tok = (const uint32_t *)(tokens_all + G * HYDK_TOKENS_PER_GROUP);
+    const uint16_t *aux = aux_all + G * HYDK_TOKENS_PER_GROUP;
+    const uint16_t *flags = flags_all + G * (HYDK_TOKENS_PER_GROUP / 16);
+    uint32_t *W = bitbuf_all + G * HYDK_BITWORDS_PER_GROUP;
+    uint32_t *win = s_win[wave];
+    const int n = __builtin_amdgcn_readfirstlane((int)sym_count_all[G]);
+    uint32_t cur = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u;
+    uint32_t carry = 0;
+
+    /* identical to k_rans_encode's: lane 0 nearest the bits already written */
+    auto emit = [&](unsigned long long val, uint32_t nbits) {
+        const uint32_t inc = scan64_inclusive(nbits);
+        const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
+        if (!total)
+            return;
+        const uint32_t newcur = cur - total;
+        const uint32_t wlo = newcur >> 5, whi = (cur - 1u) >> 5;
+        const uint32_t nwords = whi - wlo + 1u;
+        for (uint32_t i = lane; i < nwords; i += 64)
+            win[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0 && (cur & 31u))
+            win[whi - wlo] = carry;
+        __builtin_amdgcn_wave_barrier();
+        if (nbits) {
+            const uint32_t pos = cur - inc - wlo * 32u;
+            const uint32_t w = pos >> 5, sh = pos & 31u;
+            const unsigned long long lo = val << sh;
+            if ((uint32_t)lo)
+                atomicOr(&win[w], (uint32_t)lo);
+            if ((uint32_t)(lo >> 32))
+                atomicOr(&win[w + 1], (uint32_t)(lo >> 32));
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool low_partial = (newcur & 31u) != 0;
+        for (uint32_t i = lane + (low_partial ? 1u : 0u); i < nwords; i += 64)
+            W[wlo + i] = win[i];
+        carry = low_partial ? win[0] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        cur = newcur;
+    };
+
+    for (int hi_p = n - 1; hi_p >= 0; hi_p -= 64) {
+        const int p = hi_p - lane;
+        uint32_t rec = 0, a = 0, fl = 0;
+        if (p >= 0) {
+            rec = tok[p];
+            a = aux[p];
+            fl = ((uint32_t)flags[p >> 4] >> (p & 15)) & 1u;
+        }
+        const uint32_t rbits = (rec >> 11) & 0x1Fu; /* 0 for p < 0 */
+        const unsigned long long residue = rec >> 16;
+        /* refill p is written just before residue p (entropy.c:1134-1147), i.e. prepended after it;
+         * at most 16 + 16 bits per symbol for integer input */
+        const unsigned long long val = fl ? (residue << 16) | a : residue;
+        emit(val, rbits + (fl ? 16u : 0u));
+    }
+    {
+        unsigned long long val = 0;
+        uint32_t nb = 0;
+        if (lane == 0 && n > 0) {
+            val = final_state_all[G];
+            nb = 32;
+        } else if (lane == 1) {
+            val = jobs[slot].preset;
+            nb = (uint32_t)preset_bits;
+        }
+        emit(val, nb);
+    }
+    if (lane == 0) {
+        if (cur & 31u)
+            W[cur >> 5] = carry;
+        group_bits_all[G] = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u - cur;
+    }
 }
 
 /* ==========================================================================================
@@ -1370,6 +1635,16 @@ hipError_t launch_rans_rows(const HydkLfJob *d_jobs, const uint64_t *tokens, con
     else
         hipLaunchKernelGGL((k_rans_rows<4, true>), dim3(num_slots * 4), dim3(256), 0, stream, d_jobs, tokens, sym_count, tabs,
                            bitbuf, group_bits, preset_bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
+                             uint16_t *aux, uint16_t *flags, uint32_t *final_state, uint32_t *bitbuf, uint32_t *group_bits,
+                             int preset_bits, int nclusters, int num_slots, hipStream_t stream) {
+    hipLaunchKernelGGL(k_rans_lanes, dim3(num_slots), dim3(64), 0, stream, d_jobs, tokens, sym_count, tabs, aux, flags,
+                       final_state, nclusters);
+    hipLaunchKernelGGL(k_rans_emit, dim3(num_slots * 16), dim3(kThreads), 0, stream, d_jobs, tokens, sym_count, aux, flags,
+                       final_state, bitbuf, group_bits, preset_bits);
     return hipGetLastError();
 }
 

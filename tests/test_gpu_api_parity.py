@@ -263,3 +263,52 @@ def test_a_tile_sent_twice_is_rejected(lib, image):
         assert enc.error_message() == "this tile was already sent"
         # the encoder is still usable: the missing tile completes the frame
         enc.check(enc.send_tile(img, 1, 0, 2048, 2048, is_last=1))
+
+
+_MIXED = r"""
+import ctypes as C, hashlib, sys
+import numpy as np
+from hydrium_amd import api, synth
+from oracle import refprobe
+
+def encode(lib, tiles):
+    out = bytearray()
+    with api.Encoder(lib) as enc:
+        enc.check(enc.set_metadata(2048 + 300, 200))
+        buf = (C.c_uint8 * (1 << 20))()
+        enc.check(enc.provide_output(buf))
+        for tx, img in enumerate(tiles):
+            h, w, _ = img.shape
+            isz = img.dtype.itemsize
+            p = img.ctypes.data
+            enc.check(enc.send_tile_ptrs([p, p + isz, p + 2 * isz], tx, 0, 3 * w, 3, -1, api._FMT[img.dtype]))
+            while True:
+                ret = enc.check(enc.flush())
+                code, n = enc.release_output()
+                out += C.string_at(buf, n)
+                enc.check(enc.provide_output(buf))
+                if ret != api.HYD_NEED_MORE_OUTPUT:
+                    break
+    return bytes(out)
+
+a = synth.make_image("photo", 2048, 200, 8)
+b = synth.make_image_f32("photo", 300, 200)
+got = encode(api.Library(), [a, b])
+print(len(got), hashlib.md5(got).hexdigest())
+if refprobe.available():
+    want = encode(refprobe.reference_library(), [a, b])
+    assert got == want, "mixed-format frame differs from the reference"
+    print("matches reference")
+"""
+
+
+@pytest.mark.parametrize("eager", ["1", "0"])
+def test_sample_format_may_change_between_tiles(eager):
+    """a u8 tile followed by an f32 tile grows the staging arena mid-frame; with the
+    transforms deferred (HYDAMD_EAGER=0) the first tile's pixels used to be freed before they were read."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, HYDAMD_EAGER=eager, PYTHONPATH=os.path.dirname(os.path.dirname(__file__)))
+    r = subprocess.run([sys.executable, "-c", _MIXED], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr

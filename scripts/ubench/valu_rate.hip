@@ -34,7 +34,7 @@ typedef float float2_ __attribute__((ext_vector_type(2)));
 #define I_LSHLADD(a)  asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a) : "v"(u0))
 #define I_BFE(a)      asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(a))
 #define I_PERM(a)     asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a) : "v"(u0), "v"(u1))
-#define I_CNDMASK(a)  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(u0))
+#define I_CNDMASK(a)  asm volatile("v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(u0) : "vcc") /* two instructions */
 #define I_CMP(a)      asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(a), "v"(u0) : "vcc")
 #define I_LSHL64(a)   asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(a) : "v"(u0))
 #define I_BCNT(a)     asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(a) : "v"(u0))
@@ -59,7 +59,7 @@ enum Kind { K_MUL_ADD, K_FMA, K_PKMUL_PKADD, K_PKFMA, K_MAD24, K_MULLO, K_MULHI,
 static const char *kNames[K_COUNT] = {
     "v_mul_f32 + v_add_f32 (non-fused pair)", "v_fma_f32", "v_pk_mul_f32 + v_pk_add_f32", "v_pk_fma_f32", "v_mad_u32_u24",
     "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_u32_u24", "v_add_u32", "v_add3_u32", "v_lshl_add_u32", "v_bfe_u32", "v_perm_b32",
-    "v_cndmask_b32 (vcc)", "v_cmp_gt_u32 (vcc)", "v_lshlrev_b64", "v_bcnt_u32_b32", "v_ffbh_u32", "v_cvt_f32_u32", "v_cvt_i32_f32",
+    "v_cmp_gt_u32 + v_cndmask_b32 (PAIR: halve)", "v_cmp_gt_u32 (vcc)", "v_lshlrev_b64", "v_bcnt_u32_b32", "v_ffbh_u32", "v_cvt_f32_u32", "v_cvt_i32_f32",
     "v_rcp_f32", "v_med3_i32", "v_mov_b32_dpp row_shr:1", "v_add_u32_dpp row_shr:1", "v_cvt_f32_u32_sdwa WORD_1",
     "v_mul_f32", "v_add_f32", "v_pk_mul_f32"};
 // lane-level arithmetic results per instruction (2 for packed forms)
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void k(float *out, long long *cyc, int iters, 
         u[i] = threadIdx.x * 2654435761u + i;
         w[i] = u[i];
     }
+    long long w0 = wall_clock64();
     long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; it++) {
 #define BODY8(M, T) if (CHAINS == 8) { REP8(M, T); REP8(M, T); } else { M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); M(T[0]); }
@@ -116,18 +117,44 @@ __global__ __launch_bounds__(256) void k(float *out, long long *cyc, int iters, 
         else if (KIND == K_PKMUL_ONLY) { BODY8(I_PKMUL, pf) }
     }
     long long t1 = __builtin_readcyclecounter();
+    long long w1 = wall_clock64();
     float acc = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
         acc += f[i] + pf[i].x + pf[i].y + (float)u[i] + (float)(unsigned)w[i];
     out[blockIdx.x * 256 + threadIdx.x] = acc;
-    if (threadIdx.x == 0 && blockIdx.x == 0)
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
         cyc[0] = t1 - t0;
+        cyc[1] = w1 - w0; /* constant-rate counter (hipDeviceAttributeWallClockRate) */
+    }
 }
+
+static bool g_swept = false;
 
 template <int KIND>
 static void run_kind(float *out, long long *cyc, int cus, double wall_khz) {
     const int iters_tp = 4000, iters_lat = 20000;
+    if (!g_swept) { /* once: how does the issue rate grow with the waves sharing a SIMD? */
+        g_swept = true;
+        for (int per_cu = 1; per_cu <= 8; per_cu *= 2) {
+            hipEvent_t a, b;
+            CK(hipEventCreate(&a));
+            CK(hipEventCreate(&b));
+            hipLaunchKernelGGL((k<KIND, 8>), dim3(cus * per_cu), dim3(256), 0, 0, out, cyc, iters_tp, 1.0f);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(a));
+            hipLaunchKernelGGL((k<KIND, 8>), dim3(cus * per_cu), dim3(256), 0, 0, out, cyc, iters_tp, 1.0f);
+            CK(hipEventRecord(b));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            long long c2[2];
+            CK(hipMemcpy(c2, cyc, 16, hipMemcpyDeviceToHost));
+            printf("  [%s] %d waves/SIMD: kernel %.3f ms, wave 0: %lld s_memtime ticks = %lld wall-clock ticks (100 MHz) -> s_memtime runs at %.1f MHz; %.2f ns per wave-instr per SIMD\n",
+                   kNames[KIND], per_cu, ms, c2[0], c2[1], c2[1] ? (double)c2[0] / c2[1] * 100.0 : 0.0,
+                   ms * 1e6 / ((double)per_cu * iters_tp * 16));
+        }
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -170,7 +197,7 @@ int main() {
     float *out;
     long long *cyc;
     CK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
-    CK(hipMalloc(&cyc, 8));
+    CK(hipMalloc(&cyc, 16));
 #define RUN(K) run_kind<K>(out, cyc, cus, wclk);
     RUN(K_MUL_ADD) RUN(K_MUL_ONLY) RUN(K_ADD_ONLY) RUN(K_FMA) RUN(K_PKMUL_PKADD) RUN(K_PKMUL_ONLY) RUN(K_PKFMA)
     RUN(K_MAD24) RUN(K_MULLO) RUN(K_MULHI) RUN(K_MULHI24) RUN(K_ADDU) RUN(K_ADD3) RUN(K_LSHLADD) RUN(K_BFE) RUN(K_PERM)

@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=16, choices=(8, 16))
     ap.add_argument("--kind", default="photo")
     ap.add_argument("--streams", type=int, default=16, help="frames in flight (one context + HIP stream each)")
-    ap.add_argument("--rans-waves", type=int, default=5, choices=(1, 2, 3, 4, 5),
+    ap.add_argument("--rans-waves", type=int, default=5, choices=(4, 5),
                     help="entropy-stage form, see hydamd_set_rans_waves: 5 = one lane per group, a wavefront per LF group "
                          "(throughput); 4 = one wave per group (lowest single-frame latency)")
     ap.add_argument("--lf-coder", default="on", choices=("on", "off"),

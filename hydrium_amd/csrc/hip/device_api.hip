@@ -1,17 +1,23 @@
 /*
  * device_api.hip — the thin C-ABI between the C host side and the HIP kernels (include/hydrium_amd.h).
  *
- * Memory plan (sized for 288 GB of HBM3E: nothing is ever reallocated on the hot path):
- *   per LF-group slot   tokens   64 groups x 196608 records x 8 B   = 100.7 MB  (hard worst case)
- *                       bitbuf   64 groups x 1.13 MB reversed bits  =  72.4 MB  (hard worst case)
- *                       tables   HydkTables                          =  86 KB
- *                       dc       3 x 256 x 256 int32                 = 768 KB
- *                       hist / counts / section bits+offsets         <   8 KB
- *                       LF coder: records 196608 x 8 B + bits        =   3.0 MB  (hard worst case)
+ * Memory plan.  Token storage is sized for the typical case and grown on demand, never on the hot
+ * path of a frame that fits:
+ *   per LF-group slot   tokens   64 groups x tok_cap records x 4 B (8 B once a float LF group is seen);
+ *                                tok_cap = 98304 = 1.5 symbols per pixel             =  25 MB
+ *                       aux      the lane-per-group entropy form's refill words, 2 B / record + 1 bit  =  13 MB
+ *                       payload  packed HF sections, 1 byte per pixel                =   4 MB
+ *                       tables   HydkTables                                          = 235 KB
+ *                       dc       3 x 256 x 256 int32                                 = 768 KB
+ *                       LF coder: records 196608 x 8 B + bits                        =   4.5 MB  (hard worst case)
  *   per context         in_lut8 (512 B), in_lut16 (128 KB), bias_lut (256 KB)
- *                       payload  packed HF sections, sized like bitbuf (its hard upper bound)
+ *                       bitbuf   only if the wave-per-group entropy form is used: reversed bit buffers,
+ *                                tok_cap x 46 bits per group                         =  36 MB per slot
  *                       2 x (pinned host + device) staging tiles for the host-pointer path
- * A 16384x16384 frame (64 slots) therefore pins 15.7 GB; an 8192x8192 frame 3.9 GB.
+ * A 16384x16384 frame (64 slots) holds 3.0 GB, an 8192x8192 frame 0.75 GB.  A frame that needs more
+ * (a group above 1.5 symbols per pixel: noise; or more than a byte per pixel of sections) raises a
+ * status bit on the device; hydamd_sync() then enlarges the arrays to their hard maximum and runs
+ * the frame again from the job descriptors it still holds (resolve_overflow).
  */
 #include <hip/hip_runtime.h>
 
@@ -36,18 +42,19 @@ hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt
                             hipStream_t stream);
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int first_slot,
                          int num_slots, uint32_t alpha_floor, hipStream_t stream);
-hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
-                       uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int waves,
+hipError_t launch_rans(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint32_t *bitbuf,
+                       uint32_t bit_pitch_words, uint32_t *group_bits, int preset_bits, int num_slots, const uint32_t *status,
                        hipStream_t stream);
-hipError_t launch_rans_rows(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
-                            uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int whole_lf_group,
-                            hipStream_t stream);
-hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
-                             uint16_t *aux, uint16_t *flags, uint32_t *final_state, uint32_t *bitbuf, uint32_t *group_bits,
-                             int preset_bits, int nclusters, int num_slots, hipStream_t stream);
-hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, hipStream_t stream);
-hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
-                       int count, hipStream_t stream);
+hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint16_t *aux,
+                             uint16_t *flags, uint32_t aux_pitch, uint32_t *final_state, uint32_t *group_bits, int preset_bits,
+                             int nclusters, int num_slots, const uint32_t *status, hipStream_t stream);
+hipError_t launch_rans_emit(const HydkLfJob *d_jobs, const uint32_t *sym_count, const uint16_t *aux, const uint16_t *flags,
+                            uint32_t aux_pitch, const uint32_t *final_state, const uint32_t *group_bits, const uint64_t *offsets,
+                            uint8_t *payload, int preset_bits, int num_slots, const uint32_t *status, hipStream_t stream);
+hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, uint8_t *payload,
+                       uint64_t payload_cap, int clear_shared_words, uint32_t *status, hipStream_t stream);
+hipError_t launch_pack(const uint32_t *bitbuf, uint32_t bit_pitch_words, const uint32_t *group_bits, const uint64_t *offsets,
+                       uint8_t *payload, int count, const uint32_t *status, hipStream_t stream);
 hipError_t launch_lf_coder(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, HydkLfStream *streams,
                            uint32_t *bits, int num_slots, hipStream_t stream);
 hipError_t launch_lf_gather(HydkLfStream *streams, const uint32_t *bits, uint32_t *packed, unsigned long long *total,
@@ -88,9 +95,13 @@ struct HydAmdContext {
     int use_luts = 2;               /* XYB mode: 0 registers + fast reciprocal, 1 registers + IEEE division, 2 LUT gathers */
     int best_register_mode = 2;     /* best mode that passed the bit-exactness self-test */
     int register_luts_ok = 0;
-    int rans_waves = 4;             /* groups per rANS workgroup: 4 (latency) .. 16 (throughput) */
-    int rans_rows = 0;              /* 0: wave per group; 1..3: row forms 1..3 (hydamd_set_rans_waves) */
-    int rans_lanes = 0;             /* 1: lane per group (form 5); float frames still take the wave form */
+    int rans_lanes = 0;             /* entropy-stage form: 0 wave per group (form 4), 1 lane per group (form 5; float frames still take form 4) */
+    uint32_t tok_cap = HYDK_DEFAULT_TOKEN_CAP; /* token records per group the arrays below hold */
+    uint32_t rec_bytes = 4;         /* their record size: 4 until a float LF group is recorded, then 8 */
+    uint32_t bit_pitch_words = 0;   /* words per group in bitbuf (0: not allocated yet) */
+    int want_transform = 0, want_entropy = 0; /* what the caller asked for this frame: replayed if a buffer was too small */
+    bool slot_lanes[HYDAMD_MAX_LF_GROUPS] = {}; /* which entropy form coded each slot of the current frame */
+    unsigned overflow_reruns = 0;   /* frames run twice because a buffer was too small (hydamd_overflow_reruns) */
     uint32_t alpha_floor = 0;       /* running maximum alphabet of the LF groups coded before this context's */
     unsigned num_presets = 1;
     int scheme = 0;
@@ -101,11 +112,12 @@ struct HydAmdContext {
     char error[256] = "";
 
     /* device memory */
-    uint64_t *tokens = nullptr;     /* [slots][64][TOKENS_PER_GROUP] */
-    uint32_t *bitbuf = nullptr;     /* [slots][64][BITWORDS_PER_GROUP] */
-    uint16_t *rans_aux = nullptr;   /* [slots][64][TOKENS_PER_GROUP] lane form: the 16 bits a refill at each symbol sends */
-    uint16_t *rans_flags = nullptr; /* [slots][64][TOKENS_PER_GROUP / 16] lane form: one refill flag per symbol */
+    char *tokens = nullptr;         /* [slots][64][tok_cap] records of rec_bytes */
+    uint32_t *bitbuf = nullptr;     /* [slots][64][bit_pitch_words], wave form only, allocated on first use */
+    uint16_t *rans_aux = nullptr;   /* [slots][64][tok_cap] lane form: the 16 bits a refill at each symbol sends */
+    uint16_t *rans_flags = nullptr; /* [slots][64][tok_cap / 16] lane form: one refill flag per symbol */
     uint32_t *rans_final = nullptr; /* [slots][64] lane form: final states */
+    uint32_t *rbits_total = nullptr; /* [slots][64] residue bits per group */
     HydkTables *tables = nullptr;   /* [slots] */
     int32_t *dc = nullptr;          /* [slots][3][256][256] */
     uint32_t *hist = nullptr;       /* [slots][9][128] */
@@ -268,6 +280,16 @@ int check_slot(HydAmdContext *ctx, int slot) {
     return ST_OK;
 }
 
+/* where slot's token records live in the arrays as they are sized right now */
+void bind_slot_buffers(HydAmdContext *ctx, int slot) {
+    HydkLfJob &job = ctx->h_jobs[slot];
+    job.tokens = ctx->tokens + (size_t)slot * HYDK_GROUPS_PER_LFG * ctx->tok_cap * ctx->rec_bytes;
+    job.tok_cap = ctx->tok_cap;
+    job.rec_bytes = ctx->rec_bytes;
+}
+
+int widen_token_records(HydAmdContext *ctx);
+
 /* Record one LF group's job; the kernels run batched over all recorded slots in hydamd_finish_frame. */
 int record_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrdiff_t row_stride, ptrdiff_t pixel_stride,
                     int fmt, size_t width, size_t height, unsigned preset) {
@@ -277,6 +299,11 @@ int record_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrd
         return fail(ctx, ST_API_ERROR, "Invalid Sample Format");
     if (preset >= ctx->num_presets)
         return fail(ctx, ST_API_ERROR, "preset out of range for this frame");
+    if (fmt == HYDK_FMT_F32 && ctx->rec_bytes != 8) { /* float tokens need the 8-byte record: once per context */
+        const int st = widen_token_records(ctx);
+        if (st != ST_OK)
+            return st;
+    }
 
     HydkLfJob &job = ctx->h_jobs[slot];
     memset(&job, 0, sizeof(job));
@@ -296,8 +323,9 @@ int record_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrd
     job.in_lut8 = ctx->in_lut8;
     job.in_lut16 = ctx->in_lut16;
     job.bias_lut = ctx->bias_lut;
-    job.tokens = ctx->tokens + (size_t)slot * HYDK_GROUPS_PER_LFG * HYDK_TOKENS_PER_GROUP;
+    bind_slot_buffers(ctx, slot);
     job.sym_count = ctx->sym_count + (size_t)slot * HYDK_GROUPS_PER_LFG;
+    job.rbits_total = ctx->rbits_total + (size_t)slot * HYDK_GROUPS_PER_LFG;
     job.hist = ctx->hist + (size_t)slot * HYDK_MAX_CLUSTERS * HYDK_ALPHABET;
     job.alpha_max = ctx->alpha_max + slot;
     job.dc = ctx->dc + (size_t)slot * 3 * HYDK_DC_PITCH * HYDK_DC_PITCH;
@@ -310,19 +338,13 @@ int record_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrd
     return ST_OK;
 }
 
-int transform_pending_host_slots(HydAmdContext *ctx);
-
 int ensure_staging(HydAmdContext *ctx, size_t tile_bytes) {
     if (tile_bytes <= ctx->staging_cap)
         return ST_OK;
-    /* The arena is about to be replaced (a later tile of the frame has a wider sample type than the
-     * first: the reference lets sample_fmt vary per tile).  Tiles already uploaded but not yet
-     * transformed (HYDAMD_EAGER=0) would lose their pixels: run their transform kernels first. */
-    {
-        const int st = transform_pending_host_slots(ctx);
-        if (st != ST_OK)
-            return st;
-    }
+    /* A later tile of the frame has a wider sample type than the first (the reference lets sample_fmt
+     * vary per tile): the arena grows.  Tiles already uploaded keep their pixels — they are still needed
+     * if their transform kernels have not run yet (HYDAMD_EAGER=0) or have to run again (a frame that
+     * outgrows its token arrays, or whose token records are widened for a float tile). */
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->copy_stream) /* created on first use: device-pointer users never need it */
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -332,16 +354,29 @@ int ensure_staging(HydAmdContext *ctx, size_t tile_bytes) {
             (void)hipHostFree(ctx->pinned[i]);
         ctx->pinned[i] = nullptr;
     }
-    if (ctx->d_arena)
-        (void)hipFree(ctx->d_arena);
-    ctx->d_arena = nullptr;
-    ctx->staging_cap = 0;
     for (int i = 0; i < kStaging; i++) {
         HIP_TRY(ctx, hipHostMalloc(&ctx->pinned[i], tile_bytes, hipHostMallocDefault));
         if (!ctx->staged[i])
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->staged[i], hipEventDisableTiming));
     }
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_arena, tile_bytes * (size_t)ctx->max_slots));
+    char *fresh = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&fresh, tile_bytes * (size_t)ctx->max_slots));
+    if (ctx->d_arena) {
+        for (int i = 0; i < ctx->host_staged; i++) {
+            HydkLfJob &job = ctx->h_jobs[i];
+            const char *old_base = ctx->d_arena + (size_t)i * ctx->arena_tile;
+            if (!job.width || (const char *)job.src[0] != old_base)
+                continue; /* not a host-staged slot */
+            const size_t ss = sample_size(job.fmt);
+            char *base = fresh + (size_t)i * tile_bytes;
+            HIP_TRY(ctx, hipMemcpy(base, old_base, (size_t)job.width * job.height * 3 * ss, hipMemcpyDeviceToDevice));
+            job.src[0] = base;
+            job.src[1] = base + ss;
+            job.src[2] = base + 2 * ss;
+        }
+        (void)hipFree(ctx->d_arena);
+    }
+    ctx->d_arena = fresh;
     ctx->arena_tile = tile_bytes;
     ctx->staging_cap = tile_bytes;
     return ST_OK;
@@ -518,7 +553,7 @@ void hydamd_destroy(HydAmdContext *ctx) {
     for (void *p : lfdev)
         if (p)
             (void)hipFree(p);
-    void *dev[] = {ctx->rans_aux, ctx->rans_flags, ctx->rans_final, ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->hist, ctx->sym_count, ctx->group_bits,
+    void *dev[] = {ctx->rans_aux, ctx->rans_flags, ctx->rans_final, ctx->rbits_total, ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->hist, ctx->sym_count, ctx->group_bits,
                    ctx->offsets, ctx->total, ctx->status, ctx->alpha_max, ctx->d_jobs, ctx->in_lut8, ctx->in_lut16,
                    ctx->bias_lut, ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant, ctx->d_arena};
     for (void *p : dev)
@@ -545,16 +580,71 @@ void hydamd_destroy(HydAmdContext *ctx) {
     delete ctx;
 }
 
+/* hard upper bound of a frame's packed sections for the current token capacity: per symbol one 16-bit
+ * refill + the longest residue (30 bits float, 13 integer), per group state + preset + padding */
+static size_t payload_bound(const HydAmdContext *ctx) {
+    const size_t per_group = ((size_t)ctx->tok_cap * (ctx->rec_bytes == 8 ? 46 : 29) + 64 + 7) / 8;
+    return (size_t)ctx->max_slots * HYDK_GROUPS_PER_LFG * per_group;
+}
+
+/* (re)allocate the arrays whose size follows tok_cap / rec_bytes / payload_cap; the stream must be idle */
+static int alloc_frame_arrays(HydAmdContext *ctx, size_t payload_cap) {
+    const size_t groups = (size_t)ctx->max_slots * HYDK_GROUPS_PER_LFG;
+    void *old[] = {ctx->tokens, ctx->rans_aux, ctx->rans_flags, ctx->payload, ctx->bitbuf};
+    for (void *p : old)
+        if (p)
+            (void)hipFree(p);
+    ctx->tokens = nullptr;
+    ctx->rans_aux = ctx->rans_flags = nullptr;
+    ctx->payload = nullptr;
+    const bool had_bitbuf = ctx->bitbuf != nullptr;
+    ctx->bitbuf = nullptr;
+    ctx->bit_pitch_words = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->tokens, groups * ctx->tok_cap * ctx->rec_bytes));
+    HIP_TRY(ctx, hipMalloc(&ctx->rans_aux, groups * ctx->tok_cap * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->rans_flags, groups * (ctx->tok_cap / 16) * sizeof(uint16_t)));
+    ctx->payload_cap = payload_cap;
+    HIP_TRY(ctx, hipMalloc(&ctx->payload, payload_cap + 8)); /* + 8: the emit kernel addresses whole words */
+    if (had_bitbuf) {
+        ctx->bit_pitch_words = HYDK_BITWORDS_FOR(ctx->tok_cap);
+        HIP_TRY(ctx, hipMalloc(&ctx->bitbuf, groups * ctx->bit_pitch_words * sizeof(uint32_t)));
+    }
+    return ST_OK;
+}
+
+/* the wave-per-group form's reversed bit buffers, on first use */
+static int ensure_bitbuf(HydAmdContext *ctx) {
+    if (ctx->bitbuf)
+        return ST_OK;
+    const size_t groups = (size_t)ctx->max_slots * HYDK_GROUPS_PER_LFG;
+    ctx->bit_pitch_words = HYDK_BITWORDS_FOR(ctx->tok_cap);
+    HIP_TRY(ctx, hipMalloc(&ctx->bitbuf, groups * ctx->bit_pitch_words * sizeof(uint32_t)));
+    return ST_OK;
+}
+
 static int create_impl(HydAmdContext *ctx, int debug_planes) {
     const size_t slots = (size_t)ctx->max_slots, G = HYDK_GROUPS_PER_LFG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    HIP_TRY(ctx, hipMalloc(&ctx->tokens, slots * G * HYDK_TOKENS_PER_GROUP * sizeof(uint64_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->bitbuf, slots * G * HYDK_BITWORDS_PER_GROUP * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->rans_aux, slots * G * HYDK_TOKENS_PER_GROUP * sizeof(uint16_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->rans_flags, slots * G * (HYDK_TOKENS_PER_GROUP / 16) * sizeof(uint16_t)));
+    if (const char *env = getenv("HYDAMD_TOKEN_CAP")) { /* records per group before the overflow path kicks in (tests) */
+        const long v = atol(env);
+        if (v >= 16 && v <= HYDK_TOKENS_PER_GROUP)
+            ctx->tok_cap = (uint32_t)v & ~15u;
+    }
+    {
+        /* one byte per pixel of packed sections is 5 to 10 times what photographic content needs */
+        size_t cap = slots * (size_t)2048 * 2048;
+        if (const char *env = getenv("HYDAMD_PAYLOAD_CAP"))
+            if (atol(env) > 0)
+                cap = (size_t)atol(env);
+        const size_t bound = payload_bound(ctx);
+        const int st = alloc_frame_arrays(ctx, cap < bound ? cap : bound);
+        if (st != ST_OK)
+            return st;
+    }
     HIP_TRY(ctx, hipMalloc(&ctx->rans_final, slots * G * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->rbits_total, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->tables, slots * sizeof(HydkTables)));
     HIP_TRY(ctx, hipMalloc(&ctx->dc, slots * 3 * HYDK_DC_PITCH * HYDK_DC_PITCH * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->hist, slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t)));
@@ -589,10 +679,6 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipMalloc(&ctx->in_lut8, 256 * sizeof(uint16_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->in_lut16, 65536 * sizeof(uint16_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->bias_lut, 65536 * sizeof(float)));
-    /* packed sections can never exceed the reversed bit buffers they are copied from, so sizing
-     * the payload to that bound keeps hydamd_finish_frame free of any host synchronisation */
-    ctx->payload_cap = slots * G * HYDK_BITWORDS_PER_GROUP * sizeof(uint32_t);
-    HIP_TRY(ctx, hipMalloc(&ctx->payload, ctx->payload_cap));
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_total_pinned, sizeof(uint64_t), hipHostMallocDefault));
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_status_pinned, sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(ctx, hipMemset(ctx->group_bits, 0, slots * G * sizeof(uint32_t)));
@@ -633,12 +719,8 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     ctx->use_luts = ctx->best_register_mode;
     if (const char *env = getenv("HYDAMD_RANS_WAVES")) {
         const int w = atoi(env);
-        if (w == 4)
-            ctx->rans_waves = w;
-        if (w >= 1 && w <= 3)
-            ctx->rans_rows = w;
-        if (w == 5)
-            ctx->rans_lanes = 1;
+        if (w == 4 || w == 5)
+            ctx->rans_lanes = w == 5;
     }
     if (const char *env = getenv("HYDAMD_LF_CODER")) /* 0: leave the LF ints to the host coder (A/B measurements) */
         ctx->lf_on_device = atoi(env) == 2 ? 2 : atoi(env) != 0;
@@ -714,21 +796,9 @@ int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode) {
 int hydamd_set_rans_waves(HydAmdContext *ctx, int waves) {
     if (!ctx)
         return ST_API_ERROR;
-    if (waves >= 1 && waves <= 3) { /* four chains per wave, one per 16-lane row; 2: a whole LF group, 3: half of one, per workgroup */
-        ctx->rans_rows = waves;
-        ctx->rans_lanes = 0;
-        return ST_OK;
-    }
-    if (waves == 5) { /* one lane per group: a wavefront per LF group walks its 64 chains, bits are written by a second kernel */
-        ctx->rans_lanes = 1;
-        ctx->rans_rows = 0;
-        return ST_OK;
-    }
-    if (waves != 4)
-        return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group), 1/2/3 (row forms) or 5 (lane per group)");
-    ctx->rans_waves = waves;
-    ctx->rans_rows = 0;
-    ctx->rans_lanes = 0;
+    if (waves != 4 && waves != 5)
+        return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group) or 5 (lane per group)");
+    ctx->rans_lanes = waves == 5;
     return ST_OK;
 }
 
@@ -761,6 +831,7 @@ int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
     ctx->results_valid = false;
     ctx->slots_finished = 0;
     ctx->transformed = ctx->coded = ctx->lf_coded = 0;
+    ctx->want_transform = ctx->want_entropy = 0;
     ctx->host_staged = 0;
     ctx->lf_need_gather = false;
     ctx->lf_results_valid = false;
@@ -850,17 +921,6 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
     return ST_OK;
 }
 
-namespace {
-int transform_pending_host_slots(HydAmdContext *ctx) {
-    if (ctx->host_staged <= ctx->transformed)
-        return ST_OK;
-    const int st = transform_range(ctx, ctx->transformed, ctx->host_staged - ctx->transformed);
-    if (st == ST_OK)
-        ctx->transformed = ctx->host_staged;
-    return st;
-}
-} // namespace
-
 /* The LF coder's token and code kernels for slots [first, first + count), whose transform kernels
  * are already enqueued.  It needs only the LF ints they write: forked onto its own stream so that it
  * overlaps the HF entropy stage; join_lf brings the streams back together. */
@@ -886,6 +946,8 @@ int hydamd_run_transform(HydAmdContext *ctx, int num_slots) {
         return fail(ctx, ST_API_ERROR, "slot count out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->results_valid = false;
+    if (num_slots > ctx->want_transform)
+        ctx->want_transform = num_slots;
     if (num_slots > ctx->transformed) {
         const int st = transform_range(ctx, ctx->transformed, num_slots - ctx->transformed);
         if (st != ST_OK)
@@ -929,13 +991,109 @@ static int join_lf(HydAmdContext *ctx, int num_slots) {
     return ST_OK;
 }
 
+/* Start the current frame over after its arrays were re-laid out: every recorded slot is re-bound,
+ * what the transform kernels accumulate is cleared, and the stages the caller had asked for are
+ * enqueued again (the job descriptors are still in the pinned ring; pixels are borrowed until sync). */
+static int replay_frame(HydAmdContext *ctx) {
+    const int recorded = ctx->want_transform > ctx->transformed ? ctx->want_transform : ctx->transformed;
+    for (int i = 0; i < ctx->max_slots; i++)
+        if (ctx->h_jobs[i].width)
+            bind_slot_buffers(ctx, i);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->hist, 0, (size_t)ctx->max_slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t),
+                                ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->alpha_max, 0, (size_t)ctx->max_slots * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->status, 0, sizeof(uint32_t), ctx->stream));
+    const int entropy = ctx->want_entropy;
+    ctx->transformed = ctx->coded = ctx->lf_coded = 0;
+    ctx->results_valid = false;
+    if (recorded > 0) {
+        const int st = hydamd_run_transform(ctx, recorded);
+        if (st != ST_OK)
+            return st;
+    }
+    if (entropy > 0)
+        return hydamd_run_entropy(ctx, entropy);
+    return ST_OK;
+}
+
+/* The stream is idle and `status` holds the frame's status word.  If a buffer was too small: enlarge
+ * it to its hard maximum and run the frame again.  Returns ST_OK with *again set when the caller
+ * has to wait for the stream once more. */
+static int resolve_overflow(HydAmdContext *ctx, uint32_t status, bool *again) {
+    *again = false;
+    if (!(status & HYDK_STATUS_OVERFLOW))
+        return ST_OK;
+    if (status & HYDK_STATUS_LAYOUT)
+        return fail(ctx, ST_INTERNAL_ERROR, "float LF group in a context laid out for integer token records");
+    size_t payload_cap = ctx->payload_cap;
+    if (status & HYDK_STATUS_TOKENS) {
+        if (ctx->tok_cap >= HYDK_TOKENS_PER_GROUP)
+            return fail(ctx, ST_INTERNAL_ERROR, "a group produced more symbols than the format allows");
+        ctx->tok_cap = HYDK_TOKENS_PER_GROUP;
+    }
+    if (status & HYDK_STATUS_PAYLOAD) {
+        if (payload_cap >= payload_bound(ctx))
+            return fail(ctx, ST_INTERNAL_ERROR, "sections larger than their hard bound");
+        payload_cap = payload_bound(ctx);
+    }
+    int st = alloc_frame_arrays(ctx, payload_cap < payload_bound(ctx) ? payload_cap : payload_bound(ctx));
+    if (st != ST_OK)
+        return st;
+    ctx->overflow_reruns++;
+    st = replay_frame(ctx);
+    *again = st == ST_OK;
+    return st;
+}
+
+/* float input needs 8-byte token records: re-lay the token arrays once (the context stays wide) and
+ * re-run the transform kernels already enqueued for this frame */
+namespace {
+int widen_token_records(HydAmdContext *ctx) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->lf_stream)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->lf_stream));
+    ctx->rec_bytes = 8;
+    const size_t bound = payload_bound(ctx);
+    int st = alloc_frame_arrays(ctx, ctx->payload_cap < bound ? ctx->payload_cap : bound);
+    if (st != ST_OK)
+        return st;
+    if (ctx->transformed > 0 || ctx->want_entropy > 0)
+        return replay_frame(ctx);
+    for (int i = 0; i < ctx->max_slots; i++)
+        if (ctx->h_jobs[i].width)
+            bind_slot_buffers(ctx, i);
+    return ST_OK;
+}
+} // namespace
+
+/* wait for the stream; rerun the frame if one of its buffers turned out too small */
+static int wait_for_frame(HydAmdContext *ctx) {
+    for (int attempt = 0; attempt < 4; attempt++) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status_pinned, ctx->status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        bool again = false;
+        const int st = resolve_overflow(ctx, *ctx->h_status_pinned, &again);
+        if (st != ST_OK)
+            return st;
+        if (!again)
+            return ST_OK;
+        const int st2 = join_lf(ctx, 0);
+        if (st2 != ST_OK)
+            return st2;
+    }
+    return fail(ctx, ST_INTERNAL_ERROR, "frame still does not fit after enlarging its buffers");
+}
+
 int hydamd_read_alphabet_max(HydAmdContext *ctx, int slot, uint32_t *max_token_plus_one) {
     int st = check_slot(ctx, slot);
     if (st != ST_OK)
         return st;
-    HIP_TRY(ctx, hipMemcpyAsync(max_token_plus_one, ctx->alpha_max + slot, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    st = wait_for_frame(ctx); /* the maxima of a frame that outgrew its token arrays are incomplete */
+    if (st != ST_OK)
+        return st;
+    HIP_TRY(ctx, hipMemcpy(max_token_plus_one, ctx->alpha_max + slot, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return ST_OK;
 }
 
@@ -946,7 +1104,7 @@ int hydamd_set_alphabet_floor(HydAmdContext *ctx, uint32_t floor) {
     return ST_OK;
 }
 
-/* K2 + K3a for slots [first, first + count) */
+/* K2 + the rANS chains for slots [first, first + count) */
 static int entropy_range(HydAmdContext *ctx, int first, int count) {
     const size_t G = HYDK_GROUPS_PER_LFG, g0 = (size_t)first * G;
     {
@@ -957,24 +1115,25 @@ static int entropy_range(HydAmdContext *ctx, int first, int count) {
     {
         ScopedTimer timer(ctx, HYDAMD_K_RANS);
         const HydkLfJob *jobs = ctx->d_jobs + first;
-        uint64_t *tokens = ctx->tokens + g0 * HYDK_TOKENS_PER_GROUP;
-        uint32_t *bitbuf = ctx->bitbuf + g0 * HYDK_BITWORDS_PER_GROUP;
-        bool any_float = false; /* 8-byte records: only the wave and row forms read them */
+        bool any_float = false; /* 8-byte records: only the wave form reads them */
         for (int i = first; i < first + count; i++)
             any_float = any_float || ctx->h_jobs[i].fmt == HYDK_FMT_F32;
-        if (ctx->rans_lanes && !any_float)
-            HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, tokens, ctx->sym_count + g0, ctx->tables + first,
-                                                 ctx->rans_aux + g0 * HYDK_TOKENS_PER_GROUP,
-                                                 ctx->rans_flags + g0 * (HYDK_TOKENS_PER_GROUP / 16), ctx->rans_final + g0,
-                                                 bitbuf, ctx->group_bits + g0, ctx->preset_bits, ctx->nclusters, count,
-                                                 ctx->stream));
-        else if (ctx->rans_rows)
-            HIP_TRY(ctx, hydk::launch_rans_rows(jobs, tokens, ctx->sym_count + g0, ctx->tables + first, bitbuf,
-                                                ctx->group_bits + g0, ctx->preset_bits, count, ctx->rans_rows - 1,
-                                                ctx->stream));
-        else
-            HIP_TRY(ctx, hydk::launch_rans(jobs, tokens, ctx->sym_count + g0, ctx->tables + first, bitbuf,
-                                           ctx->group_bits + g0, ctx->preset_bits, count, ctx->rans_waves, ctx->stream));
+        const bool lanes = ctx->rans_lanes && !any_float;
+        if (lanes) {
+            HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, ctx->sym_count + g0, ctx->tables + first,
+                                                 ctx->rans_aux + g0 * ctx->tok_cap, ctx->rans_flags + g0 * (ctx->tok_cap / 16),
+                                                 ctx->tok_cap, ctx->rans_final + g0, ctx->group_bits + g0, ctx->preset_bits,
+                                                 ctx->nclusters, count, ctx->status, ctx->stream));
+        } else {
+            const int st = ensure_bitbuf(ctx);
+            if (st != ST_OK)
+                return st;
+            HIP_TRY(ctx, hydk::launch_rans(jobs, ctx->sym_count + g0, ctx->tables + first,
+                                           ctx->bitbuf + g0 * ctx->bit_pitch_words, ctx->bit_pitch_words,
+                                           ctx->group_bits + g0, ctx->preset_bits, count, ctx->status, ctx->stream));
+        }
+        for (int i = first; i < first + count; i++)
+            ctx->slot_lanes[i] = lanes;
     }
     return ST_OK;
 }
@@ -989,6 +1148,7 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int count = num_slots * HYDK_GROUPS_PER_LFG;
     ctx->results_valid = false;
+    ctx->want_entropy = num_slots;
     if (num_slots > ctx->coded) {
         const int st = entropy_range(ctx, ctx->coded, num_slots - ctx->coded);
         if (st != ST_OK)
@@ -996,9 +1156,28 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
         ctx->coded = num_slots;
     }
     {
+        /* section sizes -> byte offsets, then the sections themselves: lane-form slots write their bits
+         * straight into place, wave-form slots copy theirs out of the reversed bit buffers */
         ScopedTimer timer(ctx, HYDAMD_K_PACK);
-        HIP_TRY(ctx, hydk::launch_scan(ctx->group_bits, count, ctx->offsets, ctx->total, ctx->stream));
-        HIP_TRY(ctx, hydk::launch_pack(ctx->bitbuf, ctx->group_bits, ctx->offsets, ctx->payload, count, ctx->stream));
+        HIP_TRY(ctx, hydk::launch_scan(ctx->group_bits, count, ctx->offsets, ctx->total, ctx->payload, ctx->payload_cap, 1,
+                                       ctx->status, ctx->stream));
+        for (int first = 0; first < num_slots;) {
+            int last = first;
+            while (last + 1 < num_slots && ctx->slot_lanes[last + 1] == ctx->slot_lanes[first])
+                last++;
+            const int n = last - first + 1;
+            const size_t g0 = (size_t)first * HYDK_GROUPS_PER_LFG;
+            if (ctx->slot_lanes[first])
+                HIP_TRY(ctx, hydk::launch_rans_emit(ctx->d_jobs + first, ctx->sym_count + g0, ctx->rans_aux + g0 * ctx->tok_cap,
+                                                    ctx->rans_flags + g0 * (ctx->tok_cap / 16), ctx->tok_cap,
+                                                    ctx->rans_final + g0, ctx->group_bits + g0, ctx->offsets + g0, ctx->payload,
+                                                    ctx->preset_bits, n, ctx->status, ctx->stream));
+            else
+                HIP_TRY(ctx, hydk::launch_pack(ctx->bitbuf + g0 * ctx->bit_pitch_words, ctx->bit_pitch_words,
+                                               ctx->group_bits + g0, ctx->offsets + g0, ctx->payload,
+                                               n * HYDK_GROUPS_PER_LFG, ctx->status, ctx->stream));
+            first = last + 1;
+        }
     }
     {
         const int st = join_lf(ctx, num_slots);
@@ -1045,6 +1224,13 @@ int hydamd_run_lf_coder(HydAmdContext *ctx, int num_slots, int last) {
             return st;
         ctx->transformed = num_slots;
     }
+    if (ctx->lf_pending) {
+        /* earlier LF groups of this frame were coded on the side stream (a replayed frame): everything
+         * from here on, the packing of the LF streams included, runs in the main stream behind them */
+        HIP_TRY(ctx, hipEventRecord(ctx->lf_join, ctx->lf_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->lf_join, 0));
+        ctx->lf_pending = false;
+    }
     if (num_slots > ctx->lf_coded) {
         const int st = lf_range(ctx, ctx->lf_coded, num_slots - ctx->lf_coded, false);
         if (st != ST_OK)
@@ -1082,19 +1268,29 @@ int hydamd_sync(HydAmdContext *ctx) {
         if (st != ST_OK)
             return st;
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        const int st = wait_for_frame(ctx);
+        if (st != ST_OK)
+            return st;
+    }
     drain_timers(ctx);
     ctx->h_total = *ctx->h_total_pinned;
     ctx->h_lf_total = *ctx->h_lf_total_pinned;
     ctx->lf_results_valid = ctx->lf_on_device && !ctx->lf_need_gather && ctx->lf_slots > 0;
     ctx->h_status = *ctx->h_status_pinned;
-    if (ctx->h_status & 1u)
+    if (ctx->h_status & HYDK_STATUS_BAD_SAMPLE)
         return fail(ctx, ST_API_ERROR, "Invalid NaN Float");
     ctx->results_valid = true;
     return ST_OK;
 }
 
 size_t hydamd_payload_size(HydAmdContext *ctx) { return ctx && ctx->results_valid ? (size_t)ctx->h_total : 0; }
+
+size_t hydamd_payload_capacity(HydAmdContext *ctx) { return ctx ? ctx->payload_cap : 0; }
+
+unsigned hydamd_token_capacity(HydAmdContext *ctx) { return ctx ? ctx->tok_cap : 0; }
+
+unsigned hydamd_overflow_reruns(HydAmdContext *ctx) { return ctx ? ctx->overflow_reruns : 0; }
 
 const uint8_t *hydamd_payload_device(HydAmdContext *ctx) { return ctx ? ctx->payload : nullptr; }
 
@@ -1266,9 +1462,9 @@ int hydamd_read_tokens(HydAmdContext *ctx, int slot, int group, uint64_t *dst, s
     int st = check_slot(ctx, slot);
     if (st != ST_OK)
         return st;
-    if (group < 0 || group >= HYDK_GROUPS_PER_LFG || capacity > HYDK_TOKENS_PER_GROUP)
+    if (group < 0 || group >= HYDK_GROUPS_PER_LFG || capacity > ctx->tok_cap)
         return fail(ctx, ST_API_ERROR, "group or capacity out of range");
-    const uint64_t *src = ctx->tokens + ((size_t)slot * HYDK_GROUPS_PER_LFG + group) * HYDK_TOKENS_PER_GROUP;
+    const char *src = ctx->tokens + ((size_t)slot * HYDK_GROUPS_PER_LFG + group) * ctx->tok_cap * ctx->rec_bytes;
     if (ctx->h_jobs[slot].fmt == HYDK_FMT_F32) {
         HIP_TRY(ctx, hipMemcpy(dst, src, capacity * sizeof(uint64_t), hipMemcpyDeviceToHost));
         return ST_OK;

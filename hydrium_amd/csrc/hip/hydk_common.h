@@ -21,9 +21,20 @@
 #define HYDK_ALPHABET 128             /* >= largest token + 1 (71 + 1) of the (4,1,0) hybrid-uint config */
 #define HYDK_ANS_SLOTS 4096           /* 12-bit ANS precision */
 #define HYDK_DC_PITCH 256             /* varblocks per row of an LF group's DC plane */
-/* Reversed per-group bit buffer, in 32-bit words.  Worst case per symbol is one 16-bit refill plus
- * a 30-bit residue; 196608 * 46 bits = 1.13 MB, plus the 32-bit final state and preset bits. */
-#define HYDK_BITWORDS_PER_GROUP ((HYDK_TOKENS_PER_GROUP * 46 + 64 + 31) / 32 + 1)
+/* Token storage is sized for HYDK_DEFAULT_TOKEN_CAP records per group (1.5 symbols per pixel — photographic
+ * content has 0.4 to 0.5, pure noise 2.9); a group that needs more raises HYDK_STATUS_OVERFLOW and the
+ * host reruns the frame with the hard maximum. */
+#define HYDK_DEFAULT_TOKEN_CAP 98304
+/* Reversed per-group bit buffer of the wave-per-group entropy form, in 32-bit words, for `cap` token
+ * records.  Worst case per symbol is one 16-bit refill plus a 30-bit residue; plus the 32-bit final
+ * state and preset bits. */
+#define HYDK_BITWORDS_FOR(cap) (((cap) * 46 + 64 + 31) / 32 + 1)
+/* bits of the device status word */
+#define HYDK_STATUS_BAD_SAMPLE 1u /* non-finite float sample */
+#define HYDK_STATUS_TOKENS 2u     /* a group needed more token records than its array holds */
+#define HYDK_STATUS_PAYLOAD 4u    /* the frame's sections need more bytes than the payload holds */
+#define HYDK_STATUS_LAYOUT 8u     /* a float LF group met token arrays laid out for 4-byte records (host bug) */
+#define HYDK_STATUS_OVERFLOW (HYDK_STATUS_TOKENS | HYDK_STATUS_PAYLOAD | HYDK_STATUS_LAYOUT) /* later stages skip the frame */
 
 /* Token record (8 bytes) written by the transform kernel and read by the rANS kernel:
  *   lo: bits 0-7 token, 8-11 preset-local cluster, 16-21 residue bit count;  hi: residue bits. */
@@ -70,8 +81,11 @@ typedef struct HydkLfJob {
     const uint16_t *in_lut8;   /* 256 entries   */
     const uint16_t *in_lut16;  /* 65536 entries */
     const float *bias_lut;     /* 65536 entries */
-    void *tokens;            /* [groups][HYDK_TOKENS_PER_GROUP] records of 8 bytes (float input) or 4 (integer input) at an 8-byte group pitch */
+    void *tokens;            /* [groups][tok_cap] records of 8 bytes (float input) or 4 (integer input); group pitch tok_cap * rec_bytes */
+    uint32_t tok_cap;        /* records a group's token array can hold */
+    uint32_t rec_bytes;      /* record size the token array was laid out for: 4 (integer input only) or 8 */
     uint32_t *sym_count;     /* [groups] */
+    uint32_t *rbits_total;   /* [groups] residue bits of the group's symbols, summed */
     uint32_t *hist;          /* [HYDK_MAX_CLUSTERS][HYDK_ALPHABET], zeroed before launch */
     uint32_t *alpha_max;     /* [1] largest token + 1 over this LF group's symbols, zeroed before launch */
     int32_t *dc;             /* [3][HYDK_DC_PITCH][HYDK_DC_PITCH] LF ints */

@@ -10,11 +10,12 @@
  *                         (entropy.c:184-301, 943-978).
  *   k_rans_encode         one wave per group: the serial reverse rANS chain (entropy.c:1064-1159)
  *                         with wave-parallel bit emission, written back-to-front so that no
- *                         replay pass is needed (lowest latency of one frame).
- *   k_rans_rows / k_rans_rows_half   the same chain, four groups per wave (one per 16-lane row):
- *                         fewer, longer-lived workgroups that leave room for other frames'
- *                         transform kernels (highest frame rate).
- *   k_scan_sections / k_pack_sections   byte sizes, offsets and packing of the HF sections.
+ *                         replay pass is needed (lowest latency of one frame; float input).
+ *   k_rans_lanes / k_rans_emit   the same chain with one LANE per group — a wavefront walks the 64
+ *                         chains of an LF group and records each step's refill word — and a
+ *                         wave-parallel kernel that writes the bits straight into the frame's
+ *                         payload (highest frame rate: 0.3 instructions per symbol).
+ *   k_scan_sections / k_pack_sections   byte sizes and offsets of the HF sections; packing of the wave form's.
  *
  * Arithmetic contract: IEEE binary32, source operation order, NO fused multiply-add — the
  * reference's canonical bytes are the non-contracted ones.  This file is
@@ -327,11 +328,22 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
         return; /* another template instance of this launch round owns this LF group */
     if ((int)(blockIdx.x & 63) >= job.gcols * job.grows)
         return;
+    if (FMT == HYDK_FMT_F32 && job.rec_bytes != 8) {
+        /* the context's token arrays are laid out for 4-byte records; the host widens them before it
+         * records a float LF group, so this is unreachable — kept so that a host bug cannot corrupt memory */
+        if (threadIdx.x == 0) {
+            atomicOr(status, HYDK_STATUS_LAYOUT);
+            job.sym_count[blockIdx.x & 63] = 0;
+            job.rbits_total[blockIdx.x & 63] = 0;
+        }
+        return;
+    }
 
     /* [c][block][kv][kh]: row-pass output, overwritten in place by the quantised coefficients, 27.0 KiB */
     __shared__ float s_rowpass[3 * kS0Chan];
     __shared__ uint32_t s_btot[32];                   /* symbols of each varblock of the strip (three channels) */
     __shared__ uint32_t s_boff[4][33];                /* per wave: their exclusive prefix sums + strip total */
+    __shared__ uint32_t s_rbits;                      /* residue bits of the group's symbols */
     /* integer input cannot produce a token above 35 (see store_record): half the histogram suffices,
      * which is what lets two of these workgroups fit beside an entropy-stage workgroup */
     constexpr int kHistW = FMT == HYDK_FMT_F32 ? HYDK_ALPHABET : HYDK_ALPHABET / 2;
@@ -406,8 +418,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
     };
     prefetch(0);
 
-    void *const tok = (char *)job.tokens + (size_t)g * HYDK_TOKENS_PER_GROUP * sizeof(uint64_t);
+    void *const tok = (char *)job.tokens + (size_t)g * job.tok_cap * job.rec_bytes;
     uint32_t goff = 0;
+    uint32_t rb_sum = 0;     /* residue bits of the symbols this thread emitted */
+    bool overflowed = false; /* the group outgrew its token array: stop storing, report, let the host rerun the frame */
+    if (t == 0)
+        s_rbits = 0;
     unsigned long long zero_tokens = 0; /* six 10-bit counters: zero-valued coefficient tokens per cluster */
     bool bad_sample = false;
     HYDK_PHASE_INIT();
@@ -581,7 +597,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
         {
             const uint32_t tY = (uint32_t)__popcll(msk[1]), tX = (uint32_t)__popcll(msk[0]), tB = (uint32_t)__popcll(msk[2]);
             const uint32_t first = goff + boff;
-            for (uint32_t i = (uint32_t)kh; i < nblock; i += 8u) {
+            overflowed = overflowed || goff + strip_total > job.tok_cap;
+            for (uint32_t i = (uint32_t)kh; i < (overflowed ? 0u : nblock); i += 8u) {
                 /* i-th symbol of the block: which channel, which zig-zag position */
                 const bool inX = i >= nY, inB = i >= nY + nX;
                 const int visit = (int)inX + (int)inB;
@@ -624,6 +641,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
                     token = 16u + (((uint32_t)(n - 3) << 1) | ((value >> n) & 1u));
                 }
                 store_record<FMT>(tok, first + i, token, (uint32_t)cluster, rbits, residue);
+                rb_sum += rbits;
                 if (token == 0 && j != 0)
                     zero_tokens += 1ull << (10 * (cluster - coef_cl_lo)); /* at most 24 x 32 per thread and group */
                 else
@@ -656,10 +674,20 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
         top_token = max(top_token, (uint32_t)__shfl_xor((int)top_token, d));
     if (lane == 0 && top_token)
         atomicMax(job.alpha_max, top_token);
-    if (t == 0)
-        job.sym_count[g] = goff;
+#pragma unroll
+    for (int d = 32; d; d >>= 1)
+        rb_sum += (uint32_t)__shfl_xor((int)rb_sum, d);
+    if (lane == 0)
+        atomicAdd(&s_rbits, rb_sum);
+    __syncthreads();
+    if (t == 0) {
+        job.sym_count[g] = overflowed ? 0u : goff;
+        job.rbits_total[g] = s_rbits;
+        if (overflowed)
+            atomicOr(status, HYDK_STATUS_TOKENS);
+    }
     if (FMT == HYDK_FMT_F32 && bad_sample)
-        atomicOr(status, 1u);
+        atomicOr(status, HYDK_STATUS_BAD_SAMPLE);
     HYDK_PHASE_MARK(7);
     HYDK_PHASE_FLUSH();
 }
@@ -917,10 +945,10 @@ __device__ __forceinline__ uint32_t mad24(uint32_t b, uint32_t c, uint32_t a) {
     } while (0)
 
 template <int WAVES> /* groups (= waves) per workgroup */
-__global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
-                                                            const uint32_t *sym_count_all, const HydkTables *tabs,
-                                                            uint32_t *bitbuf_all, uint32_t *group_bits_all,
-                                                            int preset_bits) {
+__global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
+                                                            const HydkTables *tabs, uint32_t *bitbuf_all,
+                                                            uint32_t bit_pitch_words, uint32_t *group_bits_all,
+                                                            int preset_bits, const uint32_t *status) {
     constexpr int kThreads = 64 * WAVES;                             /* shadows the file-level constant */
     constexpr int kBlocksPerLfg = HYDK_GROUPS_PER_LFG / WAVES;
     __shared__ uint16_t s_inv[kInvEntries];                          /* 144 KiB */
@@ -934,6 +962,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
     const int first_group = (blockIdx.x % kBlocksPerLfg) * WAVES;
     const int g = first_group + wave;
     const int ngroups = jobs[slot].gcols * jobs[slot].grows;
+    if (*status & HYDK_STATUS_OVERFLOW)
+        return; /* the transform stage ran out of token space: the host reruns the frame */
     if (first_group >= ngroups) {
         if (lane == 0)
             group_bits_all[slot * HYDK_GROUPS_PER_LFG + g] = 0;
@@ -958,16 +988,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
     }
 
     const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + g;
-    const uint64_t *tok = tokens_all + G * HYDK_TOKENS_PER_GROUP;
     const bool wide = jobs[slot].fmt == HYDK_FMT_F32;
-    uint32_t *W = bitbuf_all + G * HYDK_BITWORDS_PER_GROUP;
+    const void *tok = (const char *)jobs[slot].tokens + (size_t)g * jobs[slot].tok_cap * jobs[slot].rec_bytes;
+    uint32_t *W = bitbuf_all + G * bit_pitch_words;
     uint32_t *win = s_win[wave];
     uint4 *ops = s_ops[wave];
     const int n = __builtin_amdgcn_readfirstlane((int)sym_count_all[G]); /* wave-uniform: scalar loop control */
     const unsigned char *inv_bytes = (const unsigned char *)s_inv;
 
-    uint32_t cur = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u; /* stream start so far (absolute bit position) */
-    uint32_t carry = 0;                                     /* content of the partly filled word at cur>>5 */
+    uint32_t cur = bit_pitch_words * 32u; /* stream start so far (absolute bit position) */
+    uint32_t carry = 0;                   /* content of the partly filled word at cur>>5 */
     uint32_t state;
     /* keep the recurrence in vector registers: routed through the scalar unit, every LDS lookup
      * would cost a v_mov + v_readfirstlane round trip on the critical path */
@@ -1070,216 +1100,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
     if (lane == 0) {
         if (cur & 31u)
             W[cur >> 5] = carry;
-        group_bits_all[G] = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u - cur;
+        group_bits_all[G] = bit_pitch_words * 32u - cur;
     }
 }
 #undef HYDK_RANS_STEP
-
-/* ==========================================================================================
- * K3a, packed form: four chains per wave, one per 16-lane row; 16 groups per workgroup.  Every
- * instruction of the serial walk now advances four groups, so the entropy stage of a frame needs
- * about a quarter of the issue slots of k_rans_encode and other frames' transform kernels can run
- * beside it.  Per round of 16 symbols per chain: operands are staged through LDS (one
- * ds_read_b128 per step, broadcast inside a row), states are captured by v_mov_b32_dpp row_shr:1,
- * and emission is a 16-lane segmented prefix sum into a per-row LDS window.
- * grid = 4 x LF groups, block = 256.
- * ======================================================================================== */
-constexpr int kRowWin = 28; /* 16 symbols x 46 bits = 23 words + alignment slack */
-
-/* WAVES = 4: 16 groups per workgroup, doubled table (147 KB of LDS).  WAVES = 16: a whole LF group
- * per workgroup with the plain table (74 KB), so one CU serves an LF group's entropy stage and
- * transform workgroups of other frames still fit beside it. */
-template <int WAVES, bool DOUBLED>
-__device__ __forceinline__ void rans_rows_body(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
-                                               const uint32_t *sym_count_all, const HydkTables *tabs, uint32_t *bitbuf_all,
-                                               uint32_t *group_bits_all, int preset_bits) {
-    constexpr int kThreads = 64 * WAVES;
-    constexpr int kBlocksPerLfg = HYDK_GROUPS_PER_LFG / (4 * WAVES);
-    constexpr int kTableEntries = DOUBLED ? kInvEntries : kInvEntries / 2;
-    __shared__ uint16_t s_inv[kTableEntries];
-    __shared__ uint32_t s_fb[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
-    __shared__ uint32_t s_magic[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
-    __shared__ uint4 s_ops[WAVES][4][16];                            /* [wave][row][step]: f or -2f, magic, table address, threshold */
-    __shared__ uint32_t s_win[WAVES][4][kRowWin];
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int row = lane >> 4, l = lane & 15;
-    const int slot = blockIdx.x / kBlocksPerLfg;
-    const int first_group = (blockIdx.x % kBlocksPerLfg) * 4 * WAVES;
-    const int g = first_group + (wave << 2) + row;
-    const int ngroups = jobs[slot].gcols * jobs[slot].grows;
-    if (first_group >= ngroups) {
-        if (l == 0)
-            group_bits_all[slot * HYDK_GROUPS_PER_LFG + g] = 0;
-        return;
-    }
-    const HydkTables *tab = tabs + slot;
-    {
-        const uint4 *src = DOUBLED ? (const uint4 *)&tab->inv[0][0] : (const uint4 *)&tab->inv1[0][0];
-        uint4 *dst = (uint4 *)s_inv;
-        for (int i = t; i < kTableEntries / 8; i += kThreads)
-            dst[i] = src[i];
-        for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads) {
-            s_fb[i] = (&tab->fb[0][0])[i];
-            s_magic[i] = (&tab->magic[0][0])[i];
-        }
-    }
-    __syncthreads();
-
-    const bool live = g < ngroups;
-    const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + g;
-    const uint64_t *tok = tokens_all + G * HYDK_TOKENS_PER_GROUP;
-    const bool wide = jobs[slot].fmt == HYDK_FMT_F32;
-    uint32_t *W = bitbuf_all + G * HYDK_BITWORDS_PER_GROUP;
-    uint32_t *win = s_win[wave][row];
-    uint4 *ops = s_ops[wave][row];
-    const int n = live ? (int)sym_count_all[G] : 0;
-    const unsigned char *inv_bytes = (const unsigned char *)s_inv;
-    int nmax = n;
-#pragma unroll
-    for (int d = 32; d; d >>= 1)
-        nmax = max(nmax, __shfl_xor(nmax, d));
-
-    uint32_t cur = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u; /* per row */
-    uint32_t carry = 0;
-    uint32_t state;
-    asm volatile("v_mov_b32 %0, 0x130000" : "=v"(state));
-
-    /* 16-lane segmented emission: lane l = 0 of a row is nearest the bits already written */
-    auto emit = [&](unsigned long long val, uint32_t nbits) {
-        const uint32_t inc = scan16_inclusive(nbits);
-        const uint32_t total = HYDK_DPP(inc, 0x15F, 0xF); /* row_newbcast:15 — the row's last lane to all of its lanes */
-        const uint32_t newcur = cur - total;
-        const uint32_t wlo = newcur >> 5, whi = (cur - 1u) >> 5;
-        const uint32_t nwords = total ? whi - wlo + 1u : 0u;
-        for (uint32_t i = l; i < nwords; i += 16)
-            win[i] = 0;
-        __builtin_amdgcn_wave_barrier();
-        if (l == 0 && nwords && (cur & 31u))
-            win[whi - wlo] = carry;
-        __builtin_amdgcn_wave_barrier();
-        if (nbits) {
-            const uint32_t pos = cur - inc - wlo * 32u;
-            const uint32_t w = pos >> 5, sh = pos & 31u;
-            const unsigned long long lo = val << sh;
-            const uint32_t hi = sh ? (uint32_t)(val >> (64u - sh)) : 0u;
-            if ((uint32_t)lo)
-                atomicOr(&win[w], (uint32_t)lo);
-            if ((uint32_t)(lo >> 32))
-                atomicOr(&win[w + 1], (uint32_t)(lo >> 32));
-            if (hi)
-                atomicOr(&win[w + 2], hi);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const bool low_partial = (newcur & 31u) != 0;
-        for (uint32_t i = l + (low_partial ? 1u : 0u); i < nwords; i += 16)
-            W[wlo + i] = win[i];
-        if (nwords)
-            carry = low_partial ? win[0] : 0u;
-        __builtin_amdgcn_wave_barrier();
-        cur = newcur;
-    };
-
-    uint2 rec_next = load_record(tok, n - 1 - l, wide);
-    for (int base = 0; base < nmax; base += 16) {
-        /* lane l of a row owns symbol p = (n - 1 - base) - l, walked at step l */
-        const int hi_p = n - 1 - base;
-        const int p = hi_p - l;
-        const bool valid = p >= 0;
-        const uint2 rec = rec_next;
-        rec_next = load_record(tok, p - 16, wide); /* next round's records are in flight during this round's walk */
-        const uint32_t lo = rec.x;
-        const uint32_t e = ((lo >> 8) & 0xF) * HYDK_ALPHABET + (lo & 0xFF);
-        const uint32_t fbv = s_fb[e];
-        const uint32_t f = valid ? (fbv & 0xFFFFu) : 1u;
-        const uint32_t thr = (uint32_t)(((unsigned long long)f << 20) - 1ull);
-        uint4 op;
-        op.x = DOUBLED ? (uint32_t)(-2 * (int)f) : (uint32_t)(-(int)f);
-        op.y = s_magic[e];
-        op.z = DOUBLED ? (((lo >> 8) & 0xF) * (2u * HYDK_ANS_SLOTS) + 2u * (fbv >> 16)) * 2u
-                       : (((lo >> 8) & 0xF) * (uint32_t)HYDK_ANS_SLOTS + (fbv >> 16)) * 2u;
-        op.w = thr;
-        ops[l] = op;
-        __builtin_amdgcn_wave_barrier();
-        const int cnt = min(16, hi_p + 1); /* per row; <= 0 once the row's group is finished */
-        uint32_t trail = 0;
-#define HYDK_ROW_STEP(k)                                                                                   \
-    do {                                                                                                   \
-        const uint4 o = ops[(k)];                                                                          \
-        trail = (uint32_t)__builtin_amdgcn_update_dpp((int)state, (int)trail, 0x111, 0xF, 0xF, false);     \
-        const uint32_t x = rans_renorm(state, o.w);                                                        \
-        uint32_t q = __umulhi(x, o.y);                                                                     \
-        if (DOUBLED) {                                                                                     \
-            const uint32_t at = mad24(q, o.x, o.z + 2u * x);                                               \
-            state = (q << 12) + *(const uint16_t *)(inv_bytes + at);                                       \
-        } else {                                                                                           \
-            /* q is floor(x/f) or one less: both candidate remainders come straight off the          \
-             * multiply (o.x holds -f; x - f is formed in the multiply-high's shadow) */                   \
-            const uint32_t r0 = mad24(q, o.x, x);                                                          \
-            const uint32_t r1 = mad24(q, o.x, x + o.x);                                                    \
-            const uint32_t r = min(r0, r1);                                                                \
-            q += (int)r1 >= 0;                                                                             \
-            state = (q << 12) | *(const uint16_t *)(inv_bytes + o.z + 2u * r);                             \
-        }                                                                                                  \
-    } while (0)
-        const bool full_round = __all(cnt == 16);
-        if (full_round) {
-            /* every row of the wave has a full round: no per-step predication */
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                HYDK_ROW_STEP(k);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (k < cnt)
-                    HYDK_ROW_STEP(k);
-        }
-#undef HYDK_ROW_STEP
-        __builtin_amdgcn_wave_barrier();
-        /* the state seen by step j sits in lane cnt-1-j of the row */
-        const uint32_t seen = full_round ? HYDK_DPP(trail, 0x140, 0xF) /* row_mirror: lane 15 - l */
-                                         : (uint32_t)__shfl((int)trail, (cnt - 1 - l) & 15, 16);
-        const uint32_t rbits = valid ? (lo >> 16) & 0x3Fu : 0u;
-        const bool refill = valid && seen > thr;
-        const unsigned long long residue = rec.y;
-        const unsigned long long val = refill ? (residue << 16) | (seen & 0xFFFFu) : residue;
-        emit(val, valid ? rbits + (refill ? 16u : 0u) : 0u);
-    }
-    {
-        unsigned long long val = 0;
-        uint32_t nb = 0;
-        if (live && l == 0 && n > 0) {
-            val = state;
-            nb = 32;
-        } else if (live && l == 1) {
-            val = jobs[slot].preset;
-            nb = (uint32_t)preset_bits;
-        }
-        emit(val, nb);
-    }
-    if (l == 0) {
-        if (live && (cur & 31u))
-            W[cur >> 5] = carry;
-        group_bits_all[G] = live ? (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u - cur : 0u;
-    }
-}
-
-template <int WAVES, bool DOUBLED>
-__global__ __launch_bounds__(64 * WAVES) void k_rans_rows(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
-                                                          const uint32_t *sym_count_all, const HydkTables *tabs,
-                                                          uint32_t *bitbuf_all, uint32_t *group_bits_all, int preset_bits) {
-    rans_rows_body<WAVES, DOUBLED>(jobs, tokens_all, sym_count_all, tabs, bitbuf_all, group_bits_all, preset_bits);
-}
-
-/* The throughput form (half an LF group per workgroup), capped at 128 registers: with its 94.7 KB
- * of LDS only one of these fits on a CU, and what decides the pipelined frame rate is how many
- * transform workgroups (128 VGPRs, 34 KB LDS) still fit beside it — two instead of one. */
-__global__ __launch_bounds__(1024) /* launched with 512 threads; the larger bound is what makes the compiler budget 128 registers */
-void k_rans_rows_half(
-    const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all, const uint32_t *sym_count_all, const HydkTables *tabs,
-    uint32_t *bitbuf_all, uint32_t *group_bits_all, int preset_bits) {
-    rans_rows_body<8, false>(jobs, tokens_all, sym_count_all, tabs, bitbuf_all, group_bits_all, preset_bits);
-}
 
 /* ==========================================================================================
  * K3a, throughput form: one LANE per group.  A wavefront carries the 64 chains of one LF group, so
@@ -1303,16 +1127,19 @@ struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs
     uint32_t tab2;  /* byte offset of the symbol's slot list in s_inv: 2 * (cluster * 4096 + base) */
 };
 
-__global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
-                                                   const uint32_t *sym_count_all, const HydkTables *tabs,
-                                                   uint16_t *aux_all, uint16_t *flags_all, uint32_t *final_state_all,
-                                                   int nclusters) {
+__global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
+                                                   const HydkTables *tabs, uint16_t *aux_all, uint16_t *flags_all,
+                                                   uint32_t aux_pitch /* symbols per group in aux / flags */,
+                                                   uint32_t *final_state_all, uint32_t *group_bits_all, int nclusters,
+                                                   int preset_bits, const uint32_t *status) {
     __shared__ uint16_t s_inv[kInvEntries / 2];                       /* plain inverse slot table, 72 KiB */
     __shared__ uint4 s_ops[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];        /* 18 KiB */
     const int lane = threadIdx.x;
     const int slot = blockIdx.x;
     const int ngroups = jobs[slot].gcols * jobs[slot].grows;
     const HydkTables *tab = tabs + slot;
+    if (*status & HYDK_STATUS_OVERFLOW)
+        return; /* the transform stage ran out of token space: the host reruns the frame */
     {
         const uint4 *src = (const uint4 *)&tab->inv1[0][0];
         uint4 *dst = (uint4 *)s_inv;
@@ -1332,9 +1159,11 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     const unsigned char *inv_bytes = (const unsigned char *)s_inv;
     const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + lane;
     const int n = lane < ngroups ? (int)sym_count_all[G] : 0;
-    const uint4 *tok = (const uint4 *)(tokens_all + G * HYDK_TOKENS_PER_GROUP); /* 4-byte records, 4 per uint4 */
-    uint4 *aux = (uint4 *)(aux_all + G * HYDK_TOKENS_PER_GROUP);                 /* u16 per symbol, 8 per uint4 */
-    uint16_t *flags = flags_all + G * (HYDK_TOKENS_PER_GROUP / 16);
+    /* 4-byte records, 4 per uint4 (tok_cap is a multiple of 16: rounds never straddle a group's array) */
+    const uint4 *tok = (const uint4 *)((const char *)jobs[slot].tokens + (size_t)lane * jobs[slot].tok_cap * jobs[slot].rec_bytes);
+    uint4 *aux = (uint4 *)(aux_all + G * aux_pitch); /* u16 per symbol, 8 per uint4 */
+    uint16_t *flags = flags_all + G * (aux_pitch / 16);
+    uint32_t refills = 0;
     int rj = ((n + 15) >> 4) - 1; /* this lane's current round = 16-symbol chunk index; -1: nothing (left) to do */
     int rounds = rj + 1;
 #pragma unroll
@@ -1405,43 +1234,70 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
             aux[rj * 2] = uint4{w16[0], w16[1], w16[2], w16[3]};
             aux[rj * 2 + 1] = uint4{w16[4], w16[5], w16[6], w16[7]};
             flags[rj] = (uint16_t)fl; /* bit (p mod 16): symbol p refills */
+            refills += (uint32_t)__popc(fl);
         }
         rj = rjn;
     }
 #undef HYDK_LANE_STEP
-    if (lane < ngroups)
+    if (lane < ngroups) {
         final_state_all[G] = state;
+        /* [preset id][final state][per symbol: refill word, residue bits] (encoder.c:945, entropy.c:1127-1147) */
+        group_bits_all[G] = (uint32_t)preset_bits + (n > 0 ? 32u : 0u) + 16u * refills + jobs[slot].rbits_total[lane];
+    } else {
+        group_bits_all[G] = 0;
+    }
 }
 
-/* one wave per group: records + the chain's refill words -> bits, filled from the buffer's end
- * (the emission half of k_rans_encode).  grid = 16 x LF groups, block = 256. */
-__global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restrict__ jobs, const uint64_t *tokens_all,
-                                                        const uint32_t *sym_count_all, const uint16_t *aux_all,
-                                                        const uint16_t *flags_all, const uint32_t *final_state_all,
-                                                        uint32_t *bitbuf_all, uint32_t *group_bits_all, int preset_bits) {
-    __shared__ uint32_t s_win[4][kWinWords];
+/* one wave per group: records + the chain's refill words -> bits, written straight to the section's
+ * place in the frame's payload (k_scan_sections has turned the chain's bit counts into byte offsets
+ * and cleared the two words a section may share with its neighbours).  The section is filled from
+ * its END in batches of 256 symbols aligned to the start of the token array (four consecutive symbols
+ * per lane: one aligned 16-byte record load, one 8-byte load of refill words); inside a batch the
+ * stream order [refill_p][residue_p][refill_p+1].. is plain ascending (lane, symbol) order.
+ * grid = 16 x LF groups, block = 256. */
+constexpr int kEmitBatch = 256;
+constexpr int kEmitWin = kEmitBatch + 4; /* 256 symbols x at most 32 bits = 256 words + alignment slack */
+
+__global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
+                                                        const uint16_t *aux_all, const uint16_t *flags_all, uint32_t aux_pitch,
+                                                        const uint32_t *final_state_all, const uint32_t *group_bits_all,
+                                                        const uint64_t *offsets_all, uint8_t *payload, int preset_bits,
+                                                        const uint32_t *status) {
+    __shared__ uint32_t s_win[4][kEmitWin];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int slot = blockIdx.x >> 4;
     const int g = ((blockIdx.x & 15) << 2) + wave;
     const int ngroups = jobs[slot].gcols * jobs[slot].grows;
     const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + g;
-    if (g >= ngroups) {
-        if (lane == 0)
-            group_bits_all[G] = 0;
+    if (g >= ngroups || (*status & HYDK_STATUS_OVERFLOW))
         return;
-    }
-    const uint32_t *tok = (const uint32_t *)(tokens_all + G * HYDK_TOKENS_PER_GROUP);
-    const uint16_t *aux = aux_all + G * HYDK_TOKENS_PER_GROUP;
-    const uint16_t *flags = flags_all + G * (HYDK_TOKENS_PER_GROUP / 16);
-    uint32_t *W = bitbuf_all + G * HYDK_BITWORDS_PER_GROUP;
+    const uint4 *tok = (const uint4 *)((const char *)jobs[slot].tokens + (size_t)g * jobs[slot].tok_cap * jobs[slot].rec_bytes);
+    const uint2 *aux = (const uint2 *)(aux_all + G * aux_pitch);
+    const uint16_t *flags = flags_all + G * (aux_pitch / 16);
+    uint32_t *W = (uint32_t *)payload; /* 256-byte aligned allocation */
     uint32_t *win = s_win[wave];
     const int n = __builtin_amdgcn_readfirstlane((int)sym_count_all[G]);
-    uint32_t cur = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u;
-    uint32_t carry = 0;
+    const uint32_t bits = group_bits_all[G];
+    const unsigned long long lo_bit = offsets_all[G] * 8ull, hi_bit = lo_bit + (unsigned long long)((bits + 7u) & ~7u);
+    /* words this section shares with its neighbours (ORed into; the scan kernel cleared them) */
+    const uint32_t shared_lo = (lo_bit & 31ull) ? (uint32_t)(lo_bit >> 5) : 0xFFFFFFFFu;
+    const uint32_t shared_hi = (hi_bit & 31ull) ? (uint32_t)((hi_bit - 1ull) >> 5) : 0xFFFFFFFFu;
+    /* bit positions relative to the word that holds the section's first bit: they fit 32 bits */
+    const uint32_t wbase = (uint32_t)(lo_bit >> 5);
+    uint32_t cur = (uint32_t)(lo_bit & 31ull) + bits; /* stream start so far */
+    uint32_t carry = 0;                               /* content of the partly filled word at cur >> 5 */
 
-    /* identical to k_rans_encode's: lane 0 nearest the bits already written */
-    auto emit = [&](unsigned long long val, uint32_t nbits) {
-        const uint32_t inc = scan64_inclusive(nbits);
+    auto put = [&](uint32_t word, uint32_t v) {
+        const uint32_t d = wbase + word;
+        if (d == shared_lo || d == shared_hi)
+            atomicOr(&W[d], v);
+        else
+            W[d] = v;
+    };
+    /* four (value, bit count) per lane, in stream order by (lane, index); written in front of what is there */
+    auto emit = [&](const uint32_t (&val)[4], const uint32_t (&nb)[4]) {
+        const uint32_t mine = nb[0] + nb[1] + nb[2] + nb[3];
+        const uint32_t inc = scan64_inclusive(mine);
         const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
         if (!total)
             return;
@@ -1453,57 +1309,78 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
         __builtin_amdgcn_wave_barrier();
         if (lane == 0 && (cur & 31u))
             win[whi - wlo] = carry;
+        /* win[] is private to this wave: lock-step execution + in-order LDS make the phases
+         * visible to each other; the wave barriers only pin the compiler's ordering */
         __builtin_amdgcn_wave_barrier();
-        if (nbits) {
-            const uint32_t pos = cur - inc - wlo * 32u;
-            const uint32_t w = pos >> 5, sh = pos & 31u;
-            const unsigned long long lo = val << sh;
-            if ((uint32_t)lo)
-                atomicOr(&win[w], (uint32_t)lo);
-            if ((uint32_t)(lo >> 32))
-                atomicOr(&win[w + 1], (uint32_t)(lo >> 32));
+        uint32_t pos = newcur + (inc - mine) - wlo * 32u; /* window-relative position of the lane's first value */
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (nb[j]) {
+                const uint32_t w = pos >> 5, sh = pos & 31u;
+                const unsigned long long lo = (unsigned long long)val[j] << sh;
+                if ((uint32_t)lo)
+                    atomicOr(&win[w], (uint32_t)lo);
+                if ((uint32_t)(lo >> 32))
+                    atomicOr(&win[w + 1], (uint32_t)(lo >> 32));
+            }
+            pos += nb[j];
         }
         __builtin_amdgcn_wave_barrier();
         const bool low_partial = (newcur & 31u) != 0;
         for (uint32_t i = lane + (low_partial ? 1u : 0u); i < nwords; i += 64)
-            W[wlo + i] = win[i];
+            put(wlo + i, win[i]);
         carry = low_partial ? win[0] : 0u;
         __builtin_amdgcn_wave_barrier();
         cur = newcur;
     };
 
-    for (int hi_p = n - 1; hi_p >= 0; hi_p -= 64) {
-        const int p = hi_p - lane;
-        uint32_t rec = 0, a = 0, fl = 0;
-        if (p >= 0) {
-            rec = tok[p];
-            a = aux[p];
-            fl = ((uint32_t)flags[p >> 4] >> (p & 15)) & 1u;
+    /* the next batch's records, refill words and flags travel while this one is being written */
+    uint4 rec_n = {0, 0, 0, 0};
+    uint2 a_n = {0, 0};
+    uint32_t fl_n = 0;
+    auto fetch = [&](int batch) {
+        const int p0 = batch * kEmitBatch + 4 * lane;
+        if (batch >= 0 && p0 < n) { /* the arrays are padded to a multiple of 16 symbols: whole quads are readable */
+            rec_n = tok[p0 >> 2];
+            a_n = aux[p0 >> 2];
+            fl_n = flags[p0 >> 4];
         }
-        const uint32_t rbits = (rec >> 11) & 0x1Fu; /* 0 for p < 0 */
-        const unsigned long long residue = rec >> 16;
-        /* refill p is written just before residue p (entropy.c:1134-1147), i.e. prepended after it;
-         * at most 16 + 16 bits per symbol for integer input */
-        const unsigned long long val = fl ? (residue << 16) | a : residue;
-        emit(val, rbits + (fl ? 16u : 0u));
-    }
-    {
-        unsigned long long val = 0;
-        uint32_t nb = 0;
-        if (lane == 0 && n > 0) {
-            val = final_state_all[G];
-            nb = 32;
-        } else if (lane == 1) {
-            val = jobs[slot].preset;
-            nb = (uint32_t)preset_bits;
+    };
+    const int batches = (n + kEmitBatch - 1) / kEmitBatch;
+    fetch(batches - 1);
+    for (int b = batches - 1; b >= 0; b--) {
+        const int p0 = b * kEmitBatch + 4 * lane;
+        const uint32_t recs[4] = {rec_n.x, rec_n.y, rec_n.z, rec_n.w};
+        const uint32_t aw[4] = {a_n.x & 0xFFFFu, a_n.x >> 16, a_n.y & 0xFFFFu, a_n.y >> 16};
+        const uint32_t flq = fl_n >> (p0 & 15);
+        fetch(b - 1);
+        uint32_t val[4], nb[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool valid = p0 + j < n;
+            const bool refill = valid && ((flq >> j) & 1u);
+            const uint32_t rbits = (recs[j] >> 11) & 0x1Fu, residue = recs[j] >> 16;
+            /* refill p is written just before residue p (entropy.c:1134-1147): at most 16 + 16 bits for integer input */
+            val[j] = refill ? (residue << 16) | aw[j] : residue;
+            nb[j] = valid ? rbits + (refill ? 16u : 0u) : 0u;
         }
         emit(val, nb);
     }
-    if (lane == 0) {
-        if (cur & 31u)
-            W[cur >> 5] = carry;
-        group_bits_all[G] = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u - cur;
+    {
+        /* [preset id][final state, low half first] precede everything (encoder.c:945, entropy.c:1127-1130) */
+        uint32_t val[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0};
+        if (lane == 0) {
+            val[0] = jobs[slot].preset;
+            nb[0] = (uint32_t)preset_bits;
+            if (n > 0) {
+                val[1] = final_state_all[G];
+                nb[1] = 32;
+            }
+        }
+        emit(val, nb);
     }
+    if (lane == 0 && (cur & 31u))
+        put(cur >> 5, carry);
 }
 
 /* ==========================================================================================
@@ -1511,7 +1388,8 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
  * Sections are byte-padded with zeros, as hyd_bitwriter_flush does (bitwriter.c:144-150).
  * ======================================================================================== */
 __global__ __launch_bounds__(1024) void k_scan_sections(const uint32_t *group_bits, int count, uint64_t *offsets,
-                                                        uint64_t *total) {
+                                                        uint64_t *total, uint8_t *payload, uint64_t payload_cap,
+                                                        int clear_shared_words, uint32_t *status) {
     __shared__ uint64_t s_part[1024];
     const int t = threadIdx.x;
     const int per = (count + 1023) / 1024;
@@ -1526,29 +1404,43 @@ __global__ __launch_bounds__(1024) void k_scan_sections(const uint32_t *group_bi
         s_part[t] += v;
         __syncthreads();
     }
+    const uint64_t all = s_part[1023];
+    const bool fits = all <= payload_cap && !(*status & HYDK_STATUS_OVERFLOW);
     uint64_t run = s_part[t] - sum;
     for (int i = t * per; i < min(count, (t + 1) * per); i++) {
+        const uint64_t nbytes = (group_bits[i] + 7u) >> 3;
         offsets[i] = run;
-        run += (group_bits[i] + 7u) >> 3;
+        if (clear_shared_words && fits && nbytes) {
+            /* k_rans_emit ORs into the first / last word of a section when a neighbour owns part of it */
+            if (run & 3u)
+                ((uint32_t *)payload)[run >> 2] = 0;
+            if ((run + nbytes) & 3u)
+                ((uint32_t *)payload)[(run + nbytes - 1) >> 2] = 0;
+        }
+        run += nbytes;
     }
-    if (t == 1023)
-        *total = s_part[1023];
+    if (t == 1023) {
+        *total = fits ? all : 0;
+        if (all > payload_cap)
+            atomicOr(status, HYDK_STATUS_PAYLOAD); /* the host enlarges the payload and reruns the frame */
+    }
 }
 
-__global__ __launch_bounds__(kThreads) void k_pack_sections(const uint32_t *bitbuf, const uint32_t *group_bits,
-                                                            const uint64_t *offsets, uint8_t *payload) {
+__global__ __launch_bounds__(kThreads) void k_pack_sections(const uint32_t *bitbuf, uint32_t bit_pitch_words,
+                                                            const uint32_t *group_bits, const uint64_t *offsets,
+                                                            uint8_t *payload, const uint32_t *status) {
     const int G = blockIdx.x;
     const uint32_t bits = group_bits[G];
-    if (!bits)
+    if (!bits || (*status & HYDK_STATUS_OVERFLOW))
         return;
     const uint32_t nbytes = (bits + 7u) >> 3;
-    const uint32_t *W = bitbuf + (size_t)G * HYDK_BITWORDS_PER_GROUP;
-    const uint32_t start = (uint32_t)HYDK_BITWORDS_PER_GROUP * 32u - bits;
+    const uint32_t *W = bitbuf + (size_t)G * bit_pitch_words;
+    const uint32_t start = bit_pitch_words * 32u - bits;
     const uint32_t sw = start >> 5, sh = start & 31u;
     uint8_t *dst = payload + offsets[G];
     for (uint32_t k = threadIdx.x; k * 4u < nbytes; k += kThreads) {
         const uint32_t w0 = W[sw + k];
-        const uint32_t w1 = sw + k + 1 < (uint32_t)HYDK_BITWORDS_PER_GROUP ? W[sw + k + 1] : 0u;
+        const uint32_t w1 = sw + k + 1 < bit_pitch_words ? W[sw + k + 1] : 0u;
         const uint32_t v = sh ? (w0 >> sh) | (w1 << (32u - sh)) : w0;
         const uint32_t lim = min(4u, nbytes - k * 4u);
         for (uint32_t bidx = 0; bidx < lim; bidx++)
@@ -1614,48 +1506,41 @@ hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t 
     return hipGetLastError();
 }
 
-hipError_t launch_rans(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
-                       uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int waves,
+hipError_t launch_rans(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint32_t *bitbuf,
+                       uint32_t bit_pitch_words, uint32_t *group_bits, int preset_bits, int num_slots, const uint32_t *status,
                        hipStream_t stream) {
-    (void)waves; /* the doubled table + operand staging leave LDS room for exactly four groups per workgroup */
-    hipLaunchKernelGGL(k_rans_encode<4>, dim3(num_slots * 16), dim3(256), 0, stream, d_jobs, tokens, sym_count, tabs,
-                           bitbuf, group_bits, preset_bits);
+    hipLaunchKernelGGL(k_rans_encode<4>, dim3(num_slots * 16), dim3(256), 0, stream, d_jobs, sym_count, tabs, bitbuf,
+                       bit_pitch_words, group_bits, preset_bits, status);
     return hipGetLastError();
 }
 
-hipError_t launch_rans_rows(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
-                            uint32_t *bitbuf, uint32_t *group_bits, int preset_bits, int num_slots, int whole_lf_group,
-                            hipStream_t stream) {
-    if (whole_lf_group == 2)
-        hipLaunchKernelGGL(k_rans_rows_half, dim3(num_slots * 2), dim3(512), 0, stream, d_jobs, tokens, sym_count, tabs,
-                           bitbuf, group_bits, preset_bits);
-    else if (whole_lf_group)
-        hipLaunchKernelGGL((k_rans_rows<16, false>), dim3(num_slots), dim3(1024), 0, stream, d_jobs, tokens, sym_count, tabs,
-                           bitbuf, group_bits, preset_bits);
-    else
-        hipLaunchKernelGGL((k_rans_rows<4, true>), dim3(num_slots * 4), dim3(256), 0, stream, d_jobs, tokens, sym_count, tabs,
-                           bitbuf, group_bits, preset_bits);
+hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint16_t *aux,
+                             uint16_t *flags, uint32_t aux_pitch, uint32_t *final_state, uint32_t *group_bits, int preset_bits,
+                             int nclusters, int num_slots, const uint32_t *status, hipStream_t stream) {
+    hipLaunchKernelGGL(k_rans_lanes, dim3(num_slots), dim3(64), 0, stream, d_jobs, sym_count, tabs, aux, flags, aux_pitch,
+                       final_state, group_bits, nclusters, preset_bits, status);
     return hipGetLastError();
 }
 
-hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint64_t *tokens, const uint32_t *sym_count, const HydkTables *tabs,
-                             uint16_t *aux, uint16_t *flags, uint32_t *final_state, uint32_t *bitbuf, uint32_t *group_bits,
-                             int preset_bits, int nclusters, int num_slots, hipStream_t stream) {
-    hipLaunchKernelGGL(k_rans_lanes, dim3(num_slots), dim3(64), 0, stream, d_jobs, tokens, sym_count, tabs, aux, flags,
-                       final_state, nclusters);
-    hipLaunchKernelGGL(k_rans_emit, dim3(num_slots * 16), dim3(kThreads), 0, stream, d_jobs, tokens, sym_count, aux, flags,
-                       final_state, bitbuf, group_bits, preset_bits);
+hipError_t launch_rans_emit(const HydkLfJob *d_jobs, const uint32_t *sym_count, const uint16_t *aux, const uint16_t *flags,
+                            uint32_t aux_pitch, const uint32_t *final_state, const uint32_t *group_bits, const uint64_t *offsets,
+                            uint8_t *payload, int preset_bits, int num_slots, const uint32_t *status, hipStream_t stream) {
+    hipLaunchKernelGGL(k_rans_emit, dim3(num_slots * 16), dim3(kThreads), 0, stream, d_jobs, sym_count, aux, flags, aux_pitch,
+                       final_state, group_bits, offsets, payload, preset_bits, status);
     return hipGetLastError();
 }
 
-hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, hipStream_t stream) {
-    hipLaunchKernelGGL(k_scan_sections, dim3(1), dim3(1024), 0, stream, group_bits, count, offsets, total);
+hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, uint8_t *payload,
+                       uint64_t payload_cap, int clear_shared_words, uint32_t *status, hipStream_t stream) {
+    hipLaunchKernelGGL(k_scan_sections, dim3(1), dim3(1024), 0, stream, group_bits, count, offsets, total, payload, payload_cap,
+                       clear_shared_words, status);
     return hipGetLastError();
 }
 
-hipError_t launch_pack(const uint32_t *bitbuf, const uint32_t *group_bits, const uint64_t *offsets, uint8_t *payload,
-                       int count, hipStream_t stream) {
-    hipLaunchKernelGGL(k_pack_sections, dim3(count), dim3(kThreads), 0, stream, bitbuf, group_bits, offsets, payload);
+hipError_t launch_pack(const uint32_t *bitbuf, uint32_t bit_pitch_words, const uint32_t *group_bits, const uint64_t *offsets,
+                       uint8_t *payload, int count, const uint32_t *status, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pack_sections, dim3(count), dim3(kThreads), 0, stream, bitbuf, bit_pitch_words, group_bits, offsets,
+                       payload, status);
     return hipGetLastError();
 }
 

@@ -20,7 +20,6 @@ GROUPS_PER_LFG = 64
 K_NAMES = ("transform_tokenize", "build_tables", "rans_encode", "pack_sections", "lf_coder")
 LF_INFO_DTYPE = np.dtype([("bit_count", "<u4"), ("alphabet", "<u4"), ("run_pairs", "<u4"), ("error", "<u4"),
                           ("offset", "<u4"), ("reserved", "<u4", (3,)), ("lengths", "u1", (384,))])
-BITWORDS_PER_GROUP = (196608 * 46 + 64 + 31) // 32 + 1  # csrc/hip/hydk_common.h HYDK_BITWORDS_PER_GROUP
 LF_BITWORDS = 3 * 256 * 256 * 2 + 2                     # HYDK_LF_BITWORDS
 LF_CODES = 384  # compact token space of the LF-coefficient stream (include/hydrium_amd.h HYDAMD_LF_CODES)
 
@@ -83,6 +82,12 @@ def dll(path: Optional[str] = None):
         d.hydamd_sync.argtypes = [vp]
         d.hydamd_payload_size.restype = sz
         d.hydamd_payload_size.argtypes = [vp]
+        d.hydamd_payload_capacity.restype = sz
+        d.hydamd_payload_capacity.argtypes = [vp]
+        d.hydamd_token_capacity.restype = u
+        d.hydamd_token_capacity.argtypes = [vp]
+        d.hydamd_overflow_reruns.restype = u
+        d.hydamd_overflow_reruns.argtypes = [vp]
         d.hydamd_payload_device.restype = vp
         d.hydamd_payload_device.argtypes = [vp]
         d.hydamd_read_payload.argtypes = [vp, vp, sz]
@@ -257,8 +262,14 @@ class DeviceContext:
 
     def payload_tensor(self):
         """Zero-copy torch uint8 view of the packed HF sections in HBM (valid until the next frame)."""
-        cap = self.max_lf_groups * GROUPS_PER_LFG * BITWORDS_PER_GROUP * 4
-        return self._device_view("payload", self.payload_device_ptr(), cap)[: self.payload_size()]
+        cap = int(self.d.hydamd_payload_capacity(self.h))  # pointer and capacity change if a frame outgrew the buffers
+        return self._device_view(("payload", cap), self.payload_device_ptr(), cap)[: self.payload_size()]
+
+    def token_capacity(self) -> int:
+        return int(self.d.hydamd_token_capacity(self.h))
+
+    def overflow_reruns(self) -> int:
+        return int(self.d.hydamd_overflow_reruns(self.h))
 
     def read_payload(self) -> bytes:
         n = self.payload_size()

@@ -84,9 +84,10 @@ HYDAMD_EXPORT int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode);
 /* Form of the entropy (rANS) stage.  The recurrence is serial per group, so the forms trade the
  * latency of one frame against how much of the GPU the stage occupies while it runs:
  *   4   one wavefront per group, 4 groups per workgroup (default): lowest single-frame latency
- *   1   four chains per wavefront (one per 16-lane row), 16 groups per workgroup
- *   3   same, half an LF group (32 groups) per workgroup, half-size table: best when many frames are in flight
- *   2   same, a whole LF group (64 groups) per workgroup */
+ *   5   one LANE per group: a single wavefront walks the 64 chains of an LF group and a second, wave-
+ *       parallel kernel writes the bits straight into the payload; a fifteenth of the instructions and
+ *       a sixty-fourth of the wavefronts of form 4 — best when many frames are in flight.  LF groups
+ *       with float samples are still coded by form 4. */
 HYDAMD_EXPORT int hydamd_set_rans_waves(HydAmdContext *ctx, int waves);
 
 /* Start a frame of `num_presets` presets (= LF groups, at most 255): clears histograms and the running alphabet. */
@@ -133,7 +134,16 @@ HYDAMD_EXPORT int hydamd_sync(HydAmdContext *ctx);
 
 /* ---- results; valid after hydamd_sync() ---- */
 HYDAMD_EXPORT size_t hydamd_payload_size(HydAmdContext *ctx);
+/* The device pointer may change when a frame outgrows its buffers (see below): fetch it after hydamd_sync(). */
 HYDAMD_EXPORT const uint8_t *hydamd_payload_device(HydAmdContext *ctx);
+/* Buffers are sized for typical content (1.5 symbols and 1 byte of sections per pixel) rather than for
+ * the format's hard maximum.  A frame that needs more is detected on the device; hydamd_sync() then
+ * enlarges the arrays and runs the frame again before it returns — transparent to the caller except
+ * for the time it takes and for device pointers fetched earlier.  These report the current sizes and
+ * how often that happened (a context that met one such frame stays enlarged). */
+HYDAMD_EXPORT size_t hydamd_payload_capacity(HydAmdContext *ctx);
+HYDAMD_EXPORT unsigned hydamd_token_capacity(HydAmdContext *ctx);
+HYDAMD_EXPORT unsigned hydamd_overflow_reruns(HydAmdContext *ctx);
 HYDAMD_EXPORT int hydamd_read_payload(HydAmdContext *ctx, uint8_t *dst, size_t capacity);
 /* bits[g] = exact bit length of group g's section (0 for absent groups), offsets[g] = byte offset in the payload */
 HYDAMD_EXPORT int hydamd_read_sections(HydAmdContext *ctx, int slot, uint32_t bits[HYDAMD_GROUPS_PER_LFG],

@@ -6,7 +6,7 @@ from hydrium_amd import device, synth
 img = synth.make_image("photo", 8192, 8192, 16, device="cuda")
 ctxs = [device.DeviceContext(0, 16) for _ in range(12)]
 for c in ctxs:
-    c.set_rans_waves(3); c.set_lf_coder(2); c.encode_image_tensor(img)
+    c.set_rans_waves(5); c.set_lf_coder(2); c.encode_image_tensor(img)
 for c in ctxs: c.sync()
 # host cost of enqueuing one frame when the GPU is idle
 ts = []

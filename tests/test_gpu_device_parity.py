@@ -4,6 +4,8 @@ Bar: bit-exact for everything integer (LF ints, quantised coefficients, tokens, 
 section bytes); the XYB and DCT float intermediates are also required to be bit-identical
 (tolerance 0 ulp; +0.0 and -0.0 compare equal, see kernels.hip dct8).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -160,3 +162,36 @@ def test_planar_and_strided_inputs(image):
         ctx.finish_frame(1)
         ctx.sync()
         assert ctx.read_payload() == res.stream
+
+
+@pytest.mark.parametrize("form", [4, 5])
+def test_frame_that_outgrows_its_buffers_is_rerun_transparently(form):
+    """Token arrays and the payload are sized for typical content; a noise frame (2.9 symbols and 1.8
+    bytes per pixel) overflows both on the device and hydamd_sync() reruns it with the hard maxima."""
+    import subprocess
+    import sys
+
+    code = f"""
+import numpy as np, torch
+from hydrium_amd import device, synth
+from oracle import binding as orc
+img = synth.make_image("noise", 520, 300, 8)
+want, _ = orc.encode_lf_group(img)
+with device.DeviceContext(0, 1, 0) as ctx:
+    ctx.set_rans_waves({form})
+    assert ctx.token_capacity() == 4096
+    t = torch.from_numpy(img).cuda()
+    ctx.encode_image_tensor(t); ctx.sync()
+    assert ctx.overflow_reruns() >= 1 and ctx.token_capacity() == 196608, (ctx.overflow_reruns(), ctx.token_capacity())
+    assert ctx.read_payload() == want.stream
+    ctx.encode_image_tensor(t); ctx.sync()            # the context stays enlarged: no second rerun
+    assert ctx.overflow_reruns() == 1 or ctx.overflow_reruns() == 2
+    n = ctx.overflow_reruns()
+    ctx.encode_image_tensor(t); ctx.sync()
+    assert ctx.overflow_reruns() == n and ctx.read_payload() == want.stream
+print("ok")
+"""
+    env = dict(os.environ, HYDAMD_TOKEN_CAP="4096", HYDAMD_PAYLOAD_CAP="65536",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr

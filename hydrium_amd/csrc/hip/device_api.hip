@@ -41,7 +41,11 @@ namespace hydk {
 hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, int xmode, uint32_t *status,
                             hipStream_t stream);
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int first_slot,
-                         int num_slots, uint32_t alpha_floor, hipStream_t stream);
+                         int num_slots, uint32_t alpha_floor, const uint32_t *alpha_floor_dev, hipStream_t stream);
+hipError_t launch_export(const HydkLfJob *d_jobs, const HydkTables *tabs, const uint32_t *group_bits, const HydkLfStream *lf_streams,
+                         const uint8_t *payload, const uint64_t *hf_total, const uint8_t *lf_packed,
+                         const unsigned long long *lf_total, const uint32_t *status, int num_slots, int lf_coded, uint8_t *dst,
+                         uint64_t capacity, hipStream_t stream);
 hipError_t launch_rans(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint32_t *bitbuf,
                        uint32_t bit_pitch_words, uint32_t *group_bits, int preset_bits, int num_slots, const uint32_t *status,
                        hipStream_t stream);
@@ -70,6 +74,9 @@ hipError_t launch_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, 
 #define ST_API_ERROR (-14)
 #define ST_INTERNAL_ERROR (-15)
 
+static_assert(sizeof(HydAmdBlobHeader) == 64 && sizeof(HydAmdBlobSlot) == 16 + 36 + 12 + 256 + 4608 + sizeof(HydkLfStream) &&
+                  sizeof(HydAmdBlobSlot) % 16 == 0,
+              "blob records are laid out by k_export_frame word by word");
 static_assert(HYDAMD_MAX_CLUSTERS == HYDK_MAX_CLUSTERS && HYDAMD_ALPHABET == HYDK_ALPHABET &&
                   HYDAMD_GROUPS_PER_LFG == HYDK_GROUPS_PER_LFG && HYDAMD_LF_CODES == HYDK_LF_CODES,
               "public and kernel-side table shapes must agree");
@@ -103,6 +110,7 @@ struct HydAmdContext {
     bool slot_lanes[HYDAMD_MAX_LF_GROUPS] = {}; /* which entropy form coded each slot of the current frame */
     unsigned overflow_reruns = 0;   /* frames run twice because a buffer was too small (hydamd_overflow_reruns) */
     uint32_t alpha_floor = 0;       /* running maximum alphabet of the LF groups coded before this context's */
+    const uint32_t *alpha_floor_dev = nullptr; /* the same, left in device memory by the caller's exchange (or NULL) */
     unsigned num_presets = 1;
     int scheme = 0;
     int nclusters = 9;
@@ -604,7 +612,7 @@ static int alloc_frame_arrays(HydAmdContext *ctx, size_t payload_cap) {
     HIP_TRY(ctx, hipMalloc(&ctx->rans_aux, groups * ctx->tok_cap * sizeof(uint16_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->rans_flags, groups * (ctx->tok_cap / 16) * sizeof(uint16_t)));
     ctx->payload_cap = payload_cap;
-    HIP_TRY(ctx, hipMalloc(&ctx->payload, payload_cap + 8)); /* + 8: the emit kernel addresses whole words */
+    HIP_TRY(ctx, hipMalloc(&ctx->payload, payload_cap + 16)); /* + 16: the emit and export kernels move whole words / 16-byte pieces */
     if (had_bitbuf) {
         ctx->bit_pitch_words = HYDK_BITWORDS_FOR(ctx->tok_cap);
         HIP_TRY(ctx, hipMalloc(&ctx->bitbuf, groups * ctx->bit_pitch_words * sizeof(uint32_t)));
@@ -849,6 +857,7 @@ int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
                                 (size_t)ctx->max_slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->alpha_max, 0, (size_t)ctx->max_slots * sizeof(uint32_t), ctx->stream));
     ctx->alpha_floor = 0;
+    ctx->alpha_floor_dev = nullptr;
     HIP_TRY(ctx, hipMemsetAsync(ctx->status, 0, sizeof(uint32_t), ctx->stream));
     return ST_OK;
 }
@@ -1104,13 +1113,45 @@ int hydamd_set_alphabet_floor(HydAmdContext *ctx, uint32_t floor) {
     return ST_OK;
 }
 
+const uint32_t *hydamd_alphabet_max_device(HydAmdContext *ctx) { return ctx ? ctx->alpha_max : nullptr; }
+
+int hydamd_set_alphabet_floor_device(HydAmdContext *ctx, const uint32_t *floor_on_device) {
+    if (!ctx)
+        return ST_API_ERROR;
+    ctx->alpha_floor_dev = floor_on_device;
+    return ST_OK;
+}
+
+size_t hydamd_blob_bound(HydAmdContext *ctx, int num_slots) {
+    if (!ctx || num_slots < 1 || num_slots > ctx->max_slots)
+        return 0;
+    const size_t lf = (size_t)num_slots * HYDK_LF_BITWORDS * sizeof(uint32_t);
+    return sizeof(HydAmdBlobHeader) + (size_t)num_slots * sizeof(HydAmdBlobSlot) + lf + 16 + ctx->payload_cap + 16;
+}
+
+int hydamd_export_frame(HydAmdContext *ctx, int num_slots, void *device_dst, size_t capacity) {
+    if (!ctx || !device_dst)
+        return ST_API_ERROR;
+    if (num_slots < 1 || num_slots > ctx->coded || num_slots != ctx->slots_finished)
+        return fail(ctx, ST_API_ERROR, "export needs the entropy stage of the same slots enqueued first");
+    if (ctx->lf_on_device && (ctx->lf_need_gather || ctx->lf_slots != num_slots))
+        return fail(ctx, ST_API_ERROR, "export needs the frame's LF streams packed (hydamd_run_entropy does it)");
+    if (capacity < sizeof(HydAmdBlobHeader))
+        return fail(ctx, ST_API_ERROR, "blob buffer smaller than its header");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hydk::launch_export(ctx->d_jobs, ctx->tables, ctx->group_bits, ctx->lf_streams, ctx->payload, ctx->total,
+                                     (const uint8_t *)ctx->lf_packed, ctx->lf_total, ctx->status, num_slots,
+                                     ctx->lf_on_device ? 1 : 0, (uint8_t *)device_dst, capacity, ctx->stream));
+    return ST_OK;
+}
+
 /* K2 + the rANS chains for slots [first, first + count) */
 static int entropy_range(HydAmdContext *ctx, int first, int count) {
     const size_t G = HYDK_GROUPS_PER_LFG, g0 = (size_t)first * G;
     {
         ScopedTimer timer(ctx, HYDAMD_K_TABLES);
         HIP_TRY(ctx, hydk::launch_tables(ctx->hist, ctx->tables, ctx->alpha_max, ctx->nclusters, first, count,
-                                         ctx->alpha_floor, ctx->stream));
+                                         ctx->alpha_floor, ctx->alpha_floor_dev, ctx->stream));
     }
     {
         ScopedTimer timer(ctx, HYDAMD_K_RANS);

@@ -697,7 +697,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
  * ======================================================================================== */
 __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_all, HydkTables *tabs,
                                                            const uint32_t *alpha_max_all, int nclusters,
-                                                           uint32_t alpha_floor, int first_slot) {
+                                                           uint32_t alpha_floor, const uint32_t *alpha_floor_dev,
+                                                           int first_slot) {
     const unsigned slot = (unsigned)first_slot + blockIdx.x; /* all arrays are indexed by the frame's slot */
     const uint32_t *hist = hist_all + (size_t)slot * HYDK_MAX_CLUSTERS * HYDK_ALPHABET;
     HydkTables *tab = tabs + slot;
@@ -736,6 +737,8 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
         /* the stream-wide alphabet maximum is never reset between LF groups (entropy.c:459-460,952):
          * LF group n codes with the maximum over LF groups 0..n in send order */
         uint32_t mx = alpha_floor; /* maximum over the LF groups other GPUs coded before ours */
+        if (alpha_floor_dev)       /* ... when it was exchanged on the device (no host round trip) */
+            mx = max(mx, *alpha_floor_dev);
         for (unsigned sl = 0; sl <= slot; sl++)
             mx = max(mx, alpha_max_all[sl]);
         uint32_t lg = mx > 1 ? 32 - __clz((int)(mx - 1)) : 0; /* ceil(log2(mx)) */
@@ -1449,6 +1452,84 @@ __global__ __launch_bounds__(kThreads) void k_pack_sections(const uint32_t *bitb
 }
 
 /* ==========================================================================================
+ * Export: everything another process needs to put this context's LF groups into a frame, as one
+ * self-describing blob in a caller-provided device buffer (include/hydrium_amd.h HydAmdBlobHeader /
+ * HydAmdBlobSlot): what a multi-GPU job gathers, with one collective, to the rank that assembles.
+ * grid = num_slots + 1 + kExportCopyBlocks, block = 256.
+ * ======================================================================================== */
+constexpr int kExportCopyBlocks = 120;
+constexpr uint32_t kBlobMagic = 0x42445948u; /* "HYDB" */
+constexpr int kBlobHeaderBytes = 64, kBlobSlotBytes = 16 + 36 + 12 + 256 + 4608 + (int)sizeof(HydkLfStream);
+
+__global__ __launch_bounds__(kThreads) void k_export_frame(const HydkLfJob *__restrict__ jobs, const HydkTables *tabs,
+                                                           const uint32_t *group_bits, const HydkLfStream *lf_streams,
+                                                           const uint8_t *payload, const uint64_t *hf_total,
+                                                           const uint8_t *lf_packed, const unsigned long long *lf_total,
+                                                           const uint32_t *status, int num_slots, int lf_coded,
+                                                           uint8_t *dst, uint64_t capacity) {
+    const int t = threadIdx.x, b = blockIdx.x;
+    const uint64_t hf_bytes = *hf_total, lf_bytes = lf_coded ? (uint64_t)*lf_total : 0;
+    const uint64_t lf_off = (uint64_t)kBlobHeaderBytes + (uint64_t)num_slots * kBlobSlotBytes;
+    const uint64_t hf_off = (lf_off + lf_bytes + 15ull) & ~15ull;
+    const uint64_t total = hf_off + hf_bytes;
+    const bool fits = total + 16 <= capacity; /* the copies below move whole 16-byte pieces */
+    if (b < num_slots) {
+        if (capacity < lf_off)
+            return;
+        uint32_t *rec = (uint32_t *)(dst + kBlobHeaderBytes + (size_t)b * kBlobSlotBytes);
+        const HydkTables *tab = tabs + b;
+        if (t == 0) {
+            rec[0] = jobs[b].preset;
+            rec[1] = tab->running_max_alphabet;
+            rec[2] = tab->log_alphabet_size;
+            rec[3] = tab->error;
+        }
+        if (t < HYDK_MAX_CLUSTERS)
+            rec[4 + t] = tab->alphabet[t];
+        if (t < 3)
+            rec[13 + t] = 0;
+        if (t < HYDK_GROUPS_PER_LFG)
+            rec[16 + t] = group_bits[(size_t)b * HYDK_GROUPS_PER_LFG + t];
+        for (int i = t; i < HYDK_MAX_CLUSTERS * HYDK_ALPHABET; i += kThreads)
+            rec[80 + i] = (&tab->freq[0][0])[i];
+        const uint32_t *lf = (const uint32_t *)(lf_streams + b);
+        for (int i = t; i < (int)(sizeof(HydkLfStream) / 4); i += kThreads)
+            rec[80 + HYDK_MAX_CLUSTERS * HYDK_ALPHABET + i] = lf_coded ? lf[i] : 0u;
+        return;
+    }
+    if (b == num_slots) {
+        if (t == 0 && capacity >= (uint64_t)kBlobHeaderBytes) {
+            uint32_t *h32 = (uint32_t *)dst;
+            uint64_t *h64 = (uint64_t *)dst;
+            h32[0] = kBlobMagic;
+            h32[1] = 1; /* layout version */
+            h32[2] = (uint32_t)num_slots;
+            h32[3] = *status | (fits ? 0u : HYDK_STATUS_PAYLOAD); /* an undersized blob reads like an undersized payload */
+            h64[2] = hf_bytes;
+            h64[3] = lf_bytes;
+            h64[4] = total;
+            h32[10] = (uint32_t)lf_coded;
+            for (int i = 11; i < 16; i++)
+                h32[i] = 0;
+        }
+        return;
+    }
+    if (!fits)
+        return;
+    /* the two byte strings, 16 bytes per thread and step (both sources and both targets are 16-byte aligned) */
+    const int cb = b - num_slots - 1;
+    const size_t stride = (size_t)kExportCopyBlocks * kThreads;
+    const uint4 *s1 = (const uint4 *)lf_packed;
+    uint4 *d1 = (uint4 *)(dst + lf_off);
+    for (size_t i = (size_t)cb * kThreads + t; i < (size_t)((lf_bytes + 15) >> 4); i += stride)
+        d1[i] = s1[i];
+    const uint4 *s2 = (const uint4 *)payload;
+    uint4 *d2 = (uint4 *)(dst + hf_off);
+    for (size_t i = (size_t)cb * kThreads + t; i < (size_t)((hf_bytes + 15) >> 4); i += stride)
+        d2[i] = s2[i];
+}
+
+/* ==========================================================================================
  * Self-test: do the register evaluations of the format.c LUTs reproduce the host-built tables
  * bit for bit?  (If not, the launcher keeps the exact LUT-gather variant of K1.)
  * ======================================================================================== */
@@ -1500,9 +1581,9 @@ hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt
 }
 
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int first_slot,
-                         int num_slots, uint32_t alpha_floor, hipStream_t stream) {
+                         int num_slots, uint32_t alpha_floor, const uint32_t *alpha_floor_dev, hipStream_t stream) {
     hipLaunchKernelGGL(k_build_tables, dim3(num_slots), dim3(kThreads), 0, stream, hist, tabs, alpha_max, nclusters,
-                       alpha_floor, first_slot);
+                       alpha_floor, alpha_floor_dev, first_slot);
     return hipGetLastError();
 }
 
@@ -1541,6 +1622,15 @@ hipError_t launch_pack(const uint32_t *bitbuf, uint32_t bit_pitch_words, const u
                        uint8_t *payload, int count, const uint32_t *status, hipStream_t stream) {
     hipLaunchKernelGGL(k_pack_sections, dim3(count), dim3(kThreads), 0, stream, bitbuf, bit_pitch_words, group_bits, offsets,
                        payload, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_export(const HydkLfJob *d_jobs, const HydkTables *tabs, const uint32_t *group_bits, const HydkLfStream *lf_streams,
+                         const uint8_t *payload, const uint64_t *hf_total, const uint8_t *lf_packed,
+                         const unsigned long long *lf_total, const uint32_t *status, int num_slots, int lf_coded, uint8_t *dst,
+                         uint64_t capacity, hipStream_t stream) {
+    hipLaunchKernelGGL(k_export_frame, dim3(num_slots + 1 + kExportCopyBlocks), dim3(kThreads), 0, stream, d_jobs, tabs,
+                       group_bits, lf_streams, payload, hf_total, lf_packed, lf_total, status, num_slots, lf_coded, dst, capacity);
     return hipGetLastError();
 }
 

@@ -1043,6 +1043,100 @@ HYDRIUM_EXPORT int hydamd_frame_from_streams(const HYDImageMetadata *md, int wri
                             payload, payload_len, icc, icc_size, out, out_len, err);
 }
 
+/* From the blobs hydamd_export_frame leaves on the GPUs that coded the frame's LF groups (copied to
+ * host memory by the caller): the same assembly, no GPU. */
+HYDRIUM_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write_header, int is_last, size_t nblobs,
+                                           const void *const *blobs, const size_t *blob_sizes, const uint8_t *icc,
+                                           size_t icc_size, uint8_t **out, size_t *out_len, const char **err) {
+    static const char *const bad = "malformed LF-group blob";
+    if (!md || !blobs || !blob_sizes || !out || !out_len || !nblobs) {
+        if (err)
+            *err = "null argument";
+        return HYD_API_ERROR;
+    }
+    size_t slots = 0, hf_total = 0;
+    for (size_t b = 0; b < nblobs; b++) {
+        const HydAmdBlobHeader *h = blobs[b];
+        if (!h || blob_sizes[b] < sizeof(*h) || h->magic != 0x42445948u || h->version != 1 || h->total_bytes > blob_sizes[b] ||
+            (h->status & HYDAMD_BLOB_RETRY) || !h->lf_coded) {
+            if (err)
+                *err = h && blob_sizes[b] >= sizeof(*h) && (h->status & HYDAMD_BLOB_RETRY)
+                           ? "a blob is incomplete (its frame outgrew a buffer): rerun that shard"
+                           : bad;
+            return HYD_API_ERROR;
+        }
+        const uint64_t lf_off = sizeof(*h) + (uint64_t)h->num_slots * sizeof(HydAmdBlobSlot);
+        const uint64_t hf_off = (lf_off + h->lf_bytes + 15u) & ~(uint64_t)15u;
+        if (lf_off > h->total_bytes || hf_off + h->hf_bytes != h->total_bytes) {
+            if (err)
+                *err = bad;
+            return HYD_API_ERROR;
+        }
+        if (h->status & 1u) {
+            if (err)
+                *err = "Invalid NaN Float";
+            return HYD_API_ERROR;
+        }
+        slots += h->num_slots;
+        hf_total += (size_t)h->hf_bytes;
+    }
+    const size_t lfg_x = (md->width + 2047) >> 11;
+    uint32_t *tile_xy = malloc((slots ? slots : 1) * 2 * sizeof(uint32_t));
+    HydAmdLfStream *lf = calloc(slots ? slots : 1, sizeof(HydAmdLfStream));
+    uint32_t *freq = malloc((slots ? slots : 1) * sizeof(((HydAmdBlobSlot *)0)->freq));
+    uint32_t *alpha = malloc((slots ? slots : 1) * sizeof(((HydAmdBlobSlot *)0)->alphabet));
+    uint32_t *bits = malloc((slots ? slots : 1) * sizeof(((HydAmdBlobSlot *)0)->group_bits));
+    uint8_t *payload = malloc(hf_total ? hf_total : 1);
+    int ret = HYD_OK;
+    unsigned max_alphabet = 0;
+    if (!tile_xy || !lf || !freq || !alpha || !bits || !payload) {
+        ret = HYD_NOMEM;
+        if (err)
+            *err = "out of memory";
+    }
+    size_t s = 0, hf_pos = 0;
+    for (size_t b = 0; b < nblobs && !ret; b++) {
+        const HydAmdBlobHeader *h = blobs[b];
+        const HydAmdBlobSlot *rec = (const HydAmdBlobSlot *)(h + 1);
+        const uint8_t *lf_bytes = (const uint8_t *)blobs[b] + sizeof(*h) + (size_t)h->num_slots * sizeof(HydAmdBlobSlot);
+        const uint8_t *hf_bytes = (const uint8_t *)blobs[b] + h->total_bytes - h->hf_bytes;
+        for (uint32_t i = 0; i < h->num_slots && !ret; i++, s++) {
+            if (rec[i].table_error || rec[i].lf.error ||
+                (uint64_t)rec[i].lf.offset + (((uint64_t)rec[i].lf.bit_count + 7) >> 3) > h->lf_bytes) {
+                ret = HYD_INTERNAL_ERROR;
+                if (err)
+                    *err = rec[i].table_error ? "ANS table construction failed on the device"
+                                              : rec[i].lf.error ? "LF code construction failed on the device" : bad;
+                break;
+            }
+            tile_xy[2 * s] = (uint32_t)(rec[i].preset % lfg_x);
+            tile_xy[2 * s + 1] = (uint32_t)(rec[i].preset / lfg_x);
+            lf[s].lengths = rec[i].lf.lengths;
+            lf[s].alphabet = rec[i].lf.alphabet;
+            lf[s].run_pairs = rec[i].lf.run_pairs;
+            lf[s].bits = lf_bytes + rec[i].lf.offset;
+            lf[s].bit_count = rec[i].lf.bit_count;
+            memcpy(freq + s * HYD_FRAME_MAX_CLUSTERS * HYD_FRAME_ALPHABET, rec[i].freq, sizeof(rec[i].freq));
+            memcpy(alpha + s * HYD_FRAME_MAX_CLUSTERS, rec[i].alphabet, sizeof(rec[i].alphabet));
+            memcpy(bits + s * HYDAMD_GROUPS_PER_LFG, rec[i].group_bits, sizeof(rec[i].group_bits));
+            if (rec[i].running_max_alphabet > max_alphabet)
+                max_alphabet = rec[i].running_max_alphabet;
+        }
+        memcpy(payload + hf_pos, hf_bytes, (size_t)h->hf_bytes);
+        hf_pos += (size_t)h->hf_bytes;
+    }
+    if (!ret)
+        ret = frame_from_parts(md, write_header, is_last, slots, tile_xy, NULL, lf, freq, alpha, bits, max_alphabet, payload,
+                               hf_total, icc, icc_size, out, out_len, err);
+    free(tile_xy);
+    free(lf);
+    free(freq);
+    free(alpha);
+    free(bits);
+    free(payload);
+    return ret;
+}
+
 HYDRIUM_EXPORT void hydamd_free(void *p) { free(p); }
 
 /* the CPU-only tests drive the same function through libhydrium_hosttest.so */

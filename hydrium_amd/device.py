@@ -70,6 +70,15 @@ def dll(path: Optional[str] = None):
         d.hydamd_run_entropy.argtypes = [vp, i]
         d.hydamd_read_alphabet_max.argtypes = [vp, i, C.POINTER(C.c_uint32)]
         d.hydamd_set_alphabet_floor.argtypes = [vp, C.c_uint32]
+        d.hydamd_alphabet_max_device.restype = vp
+        d.hydamd_alphabet_max_device.argtypes = [vp]
+        d.hydamd_set_alphabet_floor_device.argtypes = [vp, vp]
+        d.hydamd_blob_bound.restype = sz
+        d.hydamd_blob_bound.argtypes = [vp, i]
+        d.hydamd_export_frame.argtypes = [vp, i, vp, sz]
+        d.hydamd_frame_from_blobs.restype = i
+        d.hydamd_frame_from_blobs.argtypes = [C.POINTER(api.HYDImageMetadata), i, i, sz, C.POINTER(vp), C.POINTER(sz),
+                                              C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_char_p)]
         d.hydamd_frame_from_results.restype = i
         d.hydamd_frame_from_results.argtypes = [
             C.POINTER(api.HYDImageMetadata), i, i, sz, vp, C.POINTER(vp), vp, vp, vp, u, vp, sz, C.c_char_p, sz,
@@ -193,6 +202,24 @@ class DeviceContext:
 
     def set_alphabet_floor(self, floor: int):
         self._ck(self.d.hydamd_set_alphabet_floor(self.h, floor))
+
+    # -- the same exchange and the result hand-over without the host in the loop (multi-GPU) ----------
+    def alphabet_max_tensor(self, num_slots: int):
+        """int32 CUDA view of the per-slot maxima in the context's memory; order reads behind the context's stream."""
+        raw = self._device_view("alpha_max", int(self.d.hydamd_alphabet_max_device(self.h) or 0), self.max_lf_groups * 4)
+        return raw.view(__import__("torch").int32)[:num_slots]
+
+    def set_alphabet_floor_device(self, tensor):
+        """1-element int32 CUDA tensor the table kernel reads the floor from when it runs (kept alive by the context object)."""
+        self._floor_keep = tensor
+        self._ck(self.d.hydamd_set_alphabet_floor_device(self.h, tensor.data_ptr() if tensor is not None else None))
+
+    def blob_bound(self, num_slots: int) -> int:
+        return int(self.d.hydamd_blob_bound(self.h, num_slots))
+
+    def export_frame(self, num_slots: int, out_tensor):
+        """Enqueue the blob of slots [0, num_slots) into a uint8 CUDA tensor (behind the entropy stage, no sync)."""
+        self._ck(self.d.hydamd_export_frame(self.h, num_slots, out_tensor.data_ptr(), out_tensor.numel()))
 
     def sync(self):
         self._ck(self.d.hydamd_sync(self.h))
@@ -417,6 +444,39 @@ def frame_from_results(md: "api.HYDImageMetadata", tiles, dcs, freqs, alphabets,
         dc_arrays = [np.ascontiguousarray(a, np.int32) for a in dcs]
         dcp = (C.c_void_p * n)(*[a.ctypes.data for a in dc_arrays])
         ret = d.hydamd_frame_from_results(C.byref(md), int(write_header), int(is_last), n, tile_xy.ctypes.data, dcp, *tail)
+    if ret:
+        raise DeviceError(ret, (err.value or b"").decode())
+    data = C.string_at(out.value, out_len.value)
+    d.hydamd_free(out)
+    return data
+
+
+BLOB_HEADER_DTYPE = np.dtype([("magic", "<u4"), ("version", "<u4"), ("num_slots", "<u4"), ("status", "<u4"),
+                              ("hf_bytes", "<u8"), ("lf_bytes", "<u8"), ("total_bytes", "<u8"), ("lf_coded", "<u4"),
+                              ("reserved", "<u4", (5,))])
+BLOB_SLOT_DTYPE = np.dtype([("preset", "<u4"), ("running_max_alphabet", "<u4"), ("log_alphabet_size", "<u4"),
+                            ("table_error", "<u4"), ("alphabet", "<u4", (MAX_CLUSTERS,)), ("reserved", "<u4", (3,)),
+                            ("group_bits", "<u4", (GROUPS_PER_LFG,)), ("freq", "<u4", (MAX_CLUSTERS, ALPHABET)),
+                            ("lf", LF_INFO_DTYPE)])
+BLOB_MAGIC = 0x42445948
+BLOB_RETRY = 0xE
+
+
+def blob_header(blob) -> np.ndarray:
+    """The header record of a blob held in a bytes-like / uint8 array."""
+    return np.frombuffer(memoryview(blob)[:BLOB_HEADER_DTYPE.itemsize], BLOB_HEADER_DTYPE)[0]
+
+
+def frame_from_blobs(md: "api.HYDImageMetadata", blobs, *, write_header=True, is_last=True, icc: Optional[bytes] = None,
+                     lib=None) -> bytes:
+    """One-frame codestream from the blobs of the contexts that coded its LF groups (host only)."""
+    d = lib or dll()
+    arrs = [np.ascontiguousarray(np.frombuffer(b, np.uint8)) for b in blobs]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    sizes = (C.c_size_t * len(arrs))(*[a.size for a in arrs])
+    out, out_len, err = C.c_void_p(0), C.c_size_t(0), C.c_char_p(None)
+    ret = d.hydamd_frame_from_blobs(C.byref(md), int(write_header), int(is_last), len(arrs), ptrs, sizes, icc,
+                                    len(icc) if icc else 0, C.byref(out), C.byref(out_len), C.byref(err))
     if ret:
         raise DeviceError(ret, (err.value or b"").decode())
     data = C.string_at(out.value, out_len.value)

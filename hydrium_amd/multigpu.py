@@ -12,8 +12,11 @@ shards, both tiny next to the pixels:
   section sizes.  Rank 0 wraps them with ``hydamd_frame_from_streams`` / ``hydamd_frame_from_results``.
 
 ``Shard`` holds one shard's state; ``encode_serial`` drives N shards one after another in a single
-process (that is what the single-GPU tests run), ``encode_distributed`` is the same choreography
-with ``torch.distributed`` collectives, one process per GPU.
+process (that is what the single-GPU tests run).  ``encode_distributed`` is the one-process-per-GPU
+form: ``choreograph_frame`` keeps everything on the devices — the maxima are all-gathered as a
+tensor, each shard leaves ONE blob (``hydamd_export_frame``: tables, section sizes, LF streams, packed
+sections) that is gathered to the assembling rank, whose host builds the frame with
+``hydamd_frame_from_blobs``.
 """
 from __future__ import annotations
 
@@ -125,9 +128,107 @@ def encode_serial(img_tensor, num_shards: int, dev_index: int = 0, linear_light:
             s.close()
 
 
-def encode_distributed(slab_tensor, width: int, height: int, origin_lf_pixels, group=None, linear_light: int = 0):
+class GpuShardEngine:
+    """What ``choreograph_frame`` needs from a shard, on a GPU: every call only ENQUEUES work on the
+    shard context's HIP stream (made torch's current stream, so that torch ops and RCCL collectives
+    order themselves behind the kernels without explicit events); ``finish`` is the one host wait."""
+
+    def __init__(self, shard: Shard, slab_tensor, origin_lf_pixels):
+        import torch
+
+        self.shard, self.tensor, self.origin = shard, slab_tensor, origin_lf_pixels
+        self.n = len(shard.lf_ids)
+        self.device = slab_tensor.device
+        self.stream = torch.cuda.ExternalStream(shard.ctx.get_stream()) if shard.ctx else torch.cuda.current_stream()
+
+    def enqueue_transform(self):
+        self.shard.submit(self.tensor, self.origin)
+
+    def alphabet_maxima(self):
+        import torch
+
+        if not self.n:
+            return torch.zeros(0, dtype=torch.int32, device=self.device)
+        return self.shard.ctx.alphabet_max_tensor(self.n)
+
+    def enqueue_entropy(self, floor_tensor):
+        if self.n:
+            self.shard.ctx.set_alphabet_floor_device(floor_tensor)
+            self.shard.ctx.run_entropy(self.n)
+
+    def blob_bound(self) -> int:
+        return self.shard.ctx.blob_bound(self.n) if self.n else device.BLOB_HEADER_DTYPE.itemsize
+
+    def export_blob(self, out):
+        if self.n:
+            self.shard.ctx.export_frame(self.n, out)
+        else:  # a rank without LF groups sends an empty blob
+            import torch
+
+            h = np.zeros(1, device.BLOB_HEADER_DTYPE)
+            h["magic"], h["version"], h["lf_coded"] = device.BLOB_MAGIC, 1, 1
+            h["total_bytes"] = device.BLOB_HEADER_DTYPE.itemsize
+            out[:h.nbytes] = torch.from_numpy(h.view(np.uint8).copy()).to(out.device)
+
+    def finish(self):
+        """Wait for the shard; a frame that outgrew the context's buffers is rerun in here (hydamd_sync)."""
+        if self.n:
+            self.shard.ctx.sync()
+
+
+def choreograph_frame(engine, parts, group=None, capacity=None, to_rank=0):
+    """One frame over the ranks of ``group``: transform stage -> all-gather of the per-LF-group alphabet
+    maxima (one int32 per LF group, on the device) -> entropy stage with this rank's floor -> one
+    gather of the shards' blobs to ``to_rank``.  Returns the list of blobs (bytes, rank order) there,
+    ``None`` elsewhere.  ``engine`` is a GpuShardEngine or anything with its methods; ``parts`` the
+    LF-group partition (sharding.partition_lf_groups).  Reference: presets are numbered across the
+    whole frame (encoder.c:852-901) and the alphabet maximum runs over LF groups in send order
+    (entropy.c:459-460,952)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    most = max(len(p) for p in parts)
+    for attempt in range(3):
+        engine.enqueue_transform()
+        mine = engine.alphabet_maxima()
+        padded = torch.zeros(max(most, 1), dtype=torch.int32, device=mine.device)
+        padded[:mine.numel()] = mine
+        every = torch.empty(world * max(most, 1), dtype=torch.int32, device=mine.device)
+        dist.all_gather_into_tensor(every, padded, group=group)
+        before = every.view(world, -1)[:rank]
+        floor = (before.max() if before.numel() else torch.zeros((), dtype=torch.int32, device=mine.device)).reshape(1)
+        engine.enqueue_entropy(floor.to(torch.int32).contiguous())
+        # every rank sends the same number of bytes: the largest bound any of them reports
+        cap = torch.tensor([capacity or engine.blob_bound()], dtype=torch.int64, device=mine.device)
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
+        cap = (int(cap.item()) + 15) & ~15
+        blob = torch.zeros(cap, dtype=torch.uint8, device=mine.device)
+        engine.export_blob(blob)
+        rows = [torch.empty(cap, dtype=torch.uint8, device=mine.device) for _ in range(world)] if rank == to_rank else None
+        dist.gather(blob, gather_list=rows, dst=to_rank, group=group)
+        engine.finish()
+        # did any shard have to be rerun (its blob is then incomplete)?  everybody goes again
+        head = device.blob_header(blob[:device.BLOB_HEADER_DTYPE.itemsize].cpu().numpy().tobytes())
+        retry = torch.tensor([1 if int(head["status"]) & device.BLOB_RETRY else 0], dtype=torch.int32, device=mine.device)
+        dist.all_reduce(retry, op=dist.ReduceOp.MAX, group=group)
+        if not int(retry.item()):
+            if rank != to_rank:
+                return None
+            out = []
+            for r in rows:
+                host = r.cpu().numpy()
+                out.append(host[:int(device.blob_header(host.tobytes()[:64])["total_bytes"])].tobytes())
+            return out
+        capacity = None  # the rerun enlarged the context: take its new bound
+    raise RuntimeError("frame did not fit its buffers after two enlargements")
+
+
+def encode_distributed(slab_tensor, width: int, height: int, origin_lf_pixels, group=None, linear_light: int = 0,
+                       lib=None):
     """One process per GPU: this rank codes its LF groups out of ``slab_tensor`` (its part of the
-    picture, already in its HBM); rank 0 returns the codestream, the others ``None``."""
+    picture, already in its HBM); rank 0 returns the codestream, the others ``None``.  Nothing but the
+    final blobs crosses to the host, and only on rank 0."""
     import torch
     import torch.distributed as dist
 
@@ -137,23 +238,11 @@ def encode_distributed(slab_tensor, width: int, height: int, origin_lf_pixels, g
     parts = sharding.partition_lf_groups(n_lf, world)
     shard = Shard(torch.cuda.current_device(), parts[rank], width, height, linear_light)
     try:
-        shard.submit(slab_tensor, origin_lf_pixels)
-        all_max: List[List[int]] = [None] * world
-        dist.all_gather_object(all_max, shard.alphabet_maxima(), group=group)
-        before = [m for r in range(rank) for m in all_max[r]]
-        shard.entropy(max(before, default=0))
-        res = shard.results()
-        payload = res.pop("payload")
-        dev = slab_tensor.device
-        sizes, gathered = sharding.all_gather_sections(
-            torch.from_numpy(np.frombuffer(payload, np.uint8).copy()).to(dev), group)
-        metas: List[dict] = [None] * world
-        dist.all_gather_object(metas, res, group=group)
-        if rank != 0:
+        engine = GpuShardEngine(shard, slab_tensor, origin_lf_pixels)
+        with torch.cuda.stream(engine.stream):
+            blobs = choreograph_frame(engine, parts, group)
+        if blobs is None:
             return None
-        host = gathered.cpu().numpy()
-        for r in range(world):
-            metas[r]["payload"] = host[r, :int(sizes[r])].tobytes()
-        return assemble(width, height, metas, linear_light)
+        return device.frame_from_blobs(api.HYDImageMetadata(width, height, linear_light, -1, -1), blobs, lib=lib)
     finally:
         shard.close()

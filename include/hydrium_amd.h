@@ -199,6 +199,52 @@ HYDAMD_EXPORT int hydamd_read_alphabet_max(HydAmdContext *ctx, int slot, uint32_
 HYDAMD_EXPORT int hydamd_set_alphabet_floor(HydAmdContext *ctx, uint32_t floor);
 HYDAMD_EXPORT int hydamd_run_entropy(HydAmdContext *ctx, int num_slots);
 
+/* The same exchange without the host in the loop: the per-slot maxima as they sit in device memory
+ * ([max_lf_groups] uint32, complete once the transform kernels enqueued so far have run — order your
+ * reads behind the context's stream), and a device location the table kernel reads the floor from when
+ * it runs (the larger of it and hydamd_set_alphabet_floor's value counts; NULL clears; reset by
+ * hydamd_begin_frame).  A job that all-gathers the maxima with RCCL writes its floor there. */
+HYDAMD_EXPORT const uint32_t *hydamd_alphabet_max_device(HydAmdContext *ctx);
+HYDAMD_EXPORT int hydamd_set_alphabet_floor_device(HydAmdContext *ctx, const uint32_t *floor_on_device);
+
+/*
+ * One self-describing byte string with everything a frame assembler needs from this context's LF
+ * groups, built by a kernel in the context's stream right behind the entropy stage: no host
+ * synchronisation, one buffer to gather.  Layout: HydAmdBlobHeader, num_slots x HydAmdBlobSlot, the
+ * packed LF streams (lf_bytes), then at the next multiple of 16 the packed HF sections (hf_bytes).
+ * The LF coder must be on.  `capacity` is the size of the caller's device buffer; a blob that does not
+ * fit, or a frame that outgrew the context's buffers, has HYDAMD_BLOB_RETRY set in header.status: call
+ * hydamd_sync() (it enlarges and reruns the frame) and export again, into a larger buffer if
+ * total_bytes says so.  hydamd_blob_bound() is an upper bound for the context's current capacities.
+ */
+typedef struct HydAmdBlobHeader {
+    uint32_t magic;       /* "HYDB" */
+    uint32_t version;     /* 1 */
+    uint32_t num_slots;
+    uint32_t status;      /* device status word; & HYDAMD_BLOB_RETRY: incomplete, see above; & 1: non-finite float sample */
+    uint64_t hf_bytes, lf_bytes, total_bytes;
+    uint32_t lf_coded;    /* the slot records carry device-coded LF streams */
+    uint32_t reserved[5];
+} HydAmdBlobHeader;
+#define HYDAMD_BLOB_RETRY 0xEu
+typedef struct HydAmdBlobSlot {
+    uint32_t preset;                /* = raster id of the LF group in its frame */
+    uint32_t running_max_alphabet, log_alphabet_size, table_error;
+    uint32_t alphabet[HYDAMD_MAX_CLUSTERS];
+    uint32_t reserved[3];
+    uint32_t group_bits[HYDAMD_GROUPS_PER_LFG];
+    uint32_t freq[HYDAMD_MAX_CLUSTERS][HYDAMD_ALPHABET];
+    HydAmdLfInfo lf;                /* lf.offset is relative to the blob's LF byte string */
+} HydAmdBlobSlot;
+HYDAMD_EXPORT size_t hydamd_blob_bound(HydAmdContext *ctx, int num_slots);
+HYDAMD_EXPORT int hydamd_export_frame(HydAmdContext *ctx, int num_slots, void *device_dst, size_t capacity);
+/* Host only: a whole one-frame codestream from the blobs of the contexts (ranks) that coded its LF
+ * groups, in any order; every LF group of the image must appear exactly once.  *out as for
+ * hydamd_frame_from_streams. */
+HYDAMD_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write_header, int is_last, size_t nblobs,
+                                          const void *const *blobs, const size_t *blob_sizes, const uint8_t *icc,
+                                          size_t icc_size, uint8_t **out, size_t *out_len, const char **err);
+
 /*
  * Wrap LF-group results — from this or other GPUs — into codestream bytes (host only, no GPU).
  *   md            image metadata, as for hyd_set_metadata (one-frame mode: every LF group must be present)

@@ -124,3 +124,81 @@ def test_payload_tensor_and_rccl_gather_world_of_one(image):
             assert ctx.read_payload() == want
         finally:
             dist.destroy_process_group()
+
+
+def _nccl_world_of_one():
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    return dist
+
+
+@pytest.mark.parametrize("kind,w,h,depth", [("photo", 4096 + 200, 2048 + 72, 8), ("photo", 2048 + 64, 2048 + 64, 32)])
+def test_encode_distributed_over_rccl_world_of_one(image, kind, w, h, depth):
+    """The one-process-per-GPU entry point itself (multigpu.encode_distributed), over the "nccl" (= RCCL)
+    backend in a world of one: transform -> all-gather of maxima on the device -> entropy stage with
+    the floor read from device memory -> hydamd_export_frame -> gather -> hydamd_frame_from_blobs."""
+    import torch
+    from hydrium_amd import multigpu, synth
+    from oracle import refprobe
+
+    if depth == 32:
+        img = synth.make_image_f32(kind, w, h)
+        img[:64, :64] *= 300.0  # out-of-gamut floats: alphabets above 32
+    else:
+        img = image(kind, w, h, depth)
+    t = _cuda(img)
+    dist = _nccl_world_of_one()
+    try:
+        got = multigpu.encode_distributed(t, w, h, lambda lf: ((lf // (-(-w // 2048))) * 2048, (lf % (-(-w // 2048))) * 2048))
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert got == api.encode_image(api.Library(), np.ascontiguousarray(img))
+    if refprobe.available():
+        assert got == api.encode_image(refprobe.reference_library(), np.ascontiguousarray(img))
+
+
+@pytest.mark.parametrize("shards", [2, 5])
+def test_blobs_of_several_shards_make_the_reference_file(image, shards):
+    """hydamd_export_frame / hydamd_frame_from_blobs with the LF groups of one frame spread over several
+    contexts (what N ranks hold after the gather), floors handed over through device memory."""
+    import torch
+    from hydrium_amd import device, multigpu, sharding
+
+    img = image("photo", 4096 + 200, 2 * 2048 + 72, 8)
+    h, w, _ = img.shape
+    lfx = -(-w // 2048)
+    t = _cuda(img)
+    parts = sharding.partition_lf_groups(lfx * (-(-h // 2048)), shards)
+    engines = [multigpu.GpuShardEngine(multigpu.Shard(0, p, w, h), t, lambda lf: ((lf // lfx) * 2048, (lf % lfx) * 2048))
+               for p in parts]
+    try:
+        for e in engines:
+            e.enqueue_transform()
+        torch.cuda.synchronize()
+        maxima = [int(v) for e in engines for v in e.alphabet_maxima().cpu()]
+        blobs, seen = [], 0
+        for e in engines:
+            floor = torch.tensor([max(maxima[:seen], default=0)], dtype=torch.int32, device="cuda")
+            seen += e.n
+            e.enqueue_entropy(floor)
+            out = torch.zeros(e.blob_bound(), dtype=torch.uint8, device="cuda")
+            e.export_blob(out)
+            e.finish()
+            head = device.blob_header(out[:64].cpu().numpy().tobytes())
+            assert int(head["status"]) == 0 and int(head["num_slots"]) == e.n
+            blobs.append(out[:int(head["total_bytes"])].cpu().numpy().tobytes())
+    finally:
+        for e in engines:
+            e.shard.close()
+    got = device.frame_from_blobs(api.HYDImageMetadata(w, h, 0, -1, -1), blobs)
+    assert got == api.encode_image(api.Library(), img)

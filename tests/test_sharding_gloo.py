@@ -102,3 +102,66 @@ def test_all_gather_sections_world2_matches_single_process():
     for rank, sizes, data in results:
         assert sum(sizes) == len(want)
         assert data == want, f"rank {rank} assembled different bytes"
+
+
+def _choreography_worker(rank, world, port, q, shape, retry_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import glue
+        import oracle_engine
+        from hydrium_amd import api, device, multigpu, synth
+
+        w, h, depth = shape
+        img = synth.make_image_f32("photo", w, h) if depth == 32 else synth.make_image("photo", w, h, depth)
+        n_lf = (-(-w // 2048)) * (-(-h // 2048))
+        parts = sharding.partition_lf_groups(n_lf, world)
+        engine = oracle_engine.OracleShardEngine(img, parts[rank], fail_first_export=rank == retry_rank)
+        blobs = multigpu.choreograph_frame(engine, parts)
+        data = None
+        if rank == 0:
+            if glue._d is None:
+                glue._d = glue._lib()
+            import ctypes as C
+
+            d = glue._d  # the product's host glue without a GPU (libhydrium_hosttest.so)
+            d.hydamd_frame_from_blobs.restype = C.c_int
+            d.hydamd_frame_from_blobs.argtypes = [C.POINTER(api.HYDImageMetadata), C.c_int, C.c_int, C.c_size_t,
+                                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t,
+                                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)]
+            d.hydamd_free.argtypes = [C.c_void_p]
+            data = device.frame_from_blobs(api.HYDImageMetadata(w, h, 0, -1, -1), blobs, lib=d)
+        q.put((rank, data, engine.exports))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape,retry_rank", [((2048 + 300, 2048 + 40, 8), -1), ((2048 * 2 + 100, 300, 32), -1),
+                                              ((2048 + 300, 40, 8), 1)])
+def test_sharded_frame_choreography_world2(ref_lib, shape, retry_rank):
+    """multigpu.choreograph_frame in two processes over gloo, shards coded by the CPU oracle: the frame
+    rank 0 assembles from the gathered blobs is the reference's file.  The float image's alphabet grows
+    from LF group to LF group, so the floor exchange matters (entropy.c:459-460); `retry_rank` reports
+    one incomplete blob, which makes every rank run the frame again."""
+    from hydrium_amd import api, synth
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_choreography_worker, args=(r, world, port, q, shape, retry_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict((r[0], r[1:]) for r in (q.get(timeout=300) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w, h, depth = shape
+    img = synth.make_image_f32("photo", w, h) if depth == 32 else synth.make_image("photo", w, h, depth)
+    assert results[0][0] == api.encode_image(ref_lib, img)
+    assert results[1][0] is None
+    assert all(results[r][1] == (2 if retry_rank >= 0 else 1) for r in range(world))

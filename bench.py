@@ -51,6 +51,12 @@ def parse():
                     help="N > 1: bring each frame's sections to rank 0 only (default) or to every rank")
     ap.add_argument("--exchange", action="store_true",
                     help="run the multi-GPU exchange path (process group, all-gather per frame) even with one rank")
+    ap.add_argument("--mode", default="frame", choices=("frame", "shard", "batch"),
+                    help="frame: one 8192x8192 RGB16 frame per GPU per step (BASELINE configs[2], the contract line); "
+                         "shard: ONE 16384x16384 RGB8 frame per step, its LF groups spread over the GPUs (configs[3]); "
+                         "batch: 64 independent 3840x2160 RGB8 frames through the drop-in API, frame i on GPU i mod N (configs[4])")
+    ap.add_argument("--frames", type=int, default=64, help="--mode batch: frames in the batch")
+    ap.add_argument("--threads", type=int, default=4, help="--mode batch: host threads (encoders) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
     return ap.parse_args()
@@ -89,8 +95,244 @@ def cpu_baseline(host_img):
             "bytes": int(nbytes)}
 
 
+def run_shard(args):
+    """BASELINE configs[3]: one 16384x16384 RGB8 frame per step, sharded by LF group over the ranks;
+    presets numbered across the frame, alphabet floor exchanged on the device, one gather of blobs, the
+    frame assembled by the host of rank (step mod N) so that assembly scales with the GPUs too."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29534"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        os.environ.setdefault(k, v)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from hydrium_amd import api, device, multigpu, sharding, synth
+
+    W = H = args.size if args.size != 8192 else 16384
+    depth = 8
+    lfx, lfy = -(-W // 2048), -(-H // 2048)
+    n_lf = lfx * lfy
+    parts = sharding.partition_lf_groups(n_lf, world)
+    mine = parts[rank]
+    # this rank's LF groups are whole rows of LF groups when N divides the row count: its slab is a band
+    rows = sorted({lf // lfx for lf in mine})
+    y0 = rows[0] * 2048 if rows else 0
+    band_h = (min(H, (rows[-1] + 1) * 2048) - y0) if rows else 8
+    dev = torch.device("cuda", local)
+    slab = synth.make_image(args.kind, W, band_h, depth, x0=0, y0=y0, device=dev)
+    origin = lambda lf: ((lf // lfx) * 2048 - y0, (lf % lfx) * 2048)
+    depth_in_flight = max(2, min(args.streams, 3))
+    shards = [multigpu.Shard(local, mine, W, H) for _ in range(depth_in_flight)]
+    for sh in shards:
+        if sh.ctx:
+            sh.ctx.set_rans_waves(args.rans_waves)
+    engines = [multigpu.GpuShardEngine(sh, slab, origin) for sh in shards]
+    md = api.HYDImageMetadata(W, H, 0, -1, -1)
+
+    # first frame: exact sizes, reference bytes for the MD5, and the capacity all ranks agree on
+    with torch.cuda.stream(engines[0].stream):
+        blobs = multigpu.choreograph_frame(engines[0], parts)
+    first = device.frame_from_blobs(md, blobs) if rank == 0 else None
+    biggest = torch.tensor([max((len(b) for b in blobs), default=0) if blobs else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(biggest, src=0)
+    cap = int(int(biggest.item()) * 1.25) + 65536
+    pinned = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(world)]
+
+    asm_ms, d2h_ms = [], []
+
+    def assemble(rows_dev, want_md5):
+        """blobs -> pinned host memory -> the frame (hydamd_frame_from_blobs writes it into one buffer of its own)"""
+        t_a = time.perf_counter()
+        heads = torch.stack([r[:64] for r in rows_dev]).cpu().numpy()
+        sizes = [int(device.blob_header(heads[k].tobytes())["total_bytes"]) for k in range(len(rows_dev))]
+        for r, p, n in zip(rows_dev, pinned, sizes):
+            p[:n].copy_(r[:n], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        t_b = time.perf_counter()
+        view, release = device.frame_from_blobs(md, [p[:n].numpy() for p, n in zip(pinned, sizes)], raw=True)
+        t_c = time.perf_counter()
+        digest = hashlib.md5(view).hexdigest() if want_md5 else None
+        release()
+        d2h_ms.append((t_b - t_a) * 1e3)
+        asm_ms.append((t_c - t_b) * 1e3)
+        return digest
+
+    handles = []
+    retries = 0
+    md5s = {}
+    checking = [True]  # frames assembled during warm-up are hashed and compared with the first frame; timed ones are not
+
+    def enqueue(i):
+        e = engines[i % depth_in_flight]
+        with torch.cuda.stream(e.stream):
+            handles.append((i, multigpu.enqueue_frame(e, parts, cap, None, i % world)))
+
+    def collect():
+        nonlocal retries
+        i, h = handles.pop(0)
+        again, rows_dev = multigpu.collect_frame(h)
+        retries += int(again)
+        if rows_dev is not None and not again:
+            with torch.cuda.stream(h["engine"].stream):
+                return i, assemble(rows_dev, checking[0])
+        return i, None
+
+    # warm-up, then a steady-state interval: depth-1 frames are in flight when the clock starts and when it stops
+    seq = 0
+    for _ in range(args.warmup + depth_in_flight - 1):
+        enqueue(seq)
+        seq += 1
+        if len(handles) == depth_in_flight:
+            i, digest = collect()
+            if digest is not None:
+                md5s[i] = digest
+    checking[0] = False
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enqueue(seq)
+        seq += 1
+        collect()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    while handles:
+        collect()
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    # every rank's assembly times and one of its MD5s, for the line
+    gathered = [None] * world
+    dist.all_gather_object(gathered, dict(asm=asm_ms[-8:], d2h=d2h_ms[-8:], md5=list(md5s.values())[:2], retries=retries))
+    if rank == 0:
+        want = hashlib.md5(first).hexdigest()
+        seen = [m for g in gathered for m in g["md5"]]
+        asm = [a for g in gathered for a in g["asm"]]
+        out = {
+            "metric": "Mpixel/s encode (16K RGB8 frame sharded by LF group)", "mode": "shard",
+            "value": round(W * H * args.steps / dt / 1e6, 1), "unit": "Mpixel/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"one {W}x{H} RGB{depth} '{args.kind}' frame per step (BASELINE configs[3]), {n_lf} LF groups "
+                                   f"in raster blocks of {len(parts[0])} per GPU, presets numbered across the frame",
+                       "exchange": "all-gather of int32 alphabet maxima on the device; one RCCL gather of the shards' blobs "
+                                   "(hydamd_export_frame) to the assembling rank, which rotates with the step",
+                       "frames_in_flight": depth_in_flight, "blob_capacity_bytes": cap, "parallelism": f"{world}-way LF-group shard"},
+            "frame_bytes": len(first), "frame_md5": want,
+            "assembled_frames_identical_to_first": bool(seen) and all(m == want for m in seen),
+            "host_assembly_ms": round(sum(asm) / max(len(asm), 1), 3),
+            "blobs_to_host_ms": round(sum(a for g in gathered for a in g["d2h"]) / max(sum(len(g["d2h"]) for g in gathered), 1), 3),
+            "reruns_after_buffer_overflow": sum(g["retries"] for g in gathered),
+            "frac_of_hbm_read_roofline": round((W * H * args.steps / dt) / (HBM_PEAK_GBS * 1e9 * world / 3), 5),
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()  # RCCL has seen the contexts' streams: it goes first
+    # torch's caching allocator keeps the blocks it handed out under the contexts' streams in per-stream
+    # pools: they have to go back to the driver before those streams are destroyed with their contexts
+    handles.clear()
+    del blobs, pinned, engines
+    for sh in shards:
+        if sh.ctx:
+            sh.ctx.__dict__.pop("_floor_keep", None)
+    import gc
+
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    for sh in shards:
+        sh.close()
+
+
+def run_batch(args):
+    """BASELINE configs[4]: a batch of independent 3840x2160 RGB8 frames through the drop-in API
+    (hyd_encoder_new .. hyd_send_tile .. hyd_flush from host memory), frame i on GPU i mod N, several
+    encoder threads per GPU, no collective in the data path."""
+    import threading
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ["HYDAMD_DEVICE"] = str(local)
+    os.environ.setdefault("HYDAMD_CONTEXT_CACHE", str(max(4, args.threads)))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from hydrium_amd import api, synth
+
+    w, h = 3840, 2160
+    distinct = 8  # frame i shows picture i mod 8 (seed 1234 + i mod 8): generating 64 different 4K pictures would take a minute
+    imgs = [synth.make_image("photo", w, h, 8, seed=1234 + k) for k in range(distinct)]
+    lib = api.Library()
+    mine = list(range(rank, args.frames, world))
+    md5 = {}
+    for k in range(min(distinct, 2)):  # warm the library, the context pool and the reference MD5s
+        md5[k] = hashlib.md5(api.encode_image(lib, imgs[k])).hexdigest()
+    T = max(1, min(args.threads, len(mine) or 1))
+    got = {}
+
+    def work(t):
+        for f in mine[t::T]:
+            got[f] = hashlib.md5(api.encode_image(lib, imgs[f % distinct])).hexdigest()
+
+    for warm in range(2):
+        ts = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    consistent = all(got[f] == md5[f % distinct] for f in got if f % distinct in md5)
+    if rank == 0:
+        want = None
+        with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
+            for e in json.load(f)["files"]:
+                if (e["kind"], e["width"], e["height"], e["depth"], e["shift"]) == ("photo", w, h, 8, -1):
+                    want = e["md5"]
+        out = {
+            "metric": "Mpixel/s encode (batch of 3840x2160 RGB8 frames, drop-in API)", "mode": "batch",
+            "value": round(args.frames * w * h / dt / 1e6, 1), "unit": "Mpixel/s", "frames_per_s": round(args.frames / dt, 1),
+            "n_gpus": world, "steps": args.frames, "warmup": 1, "ms_per_step": round(dt / args.frames * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.frames} independent {w}x{h} RGB8 'photo' frames (BASELINE configs[4]), host pixels "
+                                   "through hyd_send_tile in one-frame mode, PCIe, read-back and host frame assembly inclusive",
+                       "threads_per_gpu": T, "parallelism": f"frame i on GPU i mod {world}, no collective"},
+            "frame0_md5": md5.get(0), "frame0_md5_in_golden_manifest": want,
+            "frame0_identical_to_reference": md5.get(0) == want if want else None,
+            "threads_agree_with_single_thread_run": consistent,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.mode == "shard":
+        return run_shard(args)
+    if args.mode == "batch":
+        return run_batch(args)
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -240,8 +240,14 @@ static int device_fail(HYDEncoder *e, int code);
 
 /* payload == NULL: the packed HF sections are still on the device (e->dev) and are copied straight
  * into the output stream */
+typedef struct PayloadSegments { /* the packed HF sections in pieces (one per shard blob) instead of one string */
+    size_t count;
+    const uint8_t *const *ptr;
+    const size_t *len;
+} PayloadSegments;
+
 static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgResult *res, unsigned max_alphabet,
-                          const uint8_t *payload, size_t payload_len, HydBits *lf_prebuilt) {
+                          const uint8_t *payload, size_t payload_len, HydBits *lf_prebuilt, const PayloadSegments *segs) {
     uint8_t *fetched = NULL;
     const size_t fg = ((shape->frame_width + 255) >> 8) * ((shape->frame_height + 255) >> 8);
     const int multi = fg > 1;
@@ -366,7 +372,13 @@ static int assemble_frame(HYDEncoder *e, const HydFrameShape *shape, const LfgRe
     }
     hb_append_bytes(&e->stream, body.data, body.len);
     if (multi && payload_len) {
-        if (payload) {
+        if (segs) { /* straight from the shards' blobs into the output: the only copy the sections see here */
+            uint8_t *dst = hb_extend(&e->stream, payload_len);
+            for (size_t i = 0; dst && i < segs->count; i++) {
+                memcpy(dst, segs->ptr[i], segs->len[i]);
+                dst += segs->len[i];
+            }
+        } else if (payload) {
             hb_append_bytes(&e->stream, payload, payload_len);
         } else {
             uint8_t *dst = hb_extend(&e->stream, payload_len);
@@ -467,6 +479,18 @@ static int eager_on(void) {
     return on;
 }
 
+/* HYDAMD_DEVICE: which GPU the drop-in API encodes on (default 0); a process per GPU sets it to its own */
+static int api_device(void) {
+    static int dev = -1;
+    if (dev < 0) {
+        const char *v = getenv("HYDAMD_DEVICE");
+        dev = v && *v ? atoi(v) : 0;
+        if (dev < 0)
+            dev = 0;
+    }
+    return dev;
+}
+
 static HydAmdContext *ctx_acquire(size_t slots, int linear, int *status) {
     HydAmdContext *c = NULL;
     pthread_mutex_lock(&g_ctx_lock);
@@ -480,7 +504,7 @@ static HydAmdContext *ctx_acquire(size_t slots, int linear, int *status) {
         *status = HYD_OK;
         return c;
     }
-    return hydamd_create(0, (int)slots, linear, 0, status);
+    return hydamd_create(api_device(), (int)slots, linear, 0, status);
 }
 
 static void ctx_release(HydAmdContext *c, size_t slots, int linear, int healthy) {
@@ -730,7 +754,7 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
     }
     TRACE("read back results", t0);
     t0 = now_ms();
-    ret = assemble_frame(e, shape, res, max_alphabet, NULL, payload_len, lf_sections);
+    ret = assemble_frame(e, shape, res, max_alphabet, NULL, payload_len, lf_sections, NULL);
     TRACE("assemble frame (host)", t0);
 done:
     for (size_t s = 0; s < n; s++) {
@@ -939,8 +963,8 @@ HYDRIUM_EXPORT HYDStatusCode hyd_set_suggested_icc_profile(HYDEncoder *e, const 
 static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
                             const uint32_t *tile_xy, const int32_t *const *dc, const HydAmdLfStream *lf, const uint32_t *freq,
                             const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
-                            const uint8_t *payload, size_t payload_len, const uint8_t *icc, size_t icc_size, uint8_t **out,
-                            size_t *out_len, const char **err) {
+                            const uint8_t *payload, size_t payload_len, const PayloadSegments *segs, const uint8_t *icc,
+                            size_t icc_size, uint8_t **out, size_t *out_len, const char **err) {
     HYDEncoder *e = hyd_encoder_new();
     if (!e)
         return HYD_NOMEM;
@@ -1003,13 +1027,15 @@ static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is
         shape.lfg_count = lfg_count;
         shape.lfg = e->sent;
         shape.is_last = is_last;
-        ret = assemble_frame(e, &shape, res, max_alphabet, payload, payload_len, NULL);
+        ret = assemble_frame(e, &shape, res, max_alphabet, payload, payload_len, NULL, segs);
     }
     if (!ret) {
-        *out = malloc(e->stream.len ? e->stream.len : 1);
-        if (*out) {
-            memcpy(*out, e->stream.data, e->stream.len);
+        hb_align(&e->stream);
+        if (e->stream.data && !e->stream.failed) { /* the caller takes the stream's buffer itself (hydamd_free = free) */
+            *out = e->stream.data;
             *out_len = e->stream.len;
+            e->stream.data = NULL;
+            e->stream.len = e->stream.cap = 0;
         } else {
             ret = HYD_NOMEM;
         }
@@ -1029,7 +1055,7 @@ HYDRIUM_EXPORT int hydamd_frame_from_results(const HYDImageMetadata *md, int wri
     if (!dc)
         return HYD_API_ERROR;
     return frame_from_parts(md, write_header, is_last, lfg_count, tile_xy, dc, NULL, freq, alphabet, group_bits, max_alphabet,
-                            payload, payload_len, icc, icc_size, out, out_len, err);
+                            payload, payload_len, NULL, icc, icc_size, out, out_len, err);
 }
 
 HYDRIUM_EXPORT int hydamd_frame_from_streams(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
@@ -1040,7 +1066,7 @@ HYDRIUM_EXPORT int hydamd_frame_from_streams(const HYDImageMetadata *md, int wri
     if (!lf)
         return HYD_API_ERROR;
     return frame_from_parts(md, write_header, is_last, lfg_count, tile_xy, NULL, lf, freq, alphabet, group_bits, max_alphabet,
-                            payload, payload_len, icc, icc_size, out, out_len, err);
+                            payload, payload_len, NULL, icc, icc_size, out, out_len, err);
 }
 
 /* From the blobs hydamd_export_frame leaves on the GPUs that coded the frame's LF groups (copied to
@@ -1086,10 +1112,15 @@ HYDRIUM_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write
     uint32_t *freq = malloc((slots ? slots : 1) * sizeof(((HydAmdBlobSlot *)0)->freq));
     uint32_t *alpha = malloc((slots ? slots : 1) * sizeof(((HydAmdBlobSlot *)0)->alphabet));
     uint32_t *bits = malloc((slots ? slots : 1) * sizeof(((HydAmdBlobSlot *)0)->group_bits));
-    uint8_t *payload = malloc(hf_total ? hf_total : 1);
+    /* a frame of one group splices its only section bit by bit and wants it in one piece; any other
+     * frame takes the sections piece by piece, straight from the blobs */
+    const int one_group = ((md->width + 255) >> 8) * ((md->height + 255) >> 8) == 1;
+    uint8_t *payload = one_group ? malloc(hf_total ? hf_total : 1) : NULL;
+    const uint8_t **seg_ptr = malloc(nblobs * sizeof(*seg_ptr));
+    size_t *seg_len = malloc(nblobs * sizeof(*seg_len));
     int ret = HYD_OK;
     unsigned max_alphabet = 0;
-    if (!tile_xy || !lf || !freq || !alpha || !bits || !payload) {
+    if (!tile_xy || !lf || !freq || !alpha || !bits || (one_group && !payload) || !seg_ptr || !seg_len) {
         ret = HYD_NOMEM;
         if (err)
             *err = "out of memory";
@@ -1122,12 +1153,19 @@ HYDRIUM_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write
             if (rec[i].running_max_alphabet > max_alphabet)
                 max_alphabet = rec[i].running_max_alphabet;
         }
-        memcpy(payload + hf_pos, hf_bytes, (size_t)h->hf_bytes);
+        if (payload)
+            memcpy(payload + hf_pos, hf_bytes, (size_t)h->hf_bytes);
+        seg_ptr[b] = hf_bytes;
+        seg_len[b] = (size_t)h->hf_bytes;
         hf_pos += (size_t)h->hf_bytes;
     }
-    if (!ret)
+    if (!ret) {
+        const PayloadSegments segs = {nblobs, seg_ptr, seg_len};
         ret = frame_from_parts(md, write_header, is_last, slots, tile_xy, NULL, lf, freq, alpha, bits, max_alphabet, payload,
-                               hf_total, icc, icc_size, out, out_len, err);
+                               hf_total, one_group ? NULL : &segs, icc, icc_size, out, out_len, err);
+    }
+    free((void *)seg_ptr);
+    free(seg_len);
     free(tile_xy);
     free(lf);
     free(freq);

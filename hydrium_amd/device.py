@@ -468,7 +468,7 @@ def blob_header(blob) -> np.ndarray:
 
 
 def frame_from_blobs(md: "api.HYDImageMetadata", blobs, *, write_header=True, is_last=True, icc: Optional[bytes] = None,
-                     lib=None) -> bytes:
+                     lib=None, raw: bool = False):
     """One-frame codestream from the blobs of the contexts that coded its LF groups (host only)."""
     d = lib or dll()
     arrs = [np.ascontiguousarray(np.frombuffer(b, np.uint8)) for b in blobs]
@@ -479,6 +479,9 @@ def frame_from_blobs(md: "api.HYDImageMetadata", blobs, *, write_header=True, is
                                     len(icc) if icc else 0, C.byref(out), C.byref(out_len), C.byref(err))
     if ret:
         raise DeviceError(ret, (err.value or b"").decode())
+    if raw:  # the library's own buffer, no copy: (ctypes uint8 array, release())
+        view = (C.c_uint8 * out_len.value).from_address(out.value)
+        return view, (lambda: d.hydamd_free(out))
     data = C.string_at(out.value, out_len.value)
     d.hydamd_free(out)
     return data

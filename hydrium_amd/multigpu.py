@@ -175,42 +175,67 @@ class GpuShardEngine:
         if self.n:
             self.shard.ctx.sync()
 
+    def alphabet_device(self):
+        return self.device
 
-def choreograph_frame(engine, parts, group=None, capacity=None, to_rank=0):
-    """One frame over the ranks of ``group``: transform stage -> all-gather of the per-LF-group alphabet
-    maxima (one int32 per LF group, on the device) -> entropy stage with this rank's floor -> one
-    gather of the shards' blobs to ``to_rank``.  Returns the list of blobs (bytes, rank order) there,
-    ``None`` elsewhere.  ``engine`` is a GpuShardEngine or anything with its methods; ``parts`` the
-    LF-group partition (sharding.partition_lf_groups).  Reference: presets are numbered across the
-    whole frame (encoder.c:852-901) and the alphabet maximum runs over LF groups in send order
+
+def enqueue_frame(engine, parts, capacity: int, group=None, to_rank=0):
+    """Everything a frame needs from this rank, enqueued without a host wait: transform stage ->
+    all-gather of the per-LF-group alphabet maxima (one int32 per LF group, on the device) -> entropy
+    stage with this rank's floor -> the shard's blob -> one gather of the blobs to ``to_rank``.
+    ``capacity`` is the blob size every rank sends (all ranks must pass the same value).  Returns a
+    handle for ``collect_frame``.  Reference: presets are numbered across the whole frame
+    (encoder.c:852-901) and the alphabet maximum runs over LF groups in send order
     (entropy.c:459-460,952)."""
     import torch
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    most = max(len(p) for p in parts)
+    most = max(max(len(p) for p in parts), 1)
+    engine.enqueue_transform()
+    mine = engine.alphabet_maxima()
+    padded = torch.zeros(most, dtype=torch.int32, device=mine.device)
+    padded[:mine.numel()] = mine
+    every = torch.empty(world * most, dtype=torch.int32, device=mine.device)
+    dist.all_gather_into_tensor(every, padded, group=group)
+    before = every.view(world, -1)[:rank]
+    floor = (before.max() if before.numel() else torch.zeros((), dtype=torch.int32, device=mine.device)).reshape(1)
+    engine.enqueue_entropy(floor.to(torch.int32).contiguous())
+    cap = (int(capacity) + 15) & ~15
+    blob = torch.zeros(cap, dtype=torch.uint8, device=mine.device)
+    engine.export_blob(blob)
+    rows = [torch.empty(cap, dtype=torch.uint8, device=mine.device) for _ in range(world)] if rank == to_rank else None
+    dist.gather(blob, gather_list=rows, dst=to_rank, group=group)
+    return dict(engine=engine, blob=blob, rows=rows, to_rank=to_rank, rank=rank, keep=(every, padded, floor))
+
+
+def collect_frame(handle):
+    """Wait for this rank's part of a frame queued by ``enqueue_frame``.  Returns (retry, rows): ``retry``
+    says this rank's blob is incomplete (its frame outgrew a buffer and was rerun inside the wait, or the
+    blob did not fit ``capacity``) — every rank then has to run the frame again; ``rows`` are the
+    gathered blobs as device tensors on the assembling rank, None elsewhere."""
+    handle["engine"].finish()
+    head = device.blob_header(handle["blob"][:device.BLOB_HEADER_DTYPE.itemsize].cpu().numpy().tobytes())
+    return bool(int(head["status"]) & device.BLOB_RETRY), handle["rows"]
+
+
+def choreograph_frame(engine, parts, group=None, capacity=None, to_rank=0):
+    """One frame over the ranks of ``group`` (enqueue_frame + collect_frame, rerun if a shard says so).
+    Returns the list of blobs (bytes, rank order) on ``to_rank``, ``None`` elsewhere.  ``engine`` is a
+    GpuShardEngine or anything with its methods; ``parts`` the LF-group partition
+    (sharding.partition_lf_groups)."""
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    dev = engine.alphabet_device() if hasattr(engine, "alphabet_device") else None
     for attempt in range(3):
-        engine.enqueue_transform()
-        mine = engine.alphabet_maxima()
-        padded = torch.zeros(max(most, 1), dtype=torch.int32, device=mine.device)
-        padded[:mine.numel()] = mine
-        every = torch.empty(world * max(most, 1), dtype=torch.int32, device=mine.device)
-        dist.all_gather_into_tensor(every, padded, group=group)
-        before = every.view(world, -1)[:rank]
-        floor = (before.max() if before.numel() else torch.zeros((), dtype=torch.int32, device=mine.device)).reshape(1)
-        engine.enqueue_entropy(floor.to(torch.int32).contiguous())
         # every rank sends the same number of bytes: the largest bound any of them reports
-        cap = torch.tensor([capacity or engine.blob_bound()], dtype=torch.int64, device=mine.device)
+        cap = torch.tensor([capacity or engine.blob_bound()], dtype=torch.int64, device=dev)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
-        cap = (int(cap.item()) + 15) & ~15
-        blob = torch.zeros(cap, dtype=torch.uint8, device=mine.device)
-        engine.export_blob(blob)
-        rows = [torch.empty(cap, dtype=torch.uint8, device=mine.device) for _ in range(world)] if rank == to_rank else None
-        dist.gather(blob, gather_list=rows, dst=to_rank, group=group)
-        engine.finish()
-        # did any shard have to be rerun (its blob is then incomplete)?  everybody goes again
-        head = device.blob_header(blob[:device.BLOB_HEADER_DTYPE.itemsize].cpu().numpy().tobytes())
-        retry = torch.tensor([1 if int(head["status"]) & device.BLOB_RETRY else 0], dtype=torch.int32, device=mine.device)
+        handle = enqueue_frame(engine, parts, int(cap.item()), group, to_rank)
+        again, rows = collect_frame(handle)
+        retry = torch.tensor([1 if again else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(retry, op=dist.ReduceOp.MAX, group=group)
         if not int(retry.item()):
             if rank != to_rank:
@@ -245,4 +270,14 @@ def encode_distributed(slab_tensor, width: int, height: int, origin_lf_pixels, g
             return None
         return device.frame_from_blobs(api.HYDImageMetadata(width, height, linear_light, -1, -1), blobs, lib=lib)
     finally:
+        # torch's caching allocator pools the blocks it handed out under the context's stream by that
+        # stream: give them back to the driver before the stream is destroyed with the context
+        engine = None
+        if shard.ctx:
+            shard.ctx.__dict__.pop("_floor_keep", None)
+        import gc
+
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
         shard.close()

@@ -27,9 +27,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # frames in flight live on separate HIP streams; let them map to separate hardware queues
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")  # 16 contexts + RCCL's stream + the collective stream + the default stream, each on a queue of its own
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def emit(out):
+    """Print the result line and make it the LAST thing on stdout: librccl writes a version banner to
+    stdout when the process exits, after anything Python can print."""
+    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
 
 def parse():
@@ -49,6 +57,7 @@ def parse():
                     help="code the LF coefficient streams on the GPU inside the timed loop (default) or leave them out")
     ap.add_argument("--collective", default="gather", choices=("gather", "all-gather"),
                     help="N > 1: bring each frame's sections to rank 0 only (default) or to every rank")
+    ap.add_argument("--gather-every", type=int, default=1, help="N > 1: frames whose blobs travel in one RCCL gather")
     ap.add_argument("--exchange", action="store_true",
                     help="run the multi-GPU exchange path (process group, all-gather per frame) even with one rank")
     ap.add_argument("--mode", default="frame", choices=("frame", "shard", "batch"),
@@ -230,7 +239,8 @@ def run_shard(args):
             "reruns_after_buffer_overflow": sum(g["retries"] for g in gathered),
             "frac_of_hbm_read_roofline": round((W * H * args.steps / dt) / (HBM_PEAK_GBS * 1e9 * world / 3), 5),
         }
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
     dist.barrier()
     torch.cuda.synchronize()
     dist.destroy_process_group()  # RCCL has seen the contexts' streams: it goes first
@@ -248,6 +258,8 @@ def run_shard(args):
     torch.cuda.empty_cache()
     for sh in shards:
         sh.close()
+    if out is not None:
+        emit(out)
 
 
 def run_batch(args):
@@ -322,9 +334,12 @@ def run_batch(args):
             "frame0_identical_to_reference": md5.get(0) == want if want else None,
             "threads_agree_with_single_thread_run": consistent,
         }
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
     if world > 1:
         dist.destroy_process_group()
+    if out is not None:
+        emit(out)
 
 
 def main():
@@ -364,47 +379,53 @@ def main():
         # 12 frames in flight stay within the 16 hardware queues; the latency leg uses the side stream
         c.set_lf_coder(2 if args.lf_coder == "on" else 0)
 
-    pending = []  # contexts whose frame is queued but whose sections have not been exchanged yet
-
-    xt = [0.0, 0.0]  # host seconds spent waiting for the frame / issuing the exchange
-    xstate = {"seen": 0, "cap": 0}
-    xbuf = {}
-
-    def exchange(ctx):
-        """N > 1: concatenate every rank's packed sections for the frame `ctx` just coded (RCCL all-gather)."""
-        t_a = time.perf_counter()
-        ctx.sync()
-        t_b = time.perf_counter()
-        xt[0] += t_b - t_a
-        mine = ctx.payload_tensor()
-        if args.lf_coder == "on":  # the coded LF streams travel with the HF sections: the gathered frame is complete
-            mine = torch.cat([mine, ctx.lf_payload_tensor()])
-        # the first exchanges size the collective exactly (one host sync each); every rank sees every
-        # size, so all of them agree on the same bound for the rest of the run
-        exact = xstate["seen"] < len(ctxs)
-        if exact:
-            sizes, _ = sharding.all_gather_sections(mine, dist.group.WORLD)
-            xstate["seen"] += 1
-            xstate["cap"] = max(xstate["cap"], int(int(sizes.max().item()) * 1.25) + 4096)
-        elif args.collective == "gather":  # to the assembling rank only: one chunk per xGMI link, nothing redundant
-            sharding.gather_sections(mine, xstate["cap"], 0, dist.group.WORLD, xbuf.setdefault(id(ctx), {}))
-        else:
-            sharding.all_gather_sections(mine, dist.group.WORLD, xstate["cap"], xbuf.setdefault(id(ctx), {}))
-        sharding.fence_context_stream(ctx)  # the context's next frame may not overwrite what is being gathered
-        xt[1] += time.perf_counter() - t_b
+    # N > 1: every frame's results leave each GPU as ONE blob (hydamd_export_frame: tables, section sizes,
+    # coded LF streams, packed HF sections) built by a kernel at the end of the frame's stream, and one
+    # RCCL gather brings the blobs to the assembling rank — no host synchronisation anywhere: the gather is
+    # issued asynchronously under the context's stream and the context's NEXT frame waits for it on the device.
+    ext = [torch.cuda.ExternalStream(c.get_stream()) for c in ctxs]
+    # A RCCL operation costs most of a millisecond end to end whatever it moves and the operations of a
+    # process group run one after another: one gather per frame would cap the rate near 1.1 frames/ms
+    # (measured, world of one: 74 instead of 108 Gpixel/s).  So the blobs of `per` consecutive frames
+    # (contexts) sit in one tensor and travel together.
+    per = max(1, min(args.gather_every, len(ctxs)))
+    while len(ctxs) % per:
+        per -= 1
+    ngroups = len(ctxs) // per
+    xstate = {"cap": 0, "big": [None] * ngroups, "rows": [None] * ngroups, "work": [None] * ngroups}
+    xt = [0.0, 0.0]  # host seconds spent issuing the export + gather
+    xstream = torch.cuda.Stream() if use_dist else None
 
     def step(i):
-        ctx = ctxs[i % len(ctxs)]
-        if use_dist and len(pending) == len(ctxs):
-            exchange(pending.pop(0))  # the oldest frame in flight; its context is the one reused now
-        ctx.encode_image_tensor(img)
-        if use_dist:
-            pending.append(ctx)
+        k = i % len(ctxs)
+        ctx = ctxs[k]
+        if not use_dist:
+            ctx.encode_image_tensor(img)
+            return ctx
+        j = k // per
+        with torch.cuda.stream(ext[k]):
+            if xstate["work"][j] is not None:
+                xstate["work"][j].wait()  # device-side: this stream waits until the group's previous gather has read the blobs
+            ctx.encode_image_tensor(img)
+            t_b = time.perf_counter()
+            ctx.export_frame(lfg, xstate["big"][j][k % per])
+            xt[1] += time.perf_counter() - t_b
+        if k % per == per - 1:  # the group's last frame is queued: one collective for all of its blobs
+            t_b = time.perf_counter()
+            for q in range(j * per, j * per + per):
+                xstream.wait_stream(ext[q])
+            with torch.cuda.stream(xstream):
+                xstate["work"][j] = dist.gather(xstate["big"][j].view(-1), gather_list=xstate["rows"][j], dst=0, async_op=True)
+            xt[1] += time.perf_counter() - t_b
         return ctx
 
     def drain():
-        while pending:
-            exchange(pending.pop(0))
+        for j, w in enumerate(xstate["work"]):
+            if w is not None:
+                for q in range(j * per, j * per + per):
+                    with torch.cuda.stream(ext[q]):
+                        w.wait()
+                xstate["work"][j] = None
 
     # initialisation, not measurement: every context codes one frame once so that its freshly
     # allocated buffers have been touched before anything is timed; then the W warm-up steps
@@ -412,6 +433,21 @@ def main():
         c.encode_image_tensor(img)
     for c in ctxs:
         c.sync()
+    if use_dist:
+        # blob size every rank sends: 1.25 x the largest blob of this first frame over all ranks
+        probe = torch.zeros(ctxs[0].blob_bound(lfg), dtype=torch.uint8, device=img.device)
+        with torch.cuda.stream(ext[0]):
+            ctxs[0].export_frame(lfg, probe)
+        ctxs[0].sync()
+        mine_total = int(device.blob_header(probe[:64].cpu().numpy().tobytes())["total_bytes"])
+        capt = torch.tensor([mine_total], dtype=torch.int64, device=img.device)
+        dist.all_reduce(capt, op=dist.ReduceOp.MAX)
+        xstate["cap"] = (int(int(capt.item()) * 1.25) + 65536 + 15) & ~15
+        del probe
+        for j in range(ngroups):
+            xstate["big"][j] = torch.zeros((per, xstate["cap"]), dtype=torch.uint8, device=img.device)
+            if rank == 0:
+                xstate["rows"][j] = [torch.empty(per * xstate["cap"], dtype=torch.uint8, device=img.device) for _ in range(world)]
     for i in range(args.warmup):
         step(i)
     drain()
@@ -428,7 +464,6 @@ def main():
     # context's stream; the interval runs from the completion of the last priming frames to the
     # completion of the last timed frames — K frame completions at the pipeline's own rate.  The whole
     # sequence still sits between barrier + synchronize on both sides (`wall` below reports it).
-    ext = [torch.cuda.ExternalStream(c.get_stream()) for c in ctxs]
     nprime = 4 * len(ctxs)  # several frame latencies: started together, the contexts take a while to fall into their steady interleaving
     ncool = len(ctxs)
 
@@ -551,6 +586,7 @@ def main():
         for c in ctxs:
             c.set_lf_coder(2)
 
+    out = None
     if rank == 0:
         bytes_in = W * H * 3 * (args.depth // 8)
         kernels = {k: {"avg_ms": round(v[0] / max(v[1], 1), 4), "launches": v[1],
@@ -602,7 +638,7 @@ def main():
                        "lf_coder": "gpu, in-stream" if args.lf_coder == "on" else "off",
                        "groups": lfg * 64 if W % 2048 == 0 and H % 2048 == 0 else None, "lf_groups": lfg,
                        "streams": len(ctxs), "rans_groups_per_workgroup": args.rans_waves, "parallelism": f"{world} x (one frame per GPU)" +
-                                                            (f", RCCL {args.collective} of HF sections and LF streams" if use_dist else "")},
+                                                            (f", one RCCL gather of result blobs per {per} frames to rank 0" if use_dist else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_in, "avg_launch_ms": round(dom_ms, 4),
@@ -614,9 +650,11 @@ def main():
             "valu_roofline": valu,
             "kernels": kernels,
             "kernels_note": "per-launch durations in the timed region, where the streams' kernels overlap each other",
-            "exchange_host_ms_per_step": ({"wait_for_frame": round(xt[0] / args.steps * 1e3, 4),
-                                           "issue_collectives": round(xt[1] / args.steps * 1e3, 4),
-                                           "note": "includes warm-up steps' share"} if use_dist else None),
+            "exchange": ({"blob_capacity_bytes": xstate["cap"], "host_ms_per_step_issuing_export_and_gather":
+                          round(xt[1] / max(total_frames + args.warmup, 1) * 1e3, 4),
+                          "frames_per_collective": per,
+                          "note": "one hydamd_export_frame kernel per frame, one asynchronous RCCL gather per group of frames, no host synchronisation"}
+                         if use_dist else None),
             "single_frame": lat,
             "single_frame_form5": lat5,
             "hf_sections_only": hf_only,
@@ -649,11 +687,22 @@ def main():
             out["cpu_baseline"] = cpu_baseline(host_img)
             if "api_end_to_end" in out and "md5" in out["cpu_baseline"]:
                 out["api_end_to_end"]["identical_to_cpu_reference"] = out["cpu_baseline"]["md5"] == out["api_end_to_end"]["md5"]
-        print(json.dumps(out), flush=True)
+    # tear down first, print last: RCCL writes its version banner to stdout when the process group goes away,
+    # and the line the driver parses should be the final one
+    drain()
+    xstate["big"] = xstate["rows"] = None
+    import gc
+
+    gc.collect()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    torch.cuda.empty_cache()  # blocks torch handed out under the contexts' streams go back before the streams do
     for c in ctxs:
         c.close()
-    if use_dist:
-        dist.destroy_process_group()
+    if rank == 0:
+        emit(out)
 
 
 if __name__ == "__main__":

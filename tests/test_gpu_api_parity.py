@@ -312,3 +312,49 @@ def test_sample_format_may_change_between_tiles(eager):
     env = dict(os.environ, HYDAMD_EAGER=eager, PYTHONPATH=os.path.dirname(os.path.dirname(__file__)))
     r = subprocess.run([sys.executable, "-c", _MIXED], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("width,height,tiles", [((1 << 20) + 256, 256, [(0, 0), (4096, 0)]), (20000, 20000, [(3, 5), (78, 78)])])
+def test_level10_container_through_the_api(lib, image, width, height, tiles):
+    """images past level 5 (a side over 2^20, or over 2^28 pixels): container prologue + tile-mode frames"""
+    from test_host_glue import _two_tiles_of_a_huge_image
+    from oracle import refprobe
+
+    imgs = []
+    for k, (tx, ty) in enumerate(tiles):
+        tw, th = min(256, width - tx * 256), min(256, height - ty * 256)
+        imgs.append(np.ascontiguousarray(image("photo", tw, th, 8, seed=50 + k)))
+    got = _two_tiles_of_a_huge_image(lib, width, height, tiles, imgs)
+    assert got[4:12] == b"JXL \r\n\x87\n" and b"jxll\x0a" in got[:64]
+    if refprobe.available():
+        assert got == _two_tiles_of_a_huge_image(refprobe.reference_library(), width, height, tiles, imgs)
+
+
+def test_c5_batch_of_4k_frames_on_four_threads_matches_the_reference(lib):
+    """BASELINE configs[4] beyond frame 0: eight different 3840x2160 frames, each encoded twice, on four
+    threads sharing the GPU (one encoder per frame, parked device contexts); every file against the reference."""
+    import threading
+
+    from hydrium_amd import synth
+    from oracle import refprobe
+
+    imgs = [synth.make_image("photo", 3840, 2160, 8, seed=1234 + k) for k in range(8)]
+    got = [None] * 16
+
+    def work(t):
+        for f in range(t, 16, 4):
+            got[f] = hashlib.md5(api.encode_image(lib, imgs[f % 8])).hexdigest()
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert all(got[f] == got[f % 8] for f in range(16))
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        want0 = [e["md5"] for e in json.load(f)["files"] if (e["kind"], e["width"], e["height"]) == ("photo", 3840, 2160)][0]
+    assert got[0] == want0
+    if refprobe.available():
+        ref = refprobe.reference_library(optimised=True)
+        for k in range(8):
+            assert got[k] == hashlib.md5(api.encode_image(ref, imgs[k])).hexdigest(), f"frame {k}"

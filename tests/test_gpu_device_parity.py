@@ -195,3 +195,46 @@ print("ok")
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("form", [4, 5])
+@pytest.mark.parametrize("num_presets,scheme", [(28, 0), (29, 1), (85, 1), (86, 2), (127, 2), (129, 3), (255, 3)])
+def test_every_cluster_scheme_on_the_device(image, num_presets, scheme, form):
+    """the 2- and 1-cluster-per-preset maps (frames of 86 to 255 LF groups, reference
+    encoder.c:880-901) had only run on the CPU oracle.  A frame header of `num_presets` presets with three
+    small LF groups sent under scattered preset ids: tokens, clusters, tables and section bytes of each
+    against the oracle coding the same LF group with the same (preset, num_presets), running alphabet in
+    send order."""
+    from hydrium_amd import device
+    from oracle import binding as orc
+
+    imgs = [image("photo", 300, 200, 8, seed=7), image("noise", 72, 40, 8, seed=8), image("smooth", 520, 264, 16, seed=9)]
+    presets = [0, num_presets // 2, num_presets - 1]
+    per_preset = {0: 9, 1: 3, 2: 2, 3: 1}[scheme]
+    with device.DeviceContext(0, 3, 0) as ctx:
+        ctx.set_rans_waves(form)
+        ctx.begin_frame(num_presets)
+        keep = []
+        for slot, (img, p) in enumerate(zip(imgs, presets)):
+            t = _torch_image(img)
+            keep.append(t)
+            isz = t.element_size()
+            h, w, _ = img.shape
+            base = t.data_ptr()
+            ctx.encode_lf_group(slot, [base, base + isz, base + 2 * isz], 3 * w, 3, {1: 0, 2: 1}[isz], w, h, p)
+        ctx.finish_frame(3)
+        ctx.sync()
+        payload = ctx.read_payload()
+        running = 0
+        at = 0
+        for slot, (img, p) in enumerate(zip(imgs, presets)):
+            res, running = orc.encode_lf_group(np.ascontiguousarray(img), num_presets=num_presets, preset=p,
+                                               max_alphabet_size=running)
+            assert res.cluster_to - res.cluster_from == per_preset
+            _check_lf_group(ctx, slot, res, res.cluster_from, False)
+            bits, offs = ctx.read_sections(slot)
+            assert np.array_equal(bits[:res.num_groups], res.group_bits)
+            assert int(offs[0]) == at
+            assert payload[at:at + len(res.stream)] == res.stream, f"sections of slot {slot}"
+            at += len(res.stream)
+        assert at == len(payload)

@@ -181,3 +181,54 @@ def test_icc_transform_is_decodable_for_every_platform_signature(platform, size)
     mangled = bytes((C.c_uint8 * n.value).from_address(out.value))
     d.hydt_free(out)
     assert _icc_unmangle(mangled) == bytes(icc)
+
+
+def _two_tiles_of_a_huge_image(lib, width, height, tiles, tile_imgs, shift=0):
+    """Drive a libhydrium build in tile mode over an image far too large to hold: only the given tiles
+    are sent (any tile but the last may be left out, libhydrium.h), each from its own small buffer."""
+    import ctypes as C
+
+    out = bytearray()
+    with api.Encoder(lib) as enc:
+        enc.check(enc.set_metadata(width, height, 0, shift, shift))
+        buf = (C.c_uint8 * (1 << 20))()
+        enc.check(enc.provide_output(buf))
+        for i, ((tx, ty), img) in enumerate(zip(tiles, tile_imgs)):
+            th, tw, _ = img.shape
+            p = img.ctypes.data
+            enc.check(enc.send_tile_ptrs([p, p + 1, p + 2], tx, ty, 3 * tw, 3, int(i == len(tiles) - 1), api.HYD_UINT8))
+            while True:
+                ret = enc.check(enc.flush())
+                code, n = enc.release_output()
+                enc.check(code)
+                out += C.string_at(buf, n)
+                enc.check(enc.provide_output(buf))
+                if ret != api.HYD_NEED_MORE_OUTPUT:
+                    break
+    return bytes(out)
+
+
+LEVEL10 = [((1 << 20) + 256, 256, [(0, 0), (4096, 0)]),        # wider than 2^20
+           (20000, 20000, [(3, 5), (78, 78)])]                 # more than 2^28 pixels (78 = last 256-px tile, 32 px wide)
+
+
+@pytest.mark.parametrize("width,height,tiles", LEVEL10)
+def test_level10_container_prologue(ref_lib, image, width, height, tiles):
+    """images beyond level 5 (a side over 2^20 or more than 2^28 pixels) start with the
+    ISOBMFF signature + 'jxll' level box + an open-ended 'jxlc' box (reference encoder.c:23-30,170-174,
+    libhydrium.c:67-68); nothing exercised that.  Host glue fed by the oracle against the reference."""
+    from oracle import binding as orc
+
+    imgs = []
+    for k, (tx, ty) in enumerate(tiles):
+        tw, th = min(256, width - tx * 256), min(256, height - ty * 256)
+        imgs.append(np.ascontiguousarray(image("photo", tw, th, 8, seed=50 + k)))
+    want = _two_tiles_of_a_huge_image(ref_lib, width, height, tiles, imgs)
+    # signature box, 'ftyp', then the 'jxll' box saying level 10
+    assert want[:12] == b"\0\0\0\x0cJXL \r\n\x87\n" and want[16:20] == b"ftyp" and b"jxll\x0a" in want[:64]
+    md = api.HYDImageMetadata(width, height, 0, 0, 0)
+    got = b""
+    for k, ((tx, ty), img) in enumerate(zip(tiles, imgs)):
+        r, mx = orc.encode_lf_group(img, num_presets=1, preset=0)
+        got += glue.frame_from_stages(md, k == 0, k == len(tiles) - 1, [(tx, ty)], [r], mx)
+    assert got == want

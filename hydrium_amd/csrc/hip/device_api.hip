@@ -59,8 +59,9 @@ hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets,
                        uint64_t payload_cap, int clear_shared_words, uint32_t *status, hipStream_t stream);
 hipError_t launch_pack(const uint32_t *bitbuf, uint32_t bit_pitch_words, const uint32_t *group_bits, const uint64_t *offsets,
                        uint8_t *payload, int count, const uint32_t *status, hipStream_t stream);
+size_t lf_work_bytes();
 hipError_t launch_lf_coder(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, HydkLfStream *streams,
-                           uint32_t *bits, int num_slots, hipStream_t stream);
+                           uint32_t *bits, void *work, int num_slots, hipStream_t stream);
 hipError_t launch_lf_gather(HydkLfStream *streams, const uint32_t *bits, uint32_t *packed, unsigned long long *total,
                             int num_slots, hipStream_t stream);
 hipError_t launch_lf_huffman_only(const uint32_t *hist, HydkLfStream *stream_out, uint32_t *codes, hipStream_t stream);
@@ -151,6 +152,7 @@ struct HydAmdContext {
     unsigned long long *lf_recs = nullptr; /* [slots][HYDK_LF_SYMBOLS] */
     uint32_t *lf_hist = nullptr;           /* [slots + 1][HYDK_LF_CODES]; the last entry is hydamd_debug_lf_code's scratch */
     uint32_t *lf_codes = nullptr;          /* [HYDK_LF_CODES] likewise */
+    char *lf_work = nullptr;               /* [slots] per-LF-group scratch of the LF coder's kernels (codes, window bit counts) */
     HydkLfStream *lf_streams = nullptr;    /* [slots + 1] */
     uint32_t *lf_bits = nullptr;           /* [slots][HYDK_LF_BITWORDS] */
     uint32_t *lf_packed = nullptr;         /* the same symbol data, back to back in slot order (4-byte aligned) */
@@ -557,7 +559,7 @@ void hydamd_destroy(HydAmdContext *ctx) {
         (void)hipEventDestroy(ctx->lf_ready);
     if (ctx->h_lf_total_pinned)
         (void)hipHostFree(ctx->h_lf_total_pinned);
-    void *lfdev[] = {ctx->lf_recs, ctx->lf_hist, ctx->lf_codes, ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total};
+    void *lfdev[] = {ctx->lf_recs, ctx->lf_hist, ctx->lf_codes, ctx->lf_work, ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total};
     for (void *p : lfdev)
         if (p)
             (void)hipFree(p);
@@ -666,6 +668,7 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipMalloc(&ctx->lf_recs, slots * HYDK_LF_SYMBOLS * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc(&ctx->lf_hist, (slots + 1) * HYDK_LF_CODES * sizeof(uint32_t))); /* +1: the unit-test entry's scratch */
     HIP_TRY(ctx, hipMalloc(&ctx->lf_codes, HYDK_LF_CODES * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->lf_work, slots * hydk::lf_work_bytes()));
     HIP_TRY(ctx, hipMalloc(&ctx->lf_streams, (slots + 1) * sizeof(HydkLfStream)));
     HIP_TRY(ctx, hipMalloc(&ctx->lf_bits, slots * HYDK_LF_BITWORDS * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->lf_packed, slots * HYDK_LF_BITWORDS * sizeof(uint32_t)));
@@ -942,7 +945,8 @@ static int lf_range(HydAmdContext *ctx, int first, int count, bool forked) {
     ScopedTimer timer(ctx, HYDAMD_K_LF, where);
     HIP_TRY(ctx, hydk::launch_lf_coder(ctx->d_jobs + first, ctx->lf_recs + (size_t)first * HYDK_LF_SYMBOLS,
                                        ctx->lf_hist + (size_t)first * HYDK_LF_CODES, ctx->lf_streams + first,
-                                       ctx->lf_bits + (size_t)first * HYDK_LF_BITWORDS, count, where));
+                                       ctx->lf_bits + (size_t)first * HYDK_LF_BITWORDS,
+                                       ctx->lf_work + (size_t)first * hydk::lf_work_bytes(), count, where));
     ctx->lf_pending = ctx->lf_pending || forked;
     ctx->lf_need_gather = true;
     return ST_OK;

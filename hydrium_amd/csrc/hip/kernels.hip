@@ -122,11 +122,15 @@ __device__ __forceinline__ uint32_t to_u16(float x) { /* format.c:33-36 */
  *   2  gathers from the uploaded LUTs */
 constexpr int kXybFastRcp = 0, kXybIeeeDiv = 1, kXybGather = 2;
 
-/* the 65536-entry LUTs of format.c:58-83, evaluated in registers */
+/* the 65536-entry LUTs of format.c:58-83, evaluated in registers.  The clamp of f32_to_u16 (format.c:33-36)
+ * never acts on these inputs — the curve maps [0, 1] into [0, 1) — so it is left out; like every other
+ * shortcut here that is not assumed but checked entry by entry by k_lut_selftest. */
 __device__ __forceinline__ uint32_t input_lut16_eval(uint32_t i, int linear_light) {
     const float f = (float)i * kUnit16;
-    return to_u16(linear_light ? f : linearize(f));
+    return (uint32_t)(int)((linear_light ? f : linearize(f)) * 65535.f + 0.5f);
 }
+/* floor(u / 3) for u < 2^31 in one multiply-high: u * ceil(2^32 / 3) overshoots u / 3 by less than 1/3 */
+__device__ __forceinline__ uint32_t div3(uint32_t u) { return __umulhi(u, 0x55555556u); }
 template <int XMODE>
 __device__ __forceinline__ float bias_lut_eval(uint32_t i) {
     if (XMODE == kXybIeeeDiv)
@@ -138,7 +142,7 @@ __device__ __forceinline__ float bias_lut_eval(uint32_t i) {
      * checked: k_lut_selftest compares all 65536 entries at context creation, and a device where
      * it fails runs the IEEE-division variant instead. */
     const float x = (float)i * kUnit16 + 0.0037930732552754493f;
-    float z = __uint_as_float(0x548c39cbu - __float_as_uint(x) / 3u);
+    float z = __uint_as_float(0x548c39cbu - div3(__float_as_uint(x))); /* x is a positive float below 2: its bits are below 2^30 */
     z *= 1.5015480449f - 0.534850249f * x * z * z * z;
     z *= 1.333333985f - 0.33333333f * x * z * z * z;
     const float r0 = __builtin_amdgcn_rcpf(z);
@@ -200,6 +204,18 @@ __device__ __forceinline__ void dct8(const float (&x)[8], float (&o)[8]) {
     o[0] = dc * 0.125f;
 #pragma unroll
     for (int k = 1; k < 8; k++) {
+        if (k == 4) {
+            /* every coefficient of this row is +-0.125: multiplying by a power of two is exact and commutes
+             * with the rounding of each addition (no intermediate is anywhere near the subnormal range:
+             * samples are multiples of 2^-27 or row-pass outputs of such), so the eight products and seven
+             * ordered additions collapse to seven ordered additions and one product — same bits */
+            float acc = x[0];
+#pragma unroll
+            for (int n = 1; n < 8; n++)
+                acc = kDct[3][n] > 0 ? acc + x[n] : acc - x[n];
+            o[k] = acc * 0.125f;
+            continue;
+        }
         /* the reference starts from +0.0f; 0.0f + p differs from p only in the sign of a zero,
          * which no later stage can observe (every consumer multiplies and truncates to int) */
         float acc = x[0] * kDct[k - 1][0];
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
     __shared__ uint8_t s_jinfo[64][2];                /* zig-zag position j -> {natural index kv*8+kh, frequency context (encoder.c:53-58) mod 3} */
     __shared__ unsigned long long s_below[64];        /* bits 0..j-1 */
     __shared__ unsigned long long s_nibmask[8][2][16]; /* [kh][kv nibble][4 non-zero flags] -> their zig-zag bits */
-    __shared__ float s_wq[3 * 64];                    /* quantisation weight by channel and natural index */
+    __shared__ __attribute__((aligned(16))) float s_wq[3 * 64]; /* quantisation weight [channel][kh][kv]: a thread's eight in two 16-byte reads */
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -376,8 +392,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
         s_jinfo[t][1] = (uint8_t)((j < 2 ? 0 : j < 16 ? j - 1 : j < 32 ? 15 + ((j - 16) >> 1) : 23 + ((j - 32) >> 2)) % 3);
         s_below[t] = (1ull << t) - 1ull;
     }
-    if (t < 192)
-        s_wq[t] = (float)kQuantWeight[t >> 6][kZigzag[(t >> 3) & 7][t & 7]];
+    if (t < 192) /* t = (c, kh, kv) */
+        s_wq[t] = (float)kQuantWeight[t >> 6][kZigzag[t & 7][(t >> 3) & 7]];
     {
         /* thread = (kh, half, pattern): OR of the zig-zag bits of coefficients (4*half + b, kh), b in pattern */
         const int kh_ = t >> 5, half = (t >> 4) & 1, pat = t & 15;
@@ -542,10 +558,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
                 }
                 uint32_t pat = 0; /* bit kv: coefficient (kv, kh) is non-zero */
                 int q[8];
+                const float4 w03 = *(const float4 *)&s_wq[c * 64 + kh * 8], w47 = *(const float4 *)&s_wq[c * 64 + kh * 8 + 4];
+                const float wq[8] = {w03.x, w03.y, w03.z, w03.w, w47.x, w47.y, w47.z, w47.w};
 #pragma unroll
                 for (int kv = 0; kv < 8; kv++) {
                     /* encoder.c:808-811: trunc((coef * weight) * 5); +-1 is the dead zone */
-                    int qq = (int)(v[kv] * s_wq[c * 64 + kv * 8 + kh] * 5.0f);
+                    int qq = (int)(v[kv] * wq[kv] * 5.0f);
                     const bool nz = (uint32_t)(qq + 1) > 2u && !(kv == 0 && kh == 0); /* the DC slot is coded by the LF path */
                     qq = nz ? qq : 0;
                     q[kv] = qq;
@@ -1390,27 +1408,38 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
  * K3b: section sizes -> offsets (single block), then pack each section to its byte offset.
  * Sections are byte-padded with zeros, as hyd_bitwriter_flush does (bitwriter.c:144-150).
  * ======================================================================================== */
-__global__ __launch_bounds__(1024) void k_scan_sections(const uint32_t *group_bits, int count, uint64_t *offsets,
-                                                        uint64_t *total, uint8_t *payload, uint64_t payload_cap,
-                                                        int clear_shared_words, uint32_t *status) {
-    __shared__ uint64_t s_part[1024];
-    const int t = threadIdx.x;
-    const int per = (count + 1023) / 1024;
+/* One workgroup of 256 threads: a larger one would have to wait for a compute unit with sixteen free
+ * wave slots while other frames' transform workgroups keep taking whatever frees up (measured: this
+ * kernel took 0.8 ms in the pipelined loop as a 1024-thread workgroup, against 15 us alone). */
+__global__ __launch_bounds__(kThreads) void k_scan_sections(const uint32_t *group_bits, int count, uint64_t *offsets,
+                                                            uint64_t *total, uint8_t *payload, uint64_t payload_cap,
+                                                            int clear_shared_words, uint32_t *status) {
+    __shared__ uint64_t s_wave[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (count + kThreads - 1) / kThreads;
+    const int lo = min(count, t * per), hi = min(count, lo + per);
     uint64_t sum = 0;
-    for (int i = t * per; i < min(count, (t + 1) * per); i++)
+    for (int i = lo; i < hi; i++)
         sum += (group_bits[i] + 7u) >> 3;
-    s_part[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint64_t v = t >= d ? s_part[t - d] : 0;
-        __syncthreads();
-        s_part[t] += v;
-        __syncthreads();
+    /* inclusive scan of the per-thread byte counts: inside a wave by shuffles, across the four waves through LDS */
+    uint64_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t v = __shfl_up(inc, d);
+        if (lane >= d)
+            inc += v;
     }
-    const uint64_t all = s_part[1023];
+    if (lane == 63)
+        s_wave[wave] = inc;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+    for (int w = 0; w < 4; w++) {
+        before += w < wave ? s_wave[w] : 0;
+        all += s_wave[w];
+    }
     const bool fits = all <= payload_cap && !(*status & HYDK_STATUS_OVERFLOW);
-    uint64_t run = s_part[t] - sum;
-    for (int i = t * per; i < min(count, (t + 1) * per); i++) {
+    uint64_t run = before + inc - sum;
+    for (int i = lo; i < hi; i++) {
         const uint64_t nbytes = (group_bits[i] + 7u) >> 3;
         offsets[i] = run;
         if (clear_shared_words && fits && nbytes) {
@@ -1422,7 +1451,7 @@ __global__ __launch_bounds__(1024) void k_scan_sections(const uint32_t *group_bi
         }
         run += nbytes;
     }
-    if (t == 1023) {
+    if (t == kThreads - 1) {
         *total = fits ? all : 0;
         if (all > payload_cap)
             atomicOr(status, HYDK_STATUS_PAYLOAD); /* the host enlarges the payload and reruns the frame */
@@ -1613,7 +1642,7 @@ hipError_t launch_rans_emit(const HydkLfJob *d_jobs, const uint32_t *sym_count, 
 
 hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, uint8_t *payload,
                        uint64_t payload_cap, int clear_shared_words, uint32_t *status, hipStream_t stream) {
-    hipLaunchKernelGGL(k_scan_sections, dim3(1), dim3(1024), 0, stream, group_bits, count, offsets, total, payload, payload_cap,
+    hipLaunchKernelGGL(k_scan_sections, dim3(1), dim3(kThreads), 0, stream, group_bits, count, offsets, total, payload, payload_cap,
                        clear_shared_words, status);
     return hipGetLastError();
 }

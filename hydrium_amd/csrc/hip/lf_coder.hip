@@ -10,32 +10,34 @@
  * (csrc/host/frame.c), which receives the code lengths and the packed symbol bits from here.
  *
  * The stream is one value sequence per LF group: channels Y, X, B, raster inside a channel,
- * n = 3 * vbw * vbh <= 196608 values.  One workgroup of 1024 threads per LF group, three phases:
+ * n = 3 * vbw * vbh <= 196608 values.  Everything is cut into windows that one 256-thread workgroup
+ * handles, so that an LF group is hundreds of small, short-lived workgroups that fit beside whatever
+ * else the GPU is running (a 1024-thread workgroup per LF group, as in round 1, had to wait for a
+ * compute unit with sixteen free wave slots and then held half of its registers for a millisecond:
+ * 16 % of the pipelined frame rate for 1.5 % of its instructions):
  *
- *   tokens        residuals -> run structure -> one 8-byte record per value + token histogram.
- *                 A maximal run of equal values is cut into chunks of 128: the chunk's first value
- *                 is a literal; the r <= 127 repeats behind it become one (run token r - 3,
- *                 distance) pair when r > 3 and r literals otherwise.  What a position emits
- *                 therefore depends only on its offset in its run (forward max-scan of run starts)
- *                 and on at most 127 values ahead, so a pass decides 3968 positions from a window
- *                 of 4096.
- *   code          one wavefront: the reference's O(n^2) selection loop with the two smallest
- *                 candidates found by a wave-wide minimum over a total order that reproduces its
- *                 comparator and slot-visiting order; subtree depth recursion replaced by subtree
+ *   k_lf_tokens   one workgroup per 896 values: residuals -> run structure -> one 8-byte record per
+ *                 value + token histogram.  A maximal run of equal values is cut into chunks of 128:
+ *                 the chunk's first value is a literal; the r <= 127 repeats behind it become one (run
+ *                 token r - 3, distance) pair when r > 3 and r literals otherwise.  What a position
+ *                 emits therefore depends only on its offset in its run and on at most 127 values
+ *                 ahead: the workgroup looks at a window of 1024 values and finds the run its first
+ *                 value continues by a (parallel) backward scan.
+ *   k_lf_huffman  one wavefront per LF group: the reference's O(n^2) selection loop with the two
+ *                 smallest candidates found by a wave-wide minimum over a total order that reproduces
+ *                 its comparator and slot-visiting order; subtree depth recursion replaced by subtree
  *                 heights and a parent walk.  Runs in a compact slot space (only the slots the
  *                 16509-entry alphabet can ever touch) with all candidates held in registers: no
  *                 LDS traffic or barrier inside the merge loop.
- *   pack          per-value bit strings (<= 59 bits), block prefix sum, OR into an LDS window,
- *                 coalesced flush; LSB-first like HYDBitWriter (bitwriter.c:110-124).
+ *   k_lf_count    one workgroup per 1024 values: bits each value will take -> bits of the window.
+ *   k_lf_offsets  one workgroup per LF group: exclusive prefix sum of the windows' bit counts; clears
+ *                 the words two windows share.
+ *   k_lf_pack     one workgroup per 1024 values: per-value bit strings (<= 59 bits) ORed into an LDS
+ *                 window at the window's bit offset, whole words stored, the two shared words ORed into
+ *                 memory; LSB-first like HYDBitWriter (bitwriter.c:110-124).
  *
- * k_lf_tokens is the first phase, k_lf_code the other two (see the note above the kernels).
- *
- * The work is small (<= 196608 values per 4.2 Mpx LF group, 7.2 M wave-instructions per 8K frame
- * against the transform kernel's 363 M); it exists so that a frame's sections are complete on the
- * device and the host's per-frame serial work disappears.  device_api.hip runs the kernels either on
- * a side stream beside the HF entropy stage (one frame at a time: hidden behind it) or at the end
- * of the context's own stream (many frames in flight: costs ~7 % of the frame rate, two thirds of
- * it CU occupancy rather than instructions).
+ * The work is small (<= 196608 values per 4.2 Mpx LF group); it exists so that a frame's sections are
+ * complete on the device and the host's per-frame serial work disappears.
  */
 #include <hip/hip_runtime.h>
 
@@ -45,10 +47,20 @@
 
 namespace {
 
-constexpr int kLfThreads = 1024;
-constexpr int kScanSpan = kLfThreads * 4;       /* values looked at per pass */
+constexpr int kLfThreads = 256;
+constexpr int kLfWaves = kLfThreads / 64;
+constexpr int kScanSpan = kLfThreads * 4;       /* values a token workgroup looks at */
 constexpr int kAhead = 128;                     /* a run chunk is at most 128 values */
-constexpr int kEmitSpan = kScanSpan - kAhead;   /* values decided per pass of k_lf_tokens */
+constexpr int kEmitSpan = kScanSpan - kAhead;   /* values it decides */
+constexpr int kPackSpan = kLfThreads * 4;       /* values per count / pack workgroup */
+constexpr int kMaxPackWindows = HYDK_LF_SYMBOLS / kPackSpan; /* 192 */
+
+/* per-LF-group scratch between the kernels */
+struct LfWork {
+    uint32_t codes[HYDK_LF_CODES];          /* length << 16 | bit-reversed code per compact token */
+    uint32_t win_bits[kMaxPackWindows];     /* bits of each pack window */
+    uint32_t win_off[kMaxPackWindows];      /* their exclusive prefix sums */
+};
 constexpr int kPlane = HYDK_DC_PITCH * HYDK_DC_PITCH;
 
 /* record: bits 0-31 value, bit 32 "emit a literal", bits 33-39 run length r (0: no run pair) */
@@ -120,14 +132,13 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 /* ==========================================================================================
- * phase 1 (all 1024 threads): residuals -> run structure -> records + token histogram in LDS.
- * Thread t owns window positions 4t .. 4t+3.  Three barriers per pass, everything they exchange is
- * double-buffered; the LF ints of the next pass are fetched while this one is processed.
+ * tokens: residuals -> run structure -> records + token histogram, one window per workgroup.
+ * Thread t owns window positions 4t .. 4t+3.
  * ======================================================================================== */
 struct LfTokenScratch {
-    int wtot[2][kLfThreads / 64];       /* per wave: last run head inside it (absolute index) or -1 */
-    uint32_t lastv[2][kLfThreads / 64]; /* per wave: its last value (the next wave's lane 0 compares against it) */
-    uint32_t tailv[2];                  /* the value at the last position this pass decides */
+    int wtot[kLfWaves];       /* per wave: last run head inside it (absolute index) or -1 */
+    uint32_t lastv[kLfWaves]; /* per wave: its last value (the next wave's lane 0 compares against it) */
+    int head[kLfWaves];       /* backward scan: nearest run head each wave found, or -1 */
 };
 
 /* value of the stream at plane c, block (y, x): pack_signed(lf - clamped_gradient(w, n, nw)),
@@ -151,6 +162,14 @@ __device__ __forceinline__ uint32_t lf_residual_at(const int32_t *dc, int c, int
     if (!(x | y)) /* top-left block: all three neighbours count as 0 */
         w = n = nw = 0;
     return lf_predict(cur, w, n, nw);
+}
+
+/* the stream's value at position i (0 <= i < n) */
+__device__ __forceinline__ uint32_t lf_value_at(const int32_t *dc, const LfShape &sh, int i) {
+    const int visit = (i >= sh.blocks) + (i >= 2 * sh.blocks);
+    const int rem = i - visit * sh.blocks;
+    const int y = rem / sh.vbw, x = rem - y * sh.vbw;
+    return lf_residual_at(dc, visit < 2 ? 1 - visit : 2, y, x);
 }
 
 /* the thread's four consecutive values from stream position i0 on.  The usual case — all four in one
@@ -193,119 +212,130 @@ __device__ __forceinline__ void lf_fetch(const int32_t *dc, const LfShape &sh, i
     }
 }
 
-__device__ __forceinline__ void lf_tokens_phase(const HydkLfJob &job, const LfShape &sh, unsigned long long *__restrict__ recs,
-                                                int *s_rs2 /* [2][kScanSpan] */, uint32_t *s_hist, LfTokenScratch &S) {
+/* Start of the run that position `from` (>= 0) belongs to: the largest h <= from with h == 0 or
+ * value[h] != value[h - 1].  All threads of the workgroup scan backwards together, 256 positions per
+ * step; photographic content stops in the first step, a flat plane walks all of it (768 steps at most). */
+__device__ __forceinline__ int lf_run_start(const int32_t *dc, const LfShape &sh, int from, LfTokenScratch &S) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int top = from; top >= 0; top -= kLfThreads) {
+        const int p = top - tid;
+        int head = -1;
+        if (p >= 0)
+            head = (p == 0 || lf_value_at(dc, sh, p) != lf_value_at(dc, sh, p - 1)) ? p : -1;
+        head = wave_incl_max(head);
+        if (lane == 63)
+            S.head[wave] = head;
+        __syncthreads();
+        int best = -1;
+#pragma unroll
+        for (int w = 0; w < kLfWaves; w++)
+            best = best > S.head[w] ? best : S.head[w];
+        __syncthreads();
+        if (best >= 0)
+            return best;
+    }
+    return 0;
+}
+
+__device__ __forceinline__ void lf_tokens_window(const HydkLfJob &job, const LfShape &sh, unsigned long long *__restrict__ recs,
+                                                 int tb, int *s_rs /* [kScanSpan] */, uint32_t *s_hist, LfTokenScratch &S) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t *dc = job.dc;
     const int q0 = tid * 4;
 
     for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads)
         s_hist[i] = 0;
+    uint32_t v[4];
+    lf_fetch(dc, sh, tb + q0, v);
+    /* what lies in front of the window: the value at tb - 1 and the start of the run it belongs to */
+    const uint32_t tailv = tb > 0 ? lf_value_at(dc, sh, tb - 1) : 0u;
+    const int carry = tb > 0 ? lf_run_start(dc, sh, tb - 1, S) : 0;
+    if (lane == 63)
+        S.lastv[wave] = v[3];
+    __syncthreads();
 
-    uint32_t next[4];
-    lf_fetch(dc, sh, q0, next);
-    int carry = 0;      /* run start of the position in front of the window (position 0 is a head, so unused at first) */
-    uint32_t tailv = 0; /* its value */
-    int buf = 0;
-    for (int tb = 0; tb < sh.n; tb += kEmitSpan, buf ^= 1) {
-        uint32_t v[4];
+    /* start of the run each position belongs to (absolute index): max-scan of run heads */
+    uint32_t prev = LF_DPP_KEEP(v[3], 0x138, 0xF); /* wave_shr:1 — the previous lane's last value */
+    if (lane == 0)
+        prev = wave ? S.lastv[wave - 1] : tailv;
+    int rs[4];
+    int last = -1;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            v[j] = next[j];
-        if (tb + kEmitSpan < sh.n)
-            lf_fetch(dc, sh, tb + kEmitSpan + q0, next);
-        int *s_rs = s_rs2 + buf * kScanSpan;
-        if (lane == 63)
-            S.lastv[buf][wave] = v[3];
-        if (q0 + 3 == kEmitSpan - 1)
-            S.tailv[buf] = v[3];
-        __syncthreads();
+    for (int j = 0; j < 4; j++) {
+        const int i = tb + q0 + j;
+        last = (i == 0 || i >= sh.n || v[j] != prev) ? i : last;
+        rs[j] = last;
+        prev = v[j];
+    }
+    const int inc = wave_incl_max(last);
+    if (lane == 63)
+        S.wtot[wave] = inc;
+    __syncthreads();
+    int pre = carry;
+    for (int w = 0; w < wave; w++) {
+        const int t = S.wtot[w];
+        pre = pre > t ? pre : t;
+    }
+    {
+        int excl = (int)LF_DPP_KEEP(inc, 0x138, 0xF);
+        excl = lane ? excl : -1;
+        pre = pre > excl ? pre : excl;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        rs[j] = rs[j] < 0 ? pre : rs[j];
+    *(int4 *)&s_rs[q0] = make_int4(rs[0], rs[1], rs[2], rs[3]);
+    __syncthreads();
 
-        /* start of the run each position belongs to (absolute index): max-scan of run heads */
-        uint32_t prev = LF_DPP_KEEP(v[3], 0x138, 0xF); /* wave_shr:1 — the previous lane's last value */
-        if (lane == 0)
-            prev = wave ? S.lastv[buf][wave - 1] : tailv;
-        int rs[4];
-        int last = -1;
+    /* what each position sends, without divergent control flow: offset c inside the run's current
+     * 128-chunk; "same4" = the chunk has a fifth value, i.e. more than 3 repeats behind its first */
+    const int last_q = sh.n - 1 - tb; /* window-relative index of the stream's last value */
+    uint32_t lit[4], r[4];
+    bool need[4], any_need = false;
+    int s4v[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int i = tb + q0 + j;
-            last = (i == 0 || i >= sh.n || v[j] != prev) ? i : last;
-            rs[j] = last;
-            prev = v[j];
-        }
-        const int inc = wave_incl_max(last);
-        if (lane == 63)
-            S.wtot[buf][wave] = inc;
-        __syncthreads();
-        int pre = carry;
-        for (int w = 0; w < wave; w++) {
-            const int t = S.wtot[buf][w];
-            pre = pre > t ? pre : t;
-        }
-        {
-            int excl = (int)LF_DPP_KEEP(inc, 0x138, 0xF);
-            excl = lane ? excl : -1;
-            pre = pre > excl ? pre : excl;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            rs[j] = rs[j] < 0 ? pre : rs[j];
-        *(int4 *)&s_rs[q0] = make_int4(rs[0], rs[1], rs[2], rs[3]);
-        __syncthreads();
-        carry = s_rs[kEmitSpan - 1];
-        tailv = S.tailv[buf];
-
-        /* what each position sends, without divergent control flow: offset c inside the run's current
-         * 128-chunk; "same4" = the chunk has a fifth value, i.e. more than 3 repeats behind its first */
-        const int last_q = sh.n - 1 - tb; /* window-relative index of the stream's last value */
-        uint32_t lit[4], r[4];
-        bool need[4], any_need = false;
-        int s4v[4];
+    for (int j = 0; j < 4; j++) {
+        const int q = q0 + j;
+        const bool valid = q < kEmitSpan && q <= last_q;
+        const int c = (tb + q - rs[j]) & 127;
+        const int s4 = q - c + 4;
+        const bool same4 = c <= 3 && s4 <= last_q && s_rs[s4 < kScanSpan ? s4 : kScanSpan - 1] == rs[j];
+        lit[j] = valid && (c == 0 || (c <= 3 && !same4));
+        need[j] = valid && c == 0 && same4;
+        r[j] = 0;
+        s4v[j] = s4;
+        any_need |= need[j];
+    }
+    if (__any(any_need)) { /* some chunk head has a run behind it: how long, up to 127 (7 halvings) */
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int q = q0 + j;
-            const bool valid = q < kEmitSpan && q <= last_q;
-            const int c = (tb + q - rs[j]) & 127;
-            const int s4 = q - c + 4;
-            const bool same4 = c <= 3 && s4 <= last_q && s_rs[s4 < kScanSpan ? s4 : kScanSpan - 1] == rs[j];
-            lit[j] = valid && (c == 0 || (c <= 3 && !same4));
-            need[j] = valid && c == 0 && same4;
-            r[j] = 0;
-            s4v[j] = s4;
-            any_need |= need[j];
-        }
-        if (__any(any_need)) { /* some chunk head has a run behind it: how long, up to 127 (7 halvings) */
+            int lo = need[j] ? s4v[j] : 0, hi = q + 127 < last_q ? q + 127 : last_q;
+            hi = need[j] ? hi : 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int q = q0 + j;
-                int lo = need[j] ? s4v[j] : 0, hi = q + 127 < last_q ? q + 127 : last_q;
-                hi = need[j] ? hi : 0;
-#pragma unroll
-                for (int it = 0; it < 7; it++) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    const bool in_run = s_rs[mid] == rs[j];
-                    lo = in_run ? mid : lo;
-                    hi = in_run ? hi : mid - 1;
-                }
-                r[j] = need[j] ? (uint32_t)(lo - q) : 0u;
+            for (int it = 0; it < 7; it++) {
+                const int mid = (lo + hi + 1) >> 1;
+                const bool in_run = s_rs[mid] == rs[j];
+                lo = in_run ? mid : lo;
+                hi = in_run ? hi : mid - 1;
             }
+            r[j] = need[j] ? (uint32_t)(lo - q) : 0u;
         }
+    }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (lit[j]) {
-                uint32_t token, nb, res;
-                lf_hybrid(v[j], token, nb, res);
-                atomicAdd(&s_hist[token], 1u);
-            }
-            if (r[j])
-                atomicAdd(&s_hist[256u + r[j] - 3u], 1u);
+    for (int j = 0; j < 4; j++) {
+        if (lit[j]) {
+            uint32_t token, nb, res;
+            lf_hybrid(v[j], token, nb, res);
+            atomicAdd(&s_hist[token], 1u);
         }
-        if (q0 < kEmitSpan && q0 <= last_q) { /* a thread's four records are 32 contiguous bytes; the tail of the stream is padded, never read */
-            ulonglong2 *dst = (ulonglong2 *)(recs + tb + q0);
-            dst[0] = make_ulonglong2(q0 + 0 <= last_q ? LF_REC(v[0], lit[0], r[0]) : 0ull, q0 + 1 <= last_q ? LF_REC(v[1], lit[1], r[1]) : 0ull);
-            dst[1] = make_ulonglong2(q0 + 2 <= last_q ? LF_REC(v[2], lit[2], r[2]) : 0ull, q0 + 3 <= last_q ? LF_REC(v[3], lit[3], r[3]) : 0ull);
-        }
+        if (r[j])
+            atomicAdd(&s_hist[256u + r[j] - 3u], 1u);
+    }
+    if (q0 < kEmitSpan && q0 <= last_q) { /* a thread's four records are 32 contiguous bytes; the tail of the stream is padded, never read */
+        ulonglong2 *dst = (ulonglong2 *)(recs + tb + q0);
+        dst[0] = make_ulonglong2(q0 + 0 <= last_q ? LF_REC(v[0], lit[0], r[0]) : 0ull, q0 + 1 <= last_q ? LF_REC(v[1], lit[1], r[1]) : 0ull);
+        dst[1] = make_ulonglong2(q0 + 2 <= last_q ? LF_REC(v[2], lit[2], r[2]) : 0ull, q0 + 3 <= last_q ? LF_REC(v[3], lit[3], r[3]) : 0ull);
     }
     __syncthreads();
 }
@@ -576,157 +606,200 @@ __device__ __forceinline__ void lf_huffman_wave(const uint32_t *hist, uint32_t *
 }
 
 /* ==========================================================================================
- * phase 3 (all 1024 threads): per-value bit strings -> prefix sum -> LDS window -> coalesced flush.
- * Two barriers per pass and one 30 KB window (the next pass's records are already on their way).
+ * count / offsets / pack: per-value bit strings -> bit offsets -> bits.  A window is 1024 values
+ * (four per thread); a value takes at most 59 bits.
  * ======================================================================================== */
-constexpr int kPackWords = (31 + kScanSpan * 59) / 32 + 2;
+constexpr int kPackWords = (31 + kPackSpan * 59) / 32 + 2;
 
-__device__ __forceinline__ void lf_fetch_recs(const LfShape &sh, const unsigned long long *__restrict__ recs, int i0,
-                                              unsigned long long (&r)[4]) {
+/* the bit string (value, length) each of the thread's four records sends under the LF group's code;
+ * returns their total length */
+__device__ __forceinline__ uint32_t lf_window_strings(const LfShape &sh, const unsigned long long *__restrict__ recs, int tb,
+                                                      const uint32_t *s_code, unsigned long long (&val)[4], uint32_t (&len)[4]) {
+    const int i0 = tb + (int)threadIdx.x * 4;
+    unsigned long long rec[4] = {0, 0, 0, 0};
     if (i0 < sh.n) { /* records are stored in padded groups of four */
         const ulonglong2 a = ((const ulonglong2 *)(recs + i0))[0], b = ((const ulonglong2 *)(recs + i0))[1];
-        r[0] = a.x;
-        r[1] = a.y;
-        r[2] = b.x;
-        r[3] = b.y;
-    } else {
-        r[0] = r[1] = r[2] = r[3] = 0;
+        rec[0] = a.x;
+        rec[1] = a.y;
+        rec[2] = b.x;
+        rec[3] = b.y;
     }
-}
-
-__device__ __forceinline__ uint32_t lf_pack_phase(const LfShape &sh, const unsigned long long *__restrict__ recs,
-                                                  const uint32_t *s_code, uint32_t *s_bits /* [kPackWords] */,
-                                                  uint32_t (*s_wsum)[kLfThreads / 64], uint32_t *__restrict__ out) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t gbits = 0; /* bits written so far (uniform) */
-    uint32_t carry = 0; /* thread 0 only: the bits already placed in the word at gbits >> 5 */
-    for (int w = tid; w < kPackWords; w += kLfThreads)
-        s_bits[w] = 0;
-    unsigned long long next[4];
-    lf_fetch_recs(sh, recs, tid * 4, next);
-    int buf = 0;
-    for (int tb = 0; tb < sh.n; tb += kScanSpan, buf ^= 1) {
-        unsigned long long rec[4];
+    uint32_t mine = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            rec[j] = next[j];
-        lf_fetch_recs(sh, recs, tb + kScanSpan + tid * 4, next);
-
-        unsigned long long val[4];
-        uint32_t len[4], mine = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int i = tb + tid * 4 + j;
-            val[j] = 0;
-            len[j] = 0;
-            if (i < sh.n) {
-                const uint32_t v = (uint32_t)rec[j], lit = (uint32_t)(rec[j] >> 32) & 1u, r = (uint32_t)(rec[j] >> 33) & 127u;
-                if (lit) {
-                    uint32_t token, nb, res;
-                    lf_hybrid(v, token, nb, res);
-                    const uint32_t e = s_code[token];
-                    val[j] = (e & 0xFFFFu) | ((unsigned long long)res << (e >> 16));
-                    len[j] = (e >> 16) + nb;
-                }
-                if (r) {
-                    const uint32_t e = s_code[256u + r - 3u];
-                    val[j] |= (unsigned long long)(e & 0xFFFFu) << len[j];
-                    len[j] += e >> 16;
-                }
+    for (int j = 0; j < 4; j++) {
+        val[j] = 0;
+        len[j] = 0;
+        if (i0 + j < sh.n) {
+            const uint32_t v = (uint32_t)rec[j], lit = (uint32_t)(rec[j] >> 32) & 1u, r = (uint32_t)(rec[j] >> 33) & 127u;
+            if (lit) {
+                uint32_t token, nb, res;
+                lf_hybrid(v, token, nb, res);
+                const uint32_t e = s_code[token];
+                val[j] = (e & 0xFFFFu) | ((unsigned long long)res << (e >> 16));
+                len[j] = (e >> 16) + nb;
             }
-            mine += len[j];
+            if (r) {
+                const uint32_t e = s_code[256u + r - 3u];
+                val[j] |= (unsigned long long)(e & 0xFFFFu) << len[j];
+                len[j] += e >> 16;
+            }
         }
-        const uint32_t inc = wave_incl_sum(mine);
-        if (lane == 63)
-            s_wsum[buf][wave] = inc;
-        __syncthreads(); /* also: the previous pass has flushed and cleared the window */
-        uint32_t pos = (gbits & 31u) + inc - mine, total = 0;
-        for (int w = 0; w < kLfThreads / 64; w++) {
-            const uint32_t t = s_wsum[buf][w];
-            if (w < wave)
-                pos += t;
-            total += t;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (!len[j])
-                continue;
-            const uint32_t w = pos >> 5, shl = pos & 31u;
-            const unsigned long long lo = val[j] << shl;
-            const uint32_t hi = shl ? (uint32_t)(val[j] >> (64u - shl)) : 0u;
-            if ((uint32_t)lo)
-                atomicOr(&s_bits[w], (uint32_t)lo);
-            if ((uint32_t)(lo >> 32))
-                atomicOr(&s_bits[w + 1], (uint32_t)(lo >> 32));
-            if (hi)
-                atomicOr(&s_bits[w + 2], hi);
-            pos += len[j];
-        }
-        __syncthreads();
-        /* Whole words go out and are cleared by the thread that stored them.  The partly filled last
-         * word (index `full`) belongs to thread 0 alone: it keeps its bits in a register until they
-         * are ORed into the first word of the next pass, so the window needs no second copy and no
-         * third barrier. */
-        const uint32_t end = (gbits & 31u) + total, full = end >> 5;
-        uint32_t *dst = out + (gbits >> 5);
-        for (uint32_t w = tid; w < full; w += kLfThreads) {
-            dst[w] = s_bits[w] | (w ? 0u : carry);
-            s_bits[w] = 0;
-        }
-        if (tid == 0) {
-            carry = s_bits[full] | (full ? 0u : carry);
-            s_bits[full] = 0;
-        }
-        gbits += total;
+        mine += len[j];
     }
-    if (tid == 0 && (gbits & 31u))
-        out[gbits >> 5] = carry;
-    return gbits;
+    return mine;
 }
 
 /* ==========================================================================================
- * The two kernels, grid = LF groups, block = 1024.
- *
- * Why two and not one or three: the workgroup dispatcher does not start placing a kernel's
- * workgroups while an earlier-started kernel (the HF entropy stage with its thousands of workgroups)
- * still has workgroups waiting to be placed.  k_lf_tokens is enqueued right behind the transform
- * kernel and gets its CUs before the entropy stage starts; k_lf_code then lands in the entropy
- * stage's tail, where CUs are idle anyway.  A single fused kernel would sit on 16 CUs for its whole
- * life (measured: the entropy stage 14 % slower); three kernels leave the one-wave code construction
- * waiting in the queue for most of the entropy stage (measured: 1.8 ms instead of 0.18 ms).
+ * The kernels.  All workgroups are 256 threads and live for microseconds.
  * ======================================================================================== */
+/* grid = (windows of 896 values, LF groups); hist_all must be zero on entry */
 __global__ __launch_bounds__(kLfThreads) void k_lf_tokens(const HydkLfJob *__restrict__ jobs,
                                                           unsigned long long *__restrict__ recs_all,
                                                           uint32_t *__restrict__ hist_all) {
-    const int slot = blockIdx.x, tid = threadIdx.x;
+    const int slot = blockIdx.y, tid = threadIdx.x;
     const HydkLfJob &job = jobs[slot];
     const LfShape sh = lf_shape(job);
-    __shared__ __attribute__((aligned(16))) int s_rs[2 * kScanSpan];
+    const int tb = (int)blockIdx.x * kEmitSpan;
+    if (tb >= sh.n)
+        return;
+    __shared__ __attribute__((aligned(16))) int s_rs[kScanSpan];
     __shared__ uint32_t s_hist[HYDK_LF_CODES];
     __shared__ LfTokenScratch s_tok;
-    lf_tokens_phase(job, sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, s_rs, s_hist, s_tok);
+    lf_tokens_window(job, sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, tb, s_rs, s_hist, s_tok);
     for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads)
-        hist_all[(size_t)slot * HYDK_LF_CODES + i] = s_hist[i];
+        if (s_hist[i])
+            atomicAdd(&hist_all[(size_t)slot * HYDK_LF_CODES + i], s_hist[i]);
 }
 
-__global__ __launch_bounds__(kLfThreads, 2) /* <= 64 registers: two transform workgroups fit beside it */
-void k_lf_code(const HydkLfJob *__restrict__ jobs,
-                                                        const unsigned long long *__restrict__ recs_all,
-                                                        const uint32_t *__restrict__ hist_all, HydkLfStream *__restrict__ streams,
-                                                        uint32_t *__restrict__ bits_all) {
-    const int slot = blockIdx.x, tid = threadIdx.x;
+/* grid = LF groups, block = 64: code lengths + canonical codes of each LF group's histogram */
+__global__ __launch_bounds__(64) void k_lf_codes(const uint32_t *__restrict__ hist_all, HydkLfStream *__restrict__ streams,
+                                                 LfWork *__restrict__ work) {
+    __shared__ LfHuffScratch s_huff;
+    const int slot = blockIdx.x;
+    lf_huffman_wave(hist_all + (size_t)slot * HYDK_LF_CODES, work[slot].codes, streams + slot, s_huff, (int)threadIdx.x);
+}
+
+/* grid = (windows of 1024 values, LF groups) */
+__global__ __launch_bounds__(kLfThreads) void k_lf_count(const HydkLfJob *__restrict__ jobs,
+                                                         const unsigned long long *__restrict__ recs_all,
+                                                         LfWork *__restrict__ work) {
+    const int slot = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LfShape sh = lf_shape(jobs[slot]);
+    const int tb = (int)blockIdx.x * kPackSpan;
+    if (tb >= sh.n)
+        return;
+    __shared__ uint32_t s_code[HYDK_LF_CODES];
+    __shared__ uint32_t s_wsum[kLfWaves];
+    for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads)
+        s_code[i] = work[slot].codes[i];
+    __syncthreads();
+    unsigned long long val[4];
+    uint32_t len[4];
+    const uint32_t mine = lf_window_strings(sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, tb, s_code, val, len);
+    const uint32_t inc = wave_incl_sum(mine);
+    if (lane == 63)
+        s_wsum[wave] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < kLfWaves; w++)
+            total += s_wsum[w];
+        work[slot].win_bits[blockIdx.x] = total;
+    }
+}
+
+/* grid = LF groups, block = 256: where each pack window's bits start; the words two windows share are cleared */
+__global__ __launch_bounds__(kLfThreads) void k_lf_offsets(const HydkLfJob *__restrict__ jobs, LfWork *__restrict__ work,
+                                                           HydkLfStream *__restrict__ streams, uint32_t *__restrict__ bits_all) {
+    const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const LfShape sh = lf_shape(jobs[slot]);
+    const int windows = (sh.n + kPackSpan - 1) / kPackSpan; /* <= 192 < 256 */
+    __shared__ uint32_t s_wsum[kLfWaves];
+    const uint32_t mine = tid < windows ? work[slot].win_bits[tid] : 0u;
+    const uint32_t inc = wave_incl_sum(mine);
+    if (lane == 63)
+        s_wsum[wave] = inc;
+    __syncthreads();
+    uint32_t off = inc - mine, total = 0;
+    for (int w = 0; w < kLfWaves; w++) {
+        if (w < wave)
+            off += s_wsum[w];
+        total += s_wsum[w];
+    }
+    uint32_t *out = bits_all + (size_t)slot * HYDK_LF_BITWORDS;
+    if (tid < windows) {
+        work[slot].win_off[tid] = off;
+        /* the window's first word may hold the end of the window before, its last the start of the one
+         * after: k_lf_pack ORs into exactly these two */
+        if (mine) {
+            out[off >> 5] = 0;
+            out[(off + mine - 1u) >> 5] = 0;
+        }
+    }
+    if (tid == 0)
+        streams[slot].bit_count = total;
+}
+
+/* grid = (windows of 1024 values, LF groups) */
+__global__ __launch_bounds__(kLfThreads) void k_lf_pack(const HydkLfJob *__restrict__ jobs,
+                                                        const unsigned long long *__restrict__ recs_all,
+                                                        const LfWork *__restrict__ work, uint32_t *__restrict__ bits_all) {
+    const int slot = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const LfShape sh = lf_shape(jobs[slot]);
+    const int tb = (int)blockIdx.x * kPackSpan;
+    if (tb >= sh.n)
+        return;
     __shared__ uint32_t s_bits[kPackWords];
     __shared__ uint32_t s_code[HYDK_LF_CODES];
-    __shared__ uint32_t s_wsum[2][kLfThreads / 64];
-    __shared__ LfHuffScratch s_huff;
-    if (tid < 64)
-        lf_huffman_wave(hist_all + (size_t)slot * HYDK_LF_CODES, s_code, streams + slot, s_huff, tid);
+    __shared__ uint32_t s_wsum[kLfWaves];
+    for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads)
+        s_code[i] = work[slot].codes[i];
+    for (int w = tid; w < kPackWords; w += kLfThreads)
+        s_bits[w] = 0;
     __syncthreads();
-    const uint32_t nbits = lf_pack_phase(sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, s_code, s_bits, s_wsum,
-                                         bits_all + (size_t)slot * HYDK_LF_BITWORDS);
-    if (tid == 0)
-        streams[slot].bit_count = nbits;
+    unsigned long long val[4];
+    uint32_t len[4];
+    const uint32_t mine = lf_window_strings(sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, tb, s_code, val, len);
+    const uint32_t inc = wave_incl_sum(mine);
+    if (lane == 63)
+        s_wsum[wave] = inc;
+    __syncthreads();
+    const uint32_t gbits = work[slot].win_off[blockIdx.x]; /* bits in front of this window */
+    uint32_t pos = (gbits & 31u) + inc - mine, total = 0;
+    for (int w = 0; w < kLfWaves; w++) {
+        const uint32_t t = s_wsum[w];
+        if (w < wave)
+            pos += t;
+        total += t;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!len[j])
+            continue;
+        const uint32_t w = pos >> 5, shl = pos & 31u;
+        const unsigned long long lo = val[j] << shl;
+        const uint32_t hi = shl ? (uint32_t)(val[j] >> (64u - shl)) : 0u;
+        if ((uint32_t)lo)
+            atomicOr(&s_bits[w], (uint32_t)lo);
+        if ((uint32_t)(lo >> 32))
+            atomicOr(&s_bits[w + 1], (uint32_t)(lo >> 32));
+        if (hi)
+            atomicOr(&s_bits[w + 2], hi);
+        pos += len[j];
+    }
+    __syncthreads();
+    /* whole words are stored; the first and the last word of the span may be shared with the neighbouring
+     * windows (k_lf_offsets cleared them): those are ORed into memory */
+    if (!total)
+        return;
+    const uint32_t end = (gbits & 31u) + total, last = (end - 1u) >> 5;
+    uint32_t *dst = bits_all + (size_t)slot * HYDK_LF_BITWORDS + (gbits >> 5);
+    for (uint32_t w = tid; w <= last; w += kLfThreads) {
+        if (w == 0 || w == last)
+            atomicOr(&dst[w], s_bits[w]);
+        else
+            dst[w] = s_bits[w];
+    }
 }
 
 /* The LF groups' symbol data, 4-byte aligned, back to back in slot order: one copy (or one
@@ -769,11 +842,22 @@ __global__ __launch_bounds__(64) void k_lf_huffman(const uint32_t *__restrict__ 
 
 namespace hydk {
 
-/* tokens + code for `num_slots` LF groups; every pointer addresses the first of them */
+/* bytes of scratch per LF group (device_api.hip allocates it) */
+size_t lf_work_bytes() { return sizeof(LfWork); }
+
+/* the LF coder for `num_slots` LF groups; every pointer addresses the first of them */
 hipError_t launch_lf_coder(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, HydkLfStream *streams,
-                           uint32_t *bits, int num_slots, hipStream_t stream) {
-    hipLaunchKernelGGL(k_lf_tokens, dim3(num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist);
-    hipLaunchKernelGGL(k_lf_code, dim3(num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist, streams, bits);
+                           uint32_t *bits, void *work, int num_slots, hipStream_t stream) {
+    LfWork *w = (LfWork *)work;
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)num_slots * HYDK_LF_CODES * sizeof(uint32_t), stream);
+    if (e != hipSuccess)
+        return e;
+    const int token_windows = (HYDK_LF_SYMBOLS + kEmitSpan - 1) / kEmitSpan;
+    hipLaunchKernelGGL(k_lf_tokens, dim3(token_windows, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist);
+    hipLaunchKernelGGL(k_lf_codes, dim3(num_slots), dim3(64), 0, stream, hist, streams, w);
+    hipLaunchKernelGGL(k_lf_count, dim3(kMaxPackWindows, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, w);
+    hipLaunchKernelGGL(k_lf_offsets, dim3(num_slots), dim3(kLfThreads), 0, stream, d_jobs, w, streams, bits);
+    hipLaunchKernelGGL(k_lf_pack, dim3(kMaxPackWindows, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, w, bits);
     return hipGetLastError();
 }
 

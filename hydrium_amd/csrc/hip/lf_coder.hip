@@ -29,10 +29,10 @@
  *                 heights and a parent walk.  Runs in a compact slot space (only the slots the
  *                 16509-entry alphabet can ever touch) with all candidates held in registers: no
  *                 LDS traffic or barrier inside the merge loop.
- *   k_lf_count    one workgroup per 1024 values: bits each value will take -> bits of the window.
- *   k_lf_offsets  one workgroup per LF group: exclusive prefix sum of the windows' bit counts; clears
- *                 the words two windows share.
- *   k_lf_pack     one workgroup per 1024 values: per-value bit strings (<= 59 bits) ORed into an LDS
+ *   k_lf_offsets  one workgroup per LF group: bits of each window (its token histogram times the code
+ *                 lengths, plus its residue bits), their exclusive prefix sum; clears the words two
+ *                 windows share.
+ *   k_lf_pack     one workgroup per window: per-value bit strings (<= 59 bits) ORed into an LDS
  *                 window at the window's bit offset, whole words stored, the two shared words ORed into
  *                 memory; LSB-first like HYDBitWriter (bitwriter.c:110-124).
  *
@@ -52,14 +52,14 @@ constexpr int kLfWaves = kLfThreads / 64;
 constexpr int kScanSpan = kLfThreads * 4;       /* values a token workgroup looks at */
 constexpr int kAhead = 128;                     /* a run chunk is at most 128 values */
 constexpr int kEmitSpan = kScanSpan - kAhead;   /* values it decides */
-constexpr int kPackSpan = kLfThreads * 4;       /* values per count / pack workgroup */
-constexpr int kMaxPackWindows = HYDK_LF_SYMBOLS / kPackSpan; /* 192 */
+constexpr int kMaxWindows = (HYDK_LF_SYMBOLS + kEmitSpan - 1) / kEmitSpan; /* 220 windows of 896 values */
 
 /* per-LF-group scratch between the kernels */
 struct LfWork {
-    uint32_t codes[HYDK_LF_CODES];          /* length << 16 | bit-reversed code per compact token */
-    uint32_t win_bits[kMaxPackWindows];     /* bits of each pack window */
-    uint32_t win_off[kMaxPackWindows];      /* their exclusive prefix sums */
+    uint32_t codes[HYDK_LF_CODES];               /* length << 16 | bit-reversed code per compact token */
+    uint32_t win_residue_bits[kMaxWindows];      /* residue bits the window's literals carry */
+    uint32_t win_off[kMaxWindows];               /* bits in front of each window */
+    uint16_t win_hist[kMaxWindows][HYDK_LF_CODES]; /* tokens of each window: with the code lengths, its size in bits */
 };
 constexpr int kPlane = HYDK_DC_PITCH * HYDK_DC_PITCH;
 
@@ -237,8 +237,9 @@ __device__ __forceinline__ int lf_run_start(const int32_t *dc, const LfShape &sh
     return 0;
 }
 
-__device__ __forceinline__ void lf_tokens_window(const HydkLfJob &job, const LfShape &sh, unsigned long long *__restrict__ recs,
-                                                 int tb, int *s_rs /* [kScanSpan] */, uint32_t *s_hist, LfTokenScratch &S) {
+/* returns the residue bits of the literals this thread sent */
+__device__ __forceinline__ uint32_t lf_tokens_window(const HydkLfJob &job, const LfShape &sh, unsigned long long *__restrict__ recs,
+                                                     int tb, int *s_rs /* [kScanSpan] */, uint32_t *s_hist, LfTokenScratch &S) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t *dc = job.dc;
     const int q0 = tid * 4;
@@ -322,12 +323,14 @@ __device__ __forceinline__ void lf_tokens_window(const HydkLfJob &job, const LfS
             r[j] = need[j] ? (uint32_t)(lo - q) : 0u;
         }
     }
+    uint32_t residue_bits = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (lit[j]) {
             uint32_t token, nb, res;
             lf_hybrid(v[j], token, nb, res);
             atomicAdd(&s_hist[token], 1u);
+            residue_bits += nb;
         }
         if (r[j])
             atomicAdd(&s_hist[256u + r[j] - 3u], 1u);
@@ -338,6 +341,7 @@ __device__ __forceinline__ void lf_tokens_window(const HydkLfJob &job, const LfS
         dst[1] = make_ulonglong2(q0 + 2 <= last_q ? LF_REC(v[2], lit[2], r[2]) : 0ull, q0 + 3 <= last_q ? LF_REC(v[3], lit[3], r[3]) : 0ull);
     }
     __syncthreads();
+    return residue_bits;
 }
 
 /* ==========================================================================================
@@ -609,7 +613,7 @@ __device__ __forceinline__ void lf_huffman_wave(const uint32_t *hist, uint32_t *
  * count / offsets / pack: per-value bit strings -> bit offsets -> bits.  A window is 1024 values
  * (four per thread); a value takes at most 59 bits.
  * ======================================================================================== */
-constexpr int kPackWords = (31 + kPackSpan * 59) / 32 + 2;
+constexpr int kPackWords = (31 + kEmitSpan * 59) / 32 + 2;
 
 /* the bit string (value, length) each of the thread's four records sends under the LF group's code;
  * returns their total length */
@@ -617,7 +621,8 @@ __device__ __forceinline__ uint32_t lf_window_strings(const LfShape &sh, const u
                                                       const uint32_t *s_code, unsigned long long (&val)[4], uint32_t (&len)[4]) {
     const int i0 = tb + (int)threadIdx.x * 4;
     unsigned long long rec[4] = {0, 0, 0, 0};
-    if (i0 < sh.n) { /* records are stored in padded groups of four */
+    const bool mine_window = (int)threadIdx.x * 4 < kEmitSpan; /* the last 32 threads have no values of this window */
+    if (mine_window && i0 < sh.n) { /* records are stored in padded groups of four */
         const ulonglong2 a = ((const ulonglong2 *)(recs + i0))[0], b = ((const ulonglong2 *)(recs + i0))[1];
         rec[0] = a.x;
         rec[1] = a.y;
@@ -629,7 +634,7 @@ __device__ __forceinline__ uint32_t lf_window_strings(const LfShape &sh, const u
     for (int j = 0; j < 4; j++) {
         val[j] = 0;
         len[j] = 0;
-        if (i0 + j < sh.n) {
+        if (mine_window && i0 + j < sh.n) {
             const uint32_t v = (uint32_t)rec[j], lit = (uint32_t)(rec[j] >> 32) & 1u, r = (uint32_t)(rec[j] >> 33) & 127u;
             if (lit) {
                 uint32_t token, nb, res;
@@ -655,7 +660,7 @@ __device__ __forceinline__ uint32_t lf_window_strings(const LfShape &sh, const u
 /* grid = (windows of 896 values, LF groups); hist_all must be zero on entry */
 __global__ __launch_bounds__(kLfThreads) void k_lf_tokens(const HydkLfJob *__restrict__ jobs,
                                                           unsigned long long *__restrict__ recs_all,
-                                                          uint32_t *__restrict__ hist_all) {
+                                                          uint32_t *__restrict__ hist_all, LfWork *__restrict__ work) {
     const int slot = blockIdx.y, tid = threadIdx.x;
     const HydkLfJob &job = jobs[slot];
     const LfShape sh = lf_shape(job);
@@ -665,10 +670,23 @@ __global__ __launch_bounds__(kLfThreads) void k_lf_tokens(const HydkLfJob *__res
     __shared__ __attribute__((aligned(16))) int s_rs[kScanSpan];
     __shared__ uint32_t s_hist[HYDK_LF_CODES];
     __shared__ LfTokenScratch s_tok;
-    lf_tokens_window(job, sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, tb, s_rs, s_hist, s_tok);
-    for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads)
-        if (s_hist[i])
-            atomicAdd(&hist_all[(size_t)slot * HYDK_LF_CODES + i], s_hist[i]);
+    __shared__ uint32_t s_rbits;
+    if (tid == 0)
+        s_rbits = 0;
+    uint32_t rb = lf_tokens_window(job, sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, tb, s_rs, s_hist, s_tok);
+    rb = wave_incl_sum(rb);
+    if ((tid & 63) == 63 && rb)
+        atomicAdd(&s_rbits, rb);
+    __syncthreads();
+    LfWork &w = work[slot];
+    for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads) {
+        const uint32_t c = s_hist[i];
+        w.win_hist[blockIdx.x][i] = (uint16_t)c; /* at most 896 + 7 per window */
+        if (c)
+            atomicAdd(&hist_all[(size_t)slot * HYDK_LF_CODES + i], c);
+    }
+    if (tid == 0)
+        w.win_residue_bits[blockIdx.x] = s_rbits;
 }
 
 /* grid = LF groups, block = 64: code lengths + canonical codes of each LF group's histogram */
@@ -679,56 +697,45 @@ __global__ __launch_bounds__(64) void k_lf_codes(const uint32_t *__restrict__ hi
     lf_huffman_wave(hist_all + (size_t)slot * HYDK_LF_CODES, work[slot].codes, streams + slot, s_huff, (int)threadIdx.x);
 }
 
-/* grid = (windows of 1024 values, LF groups) */
-__global__ __launch_bounds__(kLfThreads) void k_lf_count(const HydkLfJob *__restrict__ jobs,
-                                                         const unsigned long long *__restrict__ recs_all,
-                                                         LfWork *__restrict__ work) {
-    const int slot = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const LfShape sh = lf_shape(jobs[slot]);
-    const int tb = (int)blockIdx.x * kPackSpan;
-    if (tb >= sh.n)
-        return;
-    __shared__ uint32_t s_code[HYDK_LF_CODES];
-    __shared__ uint32_t s_wsum[kLfWaves];
-    for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads)
-        s_code[i] = work[slot].codes[i];
-    __syncthreads();
-    unsigned long long val[4];
-    uint32_t len[4];
-    const uint32_t mine = lf_window_strings(sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, tb, s_code, val, len);
-    const uint32_t inc = wave_incl_sum(mine);
-    if (lane == 63)
-        s_wsum[wave] = inc;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t total = 0;
-        for (int w = 0; w < kLfWaves; w++)
-            total += s_wsum[w];
-        work[slot].win_bits[blockIdx.x] = total;
-    }
-}
-
-/* grid = LF groups, block = 256: where each pack window's bits start; the words two windows share are cleared */
+/* grid = LF groups, block = 256: bits of each window = sum over tokens of (count x code length) + its
+ * residue bits; where each window's bits start; the words two windows share are cleared */
 __global__ __launch_bounds__(kLfThreads) void k_lf_offsets(const HydkLfJob *__restrict__ jobs, LfWork *__restrict__ work,
                                                            HydkLfStream *__restrict__ streams, uint32_t *__restrict__ bits_all) {
     const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LfShape sh = lf_shape(jobs[slot]);
-    const int windows = (sh.n + kPackSpan - 1) / kPackSpan; /* <= 192 < 256 */
+    const int windows = (sh.n + kEmitSpan - 1) / kEmitSpan; /* <= 220 < 256 */
+    LfWork &w = work[slot];
+    __shared__ uint32_t s_win[kMaxWindows];
     __shared__ uint32_t s_wsum[kLfWaves];
-    const uint32_t mine = tid < windows ? work[slot].win_bits[tid] : 0u;
+    /* a wave per window: lanes over the 384 tokens (6 each) */
+    uint32_t len6[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+        len6[j] = w.codes[j * 64 + lane] >> 16;
+    for (int win = wave; win < windows; win += kLfWaves) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            bits += (uint32_t)w.win_hist[win][j * 64 + lane] * len6[j];
+        bits = wave_incl_sum(bits);
+        if (lane == 63)
+            s_win[win] = bits + w.win_residue_bits[win];
+    }
+    __syncthreads();
+    const uint32_t mine = tid < windows ? s_win[tid] : 0u;
     const uint32_t inc = wave_incl_sum(mine);
     if (lane == 63)
         s_wsum[wave] = inc;
     __syncthreads();
     uint32_t off = inc - mine, total = 0;
-    for (int w = 0; w < kLfWaves; w++) {
-        if (w < wave)
-            off += s_wsum[w];
-        total += s_wsum[w];
+    for (int k = 0; k < kLfWaves; k++) {
+        if (k < wave)
+            off += s_wsum[k];
+        total += s_wsum[k];
     }
     uint32_t *out = bits_all + (size_t)slot * HYDK_LF_BITWORDS;
     if (tid < windows) {
-        work[slot].win_off[tid] = off;
+        w.win_off[tid] = off;
         /* the window's first word may hold the end of the window before, its last the start of the one
          * after: k_lf_pack ORs into exactly these two */
         if (mine) {
@@ -740,13 +747,13 @@ __global__ __launch_bounds__(kLfThreads) void k_lf_offsets(const HydkLfJob *__re
         streams[slot].bit_count = total;
 }
 
-/* grid = (windows of 1024 values, LF groups) */
+/* grid = (windows of 896 values, LF groups) */
 __global__ __launch_bounds__(kLfThreads) void k_lf_pack(const HydkLfJob *__restrict__ jobs,
                                                         const unsigned long long *__restrict__ recs_all,
                                                         const LfWork *__restrict__ work, uint32_t *__restrict__ bits_all) {
     const int slot = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LfShape sh = lf_shape(jobs[slot]);
-    const int tb = (int)blockIdx.x * kPackSpan;
+    const int tb = (int)blockIdx.x * kEmitSpan;
     if (tb >= sh.n)
         return;
     __shared__ uint32_t s_bits[kPackWords];
@@ -852,12 +859,11 @@ hipError_t launch_lf_coder(const HydkLfJob *d_jobs, unsigned long long *recs, ui
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)num_slots * HYDK_LF_CODES * sizeof(uint32_t), stream);
     if (e != hipSuccess)
         return e;
-    const int token_windows = (HYDK_LF_SYMBOLS + kEmitSpan - 1) / kEmitSpan;
-    hipLaunchKernelGGL(k_lf_tokens, dim3(token_windows, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist);
+    const int token_windows = kMaxWindows;
+    hipLaunchKernelGGL(k_lf_tokens, dim3(token_windows, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist, w);
     hipLaunchKernelGGL(k_lf_codes, dim3(num_slots), dim3(64), 0, stream, hist, streams, w);
-    hipLaunchKernelGGL(k_lf_count, dim3(kMaxPackWindows, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, w);
     hipLaunchKernelGGL(k_lf_offsets, dim3(num_slots), dim3(kLfThreads), 0, stream, d_jobs, w, streams, bits);
-    hipLaunchKernelGGL(k_lf_pack, dim3(kMaxPackWindows, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, w, bits);
+    hipLaunchKernelGGL(k_lf_pack, dim3(token_windows, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, w, bits);
     return hipGetLastError();
 }
 

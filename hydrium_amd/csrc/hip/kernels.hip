@@ -295,6 +295,11 @@ extern "C" __attribute__((visibility("default"))) int hydamd_debug_phase_ticks(u
  * Token order inside a group is block raster, channels Y, X, B (encoder.c:707-745), which the
  * strip order + prefix sum reproduces.  The next strip's pixels are in flight during B and C.
  * ======================================================================================== */
+/* Everything but the transform kernel is a small amount of work on the critical path of a frame that is
+ * already late (its stream holds nothing else): those kernels raise their wavefronts' issue priority so
+ * that, sharing a SIMD with other frames' transform waves, they run as fast as they do alone. */
+#define HYDK_URGENT() __builtin_amdgcn_s_setprio(3)
+
 /* inclusive prefix sums in registers (DPP), no LDS round trips */
 #define HYDK_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xF, false))
 __device__ __forceinline__ uint32_t scan16_inclusive(uint32_t v) { /* within each 16-lane row */
@@ -717,6 +722,7 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
                                                            const uint32_t *alpha_max_all, int nclusters,
                                                            uint32_t alpha_floor, const uint32_t *alpha_floor_dev,
                                                            int first_slot) {
+    HYDK_URGENT();
     const unsigned slot = (unsigned)first_slot + blockIdx.x; /* all arrays are indexed by the frame's slot */
     const uint32_t *hist = hist_all + (size_t)slot * HYDK_MAX_CLUSTERS * HYDK_ALPHABET;
     HydkTables *tab = tabs + slot;
@@ -978,6 +984,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
     __shared__ uint32_t s_win[WAVES][kWinWords];
     __shared__ uint4 s_ops[WAVES][64];                               /* per-symbol operands of the chunk being walked */
 
+    HYDK_URGENT();
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int slot = blockIdx.x / kBlocksPerLfg;
     const int first_group = (blockIdx.x % kBlocksPerLfg) * WAVES;
@@ -1155,6 +1162,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
                                                    int preset_bits, const uint32_t *status) {
     __shared__ uint16_t s_inv[kInvEntries / 2];                       /* plain inverse slot table, 72 KiB */
     __shared__ uint4 s_ops[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];        /* 18 KiB */
+    HYDK_URGENT();
     const int lane = threadIdx.x;
     const int slot = blockIdx.x;
     const int ngroups = jobs[slot].gcols * jobs[slot].grows;
@@ -1285,6 +1293,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
                                                         const uint64_t *offsets_all, uint8_t *payload, int preset_bits,
                                                         const uint32_t *status) {
     __shared__ uint32_t s_win[4][kEmitWin];
+    HYDK_URGENT();
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int slot = blockIdx.x >> 4;
     const int g = ((blockIdx.x & 15) << 2) + wave;
@@ -1415,6 +1424,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_sections(const uint32_t *grou
                                                             uint64_t *total, uint8_t *payload, uint64_t payload_cap,
                                                             int clear_shared_words, uint32_t *status) {
     __shared__ uint64_t s_wave[4];
+    HYDK_URGENT();
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (count + kThreads - 1) / kThreads;
     const int lo = min(count, t * per), hi = min(count, lo + per);

@@ -661,6 +661,7 @@ __device__ __forceinline__ uint32_t lf_window_strings(const LfShape &sh, const u
 __global__ __launch_bounds__(kLfThreads) void k_lf_tokens(const HydkLfJob *__restrict__ jobs,
                                                           unsigned long long *__restrict__ recs_all,
                                                           uint32_t *__restrict__ hist_all, LfWork *__restrict__ work) {
+    __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
     const int slot = blockIdx.y, tid = threadIdx.x;
     const HydkLfJob &job = jobs[slot];
     const LfShape sh = lf_shape(job);
@@ -692,6 +693,7 @@ __global__ __launch_bounds__(kLfThreads) void k_lf_tokens(const HydkLfJob *__res
 /* grid = LF groups, block = 64: code lengths + canonical codes of each LF group's histogram */
 __global__ __launch_bounds__(64) void k_lf_codes(const uint32_t *__restrict__ hist_all, HydkLfStream *__restrict__ streams,
                                                  LfWork *__restrict__ work) {
+    __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
     __shared__ LfHuffScratch s_huff;
     const int slot = blockIdx.x;
     lf_huffman_wave(hist_all + (size_t)slot * HYDK_LF_CODES, work[slot].codes, streams + slot, s_huff, (int)threadIdx.x);
@@ -701,6 +703,7 @@ __global__ __launch_bounds__(64) void k_lf_codes(const uint32_t *__restrict__ hi
  * residue bits; where each window's bits start; the words two windows share are cleared */
 __global__ __launch_bounds__(kLfThreads) void k_lf_offsets(const HydkLfJob *__restrict__ jobs, LfWork *__restrict__ work,
                                                            HydkLfStream *__restrict__ streams, uint32_t *__restrict__ bits_all) {
+    __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
     const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LfShape sh = lf_shape(jobs[slot]);
     const int windows = (sh.n + kEmitSpan - 1) / kEmitSpan; /* <= 220 < 256 */
@@ -751,6 +754,7 @@ __global__ __launch_bounds__(kLfThreads) void k_lf_offsets(const HydkLfJob *__re
 __global__ __launch_bounds__(kLfThreads) void k_lf_pack(const HydkLfJob *__restrict__ jobs,
                                                         const unsigned long long *__restrict__ recs_all,
                                                         const LfWork *__restrict__ work, uint32_t *__restrict__ bits_all) {
+    __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
     const int slot = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LfShape sh = lf_shape(jobs[slot]);
     const int tb = (int)blockIdx.x * kEmitSpan;

@@ -435,13 +435,13 @@ static void drain(HYDEncoder *e) {
 /* ---------------------------------------------------------------------------------------------
  * device context reuse
  *
- * Creating a context allocates its worst-case buffers (245 MB per LF-group slot) and pinned
- * staging, and destroying it gives them back: about 10 ms per image together, a third of what
- * hyd_send_tile costs for an 8192 x 8192 frame.  Idle contexts are therefore parked when their
- * encoder is destroyed and handed to the next encoder that needs the same shape (a few of them, so
- * that several threads encoding images back to back each find one).  Contexts that saw a device
- * error, or that are larger than 64 slots (15.7 GB), are not parked; HYDAMD_CONTEXT_CACHE=0 turns
- * the parking off.
+ * Creating a context allocates its buffers (about 50 MB per LF-group slot, more once a frame has
+ * outgrown them) and pinned staging, and destroying it gives them back: several milliseconds per
+ * image together.  Idle contexts are therefore parked when their encoder is destroyed and handed to
+ * the next encoder that needs the same shape (a few of them, so that several threads encoding images
+ * back to back each find one).  Contexts that saw a device error are not parked, nor is one that would
+ * take the parked total over HYDAMD_CONTEXT_CACHE_MB (default 8192 MB of device memory, counted at 50 MB
+ * per slot + staging); HYDAMD_CONTEXT_CACHE=0 turns the parking off and hydamd_trim_cache() empties it.
  * ------------------------------------------------------------------------------------------- */
 #define CTX_POOL_MAX 8
 typedef struct ParkedCtx {
@@ -507,9 +507,33 @@ static HydAmdContext *ctx_acquire(size_t slots, int linear, int *status) {
     return hydamd_create(api_device(), (int)slots, linear, 0, status);
 }
 
+/* what a parked context of `slots` LF-group slots holds, in MB: its frame arrays at their default sizes,
+ * the LF coder's, one staging tile per slot for 16-bit samples (hydamd_token_capacity tells whether it grew) */
+static size_t ctx_megabytes(HydAmdContext *c, size_t slots) {
+    const size_t per_slot = hydamd_token_capacity(c) > 98304 ? 200 : 75;
+    return slots * per_slot + 64;
+}
+
+static size_t ctx_pool_megabytes(void) {
+    static long mb = -1;
+    if (mb < 0) {
+        const char *v = getenv("HYDAMD_CONTEXT_CACHE_MB");
+        mb = v && *v ? atol(v) : 8192;
+        if (mb < 0)
+            mb = 0;
+    }
+    return (size_t)mb;
+}
+
 static void ctx_release(HydAmdContext *c, size_t slots, int linear, int healthy) {
     const int cap = ctx_pool_size();
-    if (healthy && cap > 0 && slots <= 64 && hydamd_sync(c) == HYD_OK) {
+    size_t parked_mb = 0;
+    pthread_mutex_lock(&g_ctx_lock);
+    for (int i = 0; i < CTX_POOL_MAX; i++)
+        if (g_pool[i].ctx)
+            parked_mb += ctx_megabytes(g_pool[i].ctx, g_pool[i].slots);
+    pthread_mutex_unlock(&g_ctx_lock);
+    if (healthy && cap > 0 && parked_mb + ctx_megabytes(c, slots) <= ctx_pool_megabytes() && hydamd_sync(c) == HYD_OK) {
         pthread_mutex_lock(&g_ctx_lock);
         int where = -1;
         for (int i = 0; i < cap && where < 0; i++)
@@ -1176,6 +1200,22 @@ HYDRIUM_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write
 }
 
 HYDRIUM_EXPORT void hydamd_free(void *p) { free(p); }
+
+/* Release every device context parked by destroyed encoders (their device memory, pinned staging and
+ * streams).  Encoders alive at the time keep theirs. */
+HYDRIUM_EXPORT void hydamd_trim_cache(void) {
+    HydAmdContext *victims[CTX_POOL_MAX];
+    int n = 0;
+    pthread_mutex_lock(&g_ctx_lock);
+    for (int i = 0; i < CTX_POOL_MAX; i++)
+        if (g_pool[i].ctx) {
+            victims[n++] = g_pool[i].ctx;
+            g_pool[i].ctx = NULL;
+        }
+    pthread_mutex_unlock(&g_ctx_lock);
+    for (int i = 0; i < n; i++)
+        hydamd_destroy(victims[i]);
+}
 
 /* the CPU-only tests drive the same function through libhydrium_hosttest.so */
 #ifdef HYD_TEST_HOOKS

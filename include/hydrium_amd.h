@@ -277,6 +277,11 @@ HYDAMD_EXPORT int hydamd_frame_from_streams(const HYDImageMetadata *md, int writ
                                             size_t icc_size, uint8_t **out, size_t *out_len, const char **err);
 HYDAMD_EXPORT void hydamd_free(void *p);
 
+/* hyd_encoder_destroy parks its device context (device memory, pinned staging, streams) for the next
+ * encoder of the same shape instead of freeing it — up to HYDAMD_CONTEXT_CACHE contexts (default 4) and
+ * HYDAMD_CONTEXT_CACHE_MB megabytes (default 8192) per process.  This releases whatever is parked. */
+HYDAMD_EXPORT void hydamd_trim_cache(void);
+
 /* ---- optional per-kernel timing with HIP events on the context's stream ---- */
 HYDAMD_EXPORT int hydamd_profile(HydAmdContext *ctx, int enable);
 /* accumulated milliseconds and launch counts per kernel class since the last call; resets the counters */

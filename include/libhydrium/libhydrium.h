@@ -78,7 +78,10 @@ typedef struct HYDEncoder HYDEncoder;
 /* New encoder, or NULL when out of memory.  No GPU work happens until the first tile. */
 HYDRIUM_EXPORT HYDEncoder *hyd_encoder_new(void);
 
-/* Releases every host and device resource of the encoder; NULL is accepted. */
+/* Destroys the encoder; NULL is accepted.  Host memory is released at once.  The encoder's GPU context
+ * (device buffers, pinned staging, streams) is kept parked for the next encoder of the same image shape in
+ * this process — bounded in number and in megabytes, see hydamd_trim_cache() in hydrium_amd.h, which
+ * releases what is parked. */
 HYDRIUM_EXPORT HYDStatusCode hyd_encoder_destroy(HYDEncoder *encoder);
 
 /* Must precede the first tile. */

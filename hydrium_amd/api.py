@@ -189,7 +189,7 @@ def tile_dims(width: int, height: int, shift_x: int, shift_y: int):
 
 def encode_image(lib: Library, img: np.ndarray, *, linear_light: int = 0, shift_x: int = -1, shift_y: int = -1,
                  out_buf_size: int = 1 << 20, layout: str = "packed", order=None, icc: Optional[bytes] = None,
-                 explicit_last: bool = False) -> bytes:
+                 explicit_last: bool = False, out_buf=None) -> bytes:
     """Encode a whole (H, W, 3) image the way the reference CLI does; returns the codestream."""
     h, w, _ = img.shape
     src = img[::-1].copy() if layout == "flipped" else img
@@ -201,7 +201,7 @@ def encode_image(lib: Library, img: np.ndarray, *, linear_light: int = 0, shift_
         enc.check(enc.set_metadata(w, h, linear_light, shift_x, shift_y))
         if icc is not None:
             enc.check(enc.set_icc(icc))
-        buf = (C.c_uint8 * out_buf_size)()
+        buf = out_buf if out_buf is not None else (C.c_uint8 * out_buf_size)()  # a caller encoding many images keeps one buffer
         enc.check(enc.provide_output(buf))
         for i, (tx, ty) in enumerate(tiles):
             is_last = -1

@@ -32,6 +32,9 @@
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef HYDK_K1_WAVES
+#define HYDK_K1_WAVES 4 /* waves per SIMD the transform kernel is compiled for (register budget 512 / this) */
+#endif
 constexpr int kS0Block = 72;            /* floats per block in the row-pass buffer: 64 + 8 pad -> conflict-free column reads */
 constexpr int kS0Chan = 32 * kS0Block;  /* floats per channel */
 constexpr int kDbgPitch = 2048;
@@ -64,6 +67,27 @@ __device__ const uint8_t kZigzag[8][8] = {
     /* kv = 6 */ {27, 29, 41, 44, 52, 55, 59, 62},
     /* kv = 7 */ {28, 42, 43, 53, 54, 60, 61, 63},
 };
+
+/* [kh][kv nibble][4 non-zero flags] -> OR of the zig-zag bits of coefficients (4 * nibble + b, kh), b in the flags:
+ * turns a thread's eight "non-zero" flags into its share of the block's zig-zag bitmap with two loads */
+struct NibbleMasks {
+    unsigned long long m[8][2][16];
+    constexpr NibbleMasks() : m() {
+        constexpr uint8_t zz[8][8] = {{0, 2, 3, 9, 10, 20, 21, 35},   {1, 4, 8, 11, 19, 22, 34, 36},  {5, 7, 12, 18, 23, 33, 37, 48},
+                                      {6, 13, 17, 24, 32, 38, 47, 49}, {14, 16, 25, 31, 39, 46, 50, 57}, {15, 26, 30, 40, 45, 51, 56, 58},
+                                      {27, 29, 41, 44, 52, 55, 59, 62}, {28, 42, 43, 53, 54, 60, 61, 63}};
+        for (int kh = 0; kh < 8; kh++)
+            for (int half = 0; half < 2; half++)
+                for (int pat = 0; pat < 16; pat++) {
+                    unsigned long long v = 0;
+                    for (int b = 0; b < 4; b++)
+                        if (pat >> b & 1)
+                            v |= 1ull << zz[4 * half + b][kh];
+                    m[kh][half][pat] = v;
+                }
+    }
+};
+__device__ const NibbleMasks kNibbleMasks = NibbleMasks();
 
 /* HF quantisation weights, channel X / Y / B, zig-zag order (encoder.c:74-93) */
 __device__ const int16_t kQuantWeight[3][64] = {
@@ -340,7 +364,7 @@ __device__ __forceinline__ void store_record(void *tok, uint32_t at, uint32_t to
 }
 
 template <int FMT, int XMODE>
-__global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
+__global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
     typedef typename SampleOf<FMT>::type sample_t;
     constexpr bool LUTS = XMODE == kXybGather;
     constexpr int kWords = FMT == HYDK_FMT_U8 ? 6 : 12; /* dwords holding 8 packed RGB pixels */
@@ -373,7 +397,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
     __shared__ uint8_t s_nnz3[64];                    /* coefficient-count context offset (encoder.c:60-66) mod 3 */
     __shared__ uint8_t s_jinfo[64][2];                /* zig-zag position j -> {natural index kv*8+kh, frequency context (encoder.c:53-58) mod 3} */
     __shared__ unsigned long long s_below[64];        /* bits 0..j-1 */
-    __shared__ unsigned long long s_nibmask[8][2][16]; /* [kh][kv nibble][4 non-zero flags] -> their zig-zag bits */
     __shared__ __attribute__((aligned(16))) float s_wq[3 * 64]; /* quantisation weight [channel][kh][kv]: a thread's eight in two 16-byte reads */
 
     const int t = threadIdx.x;
@@ -399,15 +422,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
     }
     if (t < 192) /* t = (c, kh, kv) */
         s_wq[t] = (float)kQuantWeight[t >> 6][kZigzag[t & 7][(t >> 3) & 7]];
-    {
-        /* thread = (kh, half, pattern): OR of the zig-zag bits of coefficients (4*half + b, kh), b in pattern */
-        const int kh_ = t >> 5, half = (t >> 4) & 1, pat = t & 15;
-        unsigned long long m = 0;
-        for (int b = 0; b < 4; b++)
-            if (pat >> b & 1)
-                m |= 1ull << kZigzag[4 * half + b][kh_];
-        s_nibmask[kh_][half][pat] = m;
-    }
 
     /* column / token phases: thread (block cb, horizontal frequency kh) */
     const int cb = t >> 3, kh = t & 7;
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_transform_tokenize(const HydkLf
                     for (int kv = 0; kv < 8; kv++)
                         d[kv] = q[kv];
                 }
-                const unsigned long long mine = s_nibmask[kh][0][pat & 15u] | s_nibmask[kh][1][pat >> 4];
+                const unsigned long long mine = kNibbleMasks.m[kh][0][pat & 15u] | kNibbleMasks.m[kh][1][pat >> 4];
                 const uint32_t lo = or_reduce8((uint32_t)mine), hi = or_reduce8((uint32_t)(mine >> 32));
                 msk[c] = ((unsigned long long)hi << 32) | lo;
                 if (kh == 0) /* LF int: trunc(dc * shift[c]) (encoder.c:573,582) */

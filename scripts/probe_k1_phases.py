@@ -19,23 +19,24 @@ PHASES = ["A1 pixels -> XYB (LUT evaluation, LMS mix)", "A2 row DCT + LDS store"
           "barrier 2", "C1 prefix sum (+ barrier 3)", "C2 token emission", "prologue / epilogue"]
 
 
-def build():
+def build(define="-DHYDK_PHASE_TIMERS", lib=None):
     from hydrium_amd import build as hb
 
+    lib = lib or LIB
     os.makedirs(OUT, exist_ok=True)
     objs = []
     for src in sorted(os.listdir(os.path.join(hb.CSRC, "hip"))):
         if src.endswith(".hip"):
             o = os.path.join(OUT, src + ".o")
-            hb._run([hb.HIPCC] + hb.HIP_FLAGS + ["-DHYDK_PHASE_TIMERS", "-c", os.path.join(hb.CSRC, "hip", src), "-o", o])
+            hb._run([hb.HIPCC] + hb.HIP_FLAGS + [define, "-c", os.path.join(hb.CSRC, "hip", src), "-o", o])
             objs.append(o)
     for src in sorted(os.listdir(os.path.join(hb.CSRC, "host"))):
         if src.endswith(".c"):
             o = os.path.join(OUT, src + ".o")
             hb._run([hb.CC] + hb.C_FLAGS + ["-c", os.path.join(hb.CSRC, "host", src), "-o", o])
             objs.append(o)
-    hb._run([hb.HIPCC, f"--offload-arch={hb.ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"])
-    print(LIB)
+    hb._run([hb.HIPCC, f"--offload-arch={hb.ARCH}", "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread"])
+    print(lib)
 
 
 def run():
@@ -62,5 +63,8 @@ def run():
 if __name__ == "__main__":
     if "--build" in sys.argv:
         build()
+    if "--build-variant" in sys.argv:  # --build-variant -DNAME=VALUE out.so : any other compile-time variant of the library
+        i = sys.argv.index("--build-variant")
+        build(sys.argv[i + 1], os.path.join(OUT, sys.argv[i + 2]))
     if "--run" in sys.argv:
         run()

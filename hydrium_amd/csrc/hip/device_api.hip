@@ -51,7 +51,12 @@ hipError_t launch_rans(const HydkLfJob *d_jobs, const uint32_t *sym_count, const
                        hipStream_t stream);
 hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint16_t *aux,
                              uint16_t *flags, uint32_t aux_pitch, uint32_t *final_state, uint32_t *group_bits, int preset_bits,
-                             int nclusters, int num_slots, const uint32_t *status, hipStream_t stream);
+                             int nclusters, int num_slots, const uint32_t *status, const uint32_t *lf_hist,
+                             HydkLfStream *lf_streams, void *lf_work, hipStream_t stream);
+hipError_t launch_lf_front(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, void *work, int num_slots,
+                           hipStream_t stream);
+hipError_t launch_lf_back(const HydkLfJob *d_jobs, const unsigned long long *recs, HydkLfStream *streams, uint32_t *bits,
+                          void *work, int num_slots, hipStream_t stream);
 hipError_t launch_rans_emit(const HydkLfJob *d_jobs, const uint32_t *sym_count, const uint16_t *aux, const uint16_t *flags,
                             uint32_t aux_pitch, const uint32_t *final_state, const uint32_t *group_bits, const uint64_t *offsets,
                             uint8_t *payload, int preset_bits, int num_slots, const uint32_t *status, hipStream_t stream);
@@ -1149,8 +1154,9 @@ int hydamd_export_frame(HydAmdContext *ctx, int num_slots, void *device_dst, siz
     return ST_OK;
 }
 
-/* K2 + the rANS chains for slots [first, first + count) */
-static int entropy_range(HydAmdContext *ctx, int first, int count) {
+/* K2 + the rANS chains for slots [first, first + count); with_lf_codes: the lane-form launch also builds the
+ * LF coder's prefix codes of the same slots (their token kernel must be enqueued already) */
+static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_codes) {
     const size_t G = HYDK_GROUPS_PER_LFG, g0 = (size_t)first * G;
     {
         ScopedTimer timer(ctx, HYDAMD_K_TABLES);
@@ -1164,11 +1170,16 @@ static int entropy_range(HydAmdContext *ctx, int first, int count) {
         for (int i = first; i < first + count; i++)
             any_float = any_float || ctx->h_jobs[i].fmt == HYDK_FMT_F32;
         const bool lanes = ctx->rans_lanes && !any_float;
+        if (with_lf_codes && !lanes)
+            return fail(ctx, ST_INTERNAL_ERROR, "LF code construction can only ride with the lane-form entropy stage");
         if (lanes) {
             HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, ctx->sym_count + g0, ctx->tables + first,
                                                  ctx->rans_aux + g0 * ctx->tok_cap, ctx->rans_flags + g0 * (ctx->tok_cap / 16),
                                                  ctx->tok_cap, ctx->rans_final + g0, ctx->group_bits + g0, ctx->preset_bits,
-                                                 ctx->nclusters, count, ctx->status, ctx->stream));
+                                                 ctx->nclusters, count, ctx->status,
+                                                 with_lf_codes ? ctx->lf_hist + (size_t)first * HYDK_LF_CODES : nullptr,
+                                                 ctx->lf_streams + first, ctx->lf_work + (size_t)first * hydk::lf_work_bytes(),
+                                                 ctx->stream));
         } else {
             const int st = ensure_bitbuf(ctx);
             if (st != ST_OK)
@@ -1194,8 +1205,25 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
     const int count = num_slots * HYDK_GROUPS_PER_LFG;
     ctx->results_valid = false;
     ctx->want_entropy = num_slots;
+    /* In-stream LF coder + lane-form entropy stage: the LF coder's 200 us of serial code construction per LF
+     * group rides in the chain kernel's launch instead of sitting in the stream on its own — tokens before
+     * the entropy stage, offsets + pack behind it. */
+    int lf_first = -1, lf_count = 0;
+    if (num_slots > ctx->coded && ctx->lf_on_device == 2 && ctx->rans_lanes && ctx->lf_coded == ctx->coded && !ctx->lf_pending) {
+        bool any_float = false;
+        for (int i = ctx->coded; i < num_slots; i++)
+            any_float = any_float || ctx->h_jobs[i].fmt == HYDK_FMT_F32;
+        if (!any_float) {
+            lf_first = ctx->coded;
+            lf_count = num_slots - ctx->coded;
+            ScopedTimer timer(ctx, HYDAMD_K_LF);
+            HIP_TRY(ctx, hydk::launch_lf_front(ctx->d_jobs + lf_first, ctx->lf_recs + (size_t)lf_first * HYDK_LF_SYMBOLS,
+                                               ctx->lf_hist + (size_t)lf_first * HYDK_LF_CODES,
+                                               ctx->lf_work + (size_t)lf_first * hydk::lf_work_bytes(), lf_count, ctx->stream));
+        }
+    }
     if (num_slots > ctx->coded) {
-        const int st = entropy_range(ctx, ctx->coded, num_slots - ctx->coded);
+        const int st = entropy_range(ctx, ctx->coded, num_slots - ctx->coded, lf_count > 0);
         if (st != ST_OK)
             return st;
         ctx->coded = num_slots;
@@ -1223,6 +1251,14 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
                                                n * HYDK_GROUPS_PER_LFG, ctx->status, ctx->stream));
             first = last + 1;
         }
+    }
+    if (lf_count > 0) {
+        ScopedTimer timer(ctx, HYDAMD_K_LF);
+        HIP_TRY(ctx, hydk::launch_lf_back(ctx->d_jobs + lf_first, ctx->lf_recs + (size_t)lf_first * HYDK_LF_SYMBOLS,
+                                          ctx->lf_streams + lf_first, ctx->lf_bits + (size_t)lf_first * HYDK_LF_BITWORDS,
+                                          ctx->lf_work + (size_t)lf_first * hydk::lf_work_bytes(), lf_count, ctx->stream));
+        ctx->lf_coded = num_slots;
+        ctx->lf_need_gather = true;
     }
     {
         const int st = join_lf(ctx, num_slots);

@@ -1162,6 +1162,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
  * Integer sample formats only (4-byte records); float frames use k_rans_encode.
  * grid = LF groups, block = 64.
  * ======================================================================================== */
+#include "lf_huffman.h" /* the LF coder's code construction rides in this kernel's launch, see below */
+
 struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs besides the state */
     uint32_t thr;   /* (f << 20) - 1: renormalise when state > thr (entropy.c:1092) */
     uint32_t magic; /* floor(2^32 / f) */
@@ -1173,11 +1175,20 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
                                                    const HydkTables *tabs, uint16_t *aux_all, uint16_t *flags_all,
                                                    uint32_t aux_pitch /* symbols per group in aux / flags */,
                                                    uint32_t *final_state_all, uint32_t *group_bits_all, int nclusters,
-                                                   int preset_bits, const uint32_t *status) {
+                                                   int preset_bits, const uint32_t *status, int num_slots,
+                                                   const uint32_t *lf_hist, HydkLfStream *lf_streams, void *lf_work) {
     __shared__ uint16_t s_inv[kInvEntries / 2];                       /* plain inverse slot table, 72 KiB */
     __shared__ uint4 s_ops[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];        /* 18 KiB */
     HYDK_URGENT();
     const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= num_slots) {
+        /* passengers: workgroup num_slots + s builds the prefix code of LF group s's coefficient stream
+         * (lf_coder.hip; 200 us of serial work on one wavefront, like the chains and independent of them) */
+        __shared__ LfHuffScratch s_huff;
+        const int s = (int)blockIdx.x - num_slots;
+        lf_huffman_wave(lf_hist + (size_t)s * HYDK_LF_CODES, ((LfWork *)lf_work)[s].codes, lf_streams + s, s_huff, lane);
+        return;
+    }
     const int slot = blockIdx.x;
     const int ngroups = jobs[slot].gcols * jobs[slot].grows;
     const HydkTables *tab = tabs + slot;
@@ -1648,11 +1659,14 @@ hipError_t launch_rans(const HydkLfJob *d_jobs, const uint32_t *sym_count, const
     return hipGetLastError();
 }
 
+/* lf_hist != NULL: the launch also builds the LF coder's prefix codes of the same LF groups (num_slots more workgroups) */
 hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint16_t *aux,
                              uint16_t *flags, uint32_t aux_pitch, uint32_t *final_state, uint32_t *group_bits, int preset_bits,
-                             int nclusters, int num_slots, const uint32_t *status, hipStream_t stream) {
-    hipLaunchKernelGGL(k_rans_lanes, dim3(num_slots), dim3(64), 0, stream, d_jobs, sym_count, tabs, aux, flags, aux_pitch,
-                       final_state, group_bits, nclusters, preset_bits, status);
+                             int nclusters, int num_slots, const uint32_t *status, const uint32_t *lf_hist,
+                             HydkLfStream *lf_streams, void *lf_work, hipStream_t stream) {
+    hipLaunchKernelGGL(k_rans_lanes, dim3(lf_hist ? 2 * num_slots : num_slots), dim3(64), 0, stream, d_jobs, sym_count, tabs,
+                       aux, flags, aux_pitch, final_state, group_bits, nclusters, preset_bits, status, num_slots, lf_hist,
+                       lf_streams, lf_work);
     return hipGetLastError();
 }
 

@@ -1305,12 +1305,13 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
 /* one wave per group: records + the chain's refill words -> bits, written straight to the section's
  * place in the frame's payload (k_scan_sections has turned the chain's bit counts into byte offsets
  * and cleared the two words a section may share with its neighbours).  The section is filled from
- * its END in batches of 256 symbols aligned to the start of the token array (four consecutive symbols
- * per lane: one aligned 16-byte record load, one 8-byte load of refill words); inside a batch the
+ * its END in batches of 512 symbols aligned to the start of the token array (eight consecutive symbols
+ * per lane: two aligned 16-byte record loads, one 16-byte load of refill words); inside a batch the
  * stream order [refill_p][residue_p][refill_p+1].. is plain ascending (lane, symbol) order.
  * grid = 16 x LF groups, block = 256. */
-constexpr int kEmitBatch = 256;
-constexpr int kEmitWin = kEmitBatch + 4; /* 256 symbols x at most 32 bits = 256 words + alignment slack */
+constexpr int kEmitPer = 8;                  /* symbols per lane and batch */
+constexpr int kEmitBatch = 64 * kEmitPer;    /* 512 */
+constexpr int kEmitWin = kEmitBatch + 4;     /* 512 symbols x at most 32 bits = 512 words + alignment slack */
 
 __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
                                                         const uint16_t *aux_all, const uint16_t *flags_all, uint32_t aux_pitch,
@@ -1327,7 +1328,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
     if (g >= ngroups || (*status & HYDK_STATUS_OVERFLOW))
         return;
     const uint4 *tok = (const uint4 *)((const char *)jobs[slot].tokens + (size_t)g * jobs[slot].tok_cap * jobs[slot].rec_bytes);
-    const uint2 *aux = (const uint2 *)(aux_all + G * aux_pitch);
+    const uint4 *aux = (const uint4 *)(aux_all + G * aux_pitch);
     const uint16_t *flags = flags_all + G * (aux_pitch / 16);
     uint32_t *W = (uint32_t *)payload; /* 256-byte aligned allocation */
     uint32_t *win = s_win[wave];
@@ -1349,9 +1350,12 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
         else
             W[d] = v;
     };
-    /* four (value, bit count) per lane, in stream order by (lane, index); written in front of what is there */
-    auto emit = [&](const uint32_t (&val)[4], const uint32_t (&nb)[4]) {
-        const uint32_t mine = nb[0] + nb[1] + nb[2] + nb[3];
+    /* eight (value, bit count) per lane, in stream order by (lane, index); written in front of what is there */
+    auto emit = [&](const uint32_t (&val)[kEmitPer], const uint32_t (&nb)[kEmitPer]) {
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < kEmitPer; j++)
+            mine += nb[j];
         const uint32_t inc = scan64_inclusive(mine);
         const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
         if (!total)
@@ -1369,7 +1373,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
         __builtin_amdgcn_wave_barrier();
         uint32_t pos = newcur + (inc - mine) - wlo * 32u; /* window-relative position of the lane's first value */
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < kEmitPer; j++) {
             if (nb[j]) {
                 const uint32_t w = pos >> 5, sh = pos & 31u;
                 const unsigned long long lo = (unsigned long long)val[j] << sh;
@@ -1390,28 +1394,30 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
     };
 
     /* the next batch's records, refill words and flags travel while this one is being written */
-    uint4 rec_n = {0, 0, 0, 0};
-    uint2 a_n = {0, 0};
+    uint4 rec_n[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    uint4 a_n = {0, 0, 0, 0};
     uint32_t fl_n = 0;
     auto fetch = [&](int batch) {
-        const int p0 = batch * kEmitBatch + 4 * lane;
-        if (batch >= 0 && p0 < n) { /* the arrays are padded to a multiple of 16 symbols: whole quads are readable */
-            rec_n = tok[p0 >> 2];
-            a_n = aux[p0 >> 2];
+        const int p0 = batch * kEmitBatch + kEmitPer * lane;
+        if (batch >= 0 && p0 < n) { /* the arrays are padded to a multiple of 16 symbols: whole octets are readable */
+            rec_n[0] = tok[p0 >> 2];
+            rec_n[1] = tok[(p0 >> 2) + 1];
+            a_n = aux[p0 >> 3];
             fl_n = flags[p0 >> 4];
         }
     };
     const int batches = (n + kEmitBatch - 1) / kEmitBatch;
     fetch(batches - 1);
     for (int b = batches - 1; b >= 0; b--) {
-        const int p0 = b * kEmitBatch + 4 * lane;
-        const uint32_t recs[4] = {rec_n.x, rec_n.y, rec_n.z, rec_n.w};
-        const uint32_t aw[4] = {a_n.x & 0xFFFFu, a_n.x >> 16, a_n.y & 0xFFFFu, a_n.y >> 16};
+        const int p0 = b * kEmitBatch + kEmitPer * lane;
+        const uint32_t recs[kEmitPer] = {rec_n[0].x, rec_n[0].y, rec_n[0].z, rec_n[0].w, rec_n[1].x, rec_n[1].y, rec_n[1].z, rec_n[1].w};
+        const uint32_t aw[kEmitPer] = {a_n.x & 0xFFFFu, a_n.x >> 16, a_n.y & 0xFFFFu, a_n.y >> 16,
+                                       a_n.z & 0xFFFFu, a_n.z >> 16, a_n.w & 0xFFFFu, a_n.w >> 16};
         const uint32_t flq = fl_n >> (p0 & 15);
         fetch(b - 1);
-        uint32_t val[4], nb[4];
+        uint32_t val[kEmitPer], nb[kEmitPer];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < kEmitPer; j++) {
             const bool valid = p0 + j < n;
             const bool refill = valid && ((flq >> j) & 1u);
             const uint32_t rbits = (recs[j] >> 11) & 0x1Fu, residue = recs[j] >> 16;
@@ -1423,7 +1429,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
     }
     {
         /* [preset id][final state, low half first] precede everything (encoder.c:945, entropy.c:1127-1130) */
-        uint32_t val[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0};
+        uint32_t val[kEmitPer] = {0, 0, 0, 0, 0, 0, 0, 0}, nb[kEmitPer] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (lane == 0) {
             val[0] = jobs[slot].preset;
             nb[0] = (uint32_t)preset_bits;

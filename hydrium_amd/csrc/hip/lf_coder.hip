@@ -56,6 +56,7 @@ constexpr int kPlane = HYDK_DC_PITCH * HYDK_DC_PITCH;
 
 struct LfShape {
     int vbw, blocks, n;
+    uint32_t vbw_magic; /* ceil(2^32 / vbw): rem / vbw = mulhi(rem, magic) for rem < 2^16 (vbw = 1: handled apart) */
 };
 
 __device__ __forceinline__ LfShape lf_shape(const HydkLfJob &job) {
@@ -63,7 +64,14 @@ __device__ __forceinline__ LfShape lf_shape(const HydkLfJob &job) {
     sh.vbw = (job.width + 7) >> 3;
     sh.blocks = sh.vbw * ((job.height + 7) >> 3);
     sh.n = 3 * sh.blocks;
+    sh.vbw_magic = sh.vbw > 1 ? (uint32_t)(0xFFFFFFFFu / (uint32_t)sh.vbw) + 1u : 0u;
     return sh;
+}
+
+/* rem / vbw for 0 <= rem < 65536 without the 30-instruction integer division: the multiply-high by
+ * ceil(2^32 / vbw) overshoots rem / vbw by less than 2^-16, never across an integer (vbw <= 256) */
+__device__ __forceinline__ int lf_row_of(const LfShape &sh, int rem) {
+    return sh.vbw > 1 ? (int)__umulhi((uint32_t)rem, sh.vbw_magic) : rem;
 }
 
 /* hybrid-uint config (split 7, msb 1, lsb 1), entropy.c:427-444 */
@@ -148,7 +156,7 @@ __device__ __forceinline__ uint32_t lf_residual_at(const int32_t *dc, int c, int
 __device__ __forceinline__ uint32_t lf_value_at(const int32_t *dc, const LfShape &sh, int i) {
     const int visit = (i >= sh.blocks) + (i >= 2 * sh.blocks);
     const int rem = i - visit * sh.blocks;
-    const int y = rem / sh.vbw, x = rem - y * sh.vbw;
+    const int y = lf_row_of(sh, rem), x = rem - y * sh.vbw;
     return lf_residual_at(dc, visit < 2 ? 1 - visit : 2, y, x);
 }
 
@@ -162,7 +170,7 @@ __device__ __forceinline__ void lf_fetch(const int32_t *dc, const LfShape &sh, i
         return;
     int visit = (i0 >= sh.blocks) + (i0 >= 2 * sh.blocks);
     const int rem = i0 - visit * sh.blocks;
-    int y = rem / sh.vbw, x = rem - y * sh.vbw;
+    int y = lf_row_of(sh, rem), x = rem - y * sh.vbw;
     if (x + 3 < sh.vbw) { /* same row, hence same channel and inside the stream */
         const int c = visit < 2 ? 1 - visit : 2; /* Y, X, B */
         const int32_t *row = dc + c * kPlane + y * HYDK_DC_PITCH + x;

@@ -232,3 +232,51 @@ def test_level10_container_prologue(ref_lib, image, width, height, tiles):
         r, mx = orc.encode_lf_group(img, num_presets=1, preset=0)
         got += glue.frame_from_stages(md, k == 0, k == len(tiles) - 1, [(tx, ty)], [r], mx)
     assert got == want
+
+
+def test_frame_from_blobs_single_process_and_malformed_input(ref_lib, image):
+    """hydamd_frame_from_blobs on the host: two shards' blobs (built from oracle results in the layout
+    hydamd_export_frame writes) give the reference file; damaged, incomplete or repeated blobs give an
+    error, not a crash."""
+    import ctypes as C
+
+    import torch
+
+    import oracle_engine
+    from hydrium_amd import device
+
+    img = image("photo", 2048 + 300, 72, 8)
+    if glue._d is None:
+        glue._d = glue._lib()
+    d = glue._d
+    d.hydamd_frame_from_blobs.restype = C.c_int
+    d.hydamd_frame_from_blobs.argtypes = [C.POINTER(api.HYDImageMetadata), C.c_int, C.c_int, C.c_size_t,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)]
+    blobs, floor = [], 0
+    for lf in (0, 1):
+        e = oracle_engine.OracleShardEngine(img, [lf])
+        e.enqueue_transform()
+        e.enqueue_entropy(torch.tensor([floor], dtype=torch.int32))
+        out = torch.zeros(e.blob_bound(), dtype=torch.uint8)
+        e.export_blob(out)
+        n = int(device.blob_header(out[:64].numpy().tobytes())["total_bytes"])
+        blobs.append(out[:n].numpy().tobytes())
+        floor = max(floor, e.results[-1][2])
+    md = api.HYDImageMetadata(img.shape[1], img.shape[0], 0, -1, -1)
+    assert device.frame_from_blobs(md, blobs, lib=d) == api.encode_image(ref_lib, img)
+
+    def fails(bl):
+        with pytest.raises(device.DeviceError):
+            device.frame_from_blobs(md, bl, lib=d)
+
+    fails([blobs[0]])                                   # an LF group is missing
+    fails([blobs[0], blobs[0]])                         # an LF group twice
+    fails([blobs[0], blobs[1][:100]])                   # truncated
+    fails([blobs[0], b"\0" * len(blobs[1])])            # no magic
+    bad = bytearray(blobs[1])
+    bad[12] |= 2                                        # header.status: "this shard must rerun its frame"
+    fails([blobs[0], bytes(bad)])
+    huge = bytearray(blobs[1])
+    huge[64 + 16 + 36 + 12 + 256 + 4608 + 16:64 + 16 + 36 + 12 + 256 + 4608 + 20] = (1 << 30).to_bytes(4, "little")  # lf.offset beyond the blob
+    fails([blobs[0], bytes(huge)])

@@ -60,6 +60,10 @@ hipError_t launch_lf_back(const HydkLfJob *d_jobs, const unsigned long long *rec
 hipError_t launch_rans_emit(const HydkLfJob *d_jobs, const uint32_t *sym_count, const uint16_t *aux, const uint16_t *flags,
                             uint32_t aux_pitch, const uint32_t *final_state, const uint32_t *group_bits, const uint64_t *offsets,
                             uint8_t *payload, int preset_bits, int num_slots, const uint32_t *status, hipStream_t stream);
+hipError_t launch_frame_begin(const HydkLfJob *host_jobs, HydkLfJob *d_jobs, int count, uint32_t *accum, size_t accum_words,
+                              hipStream_t stream);
+hipError_t launch_publish(const uint64_t *total, uint64_t *h_total, const unsigned long long *lf_total,
+                          unsigned long long *h_lf_total, const uint32_t *status, uint32_t *h_status, hipStream_t stream);
 hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, uint8_t *payload,
                        uint64_t payload_cap, int clear_shared_words, uint32_t *status, hipStream_t stream);
 hipError_t launch_pack(const uint32_t *bitbuf, uint32_t bit_pitch_words, const uint32_t *group_bits, const uint64_t *offsets,
@@ -193,6 +197,11 @@ struct HydAmdContext {
     uint32_t h_status = 0;
     int slots_finished = 0;
     bool results_valid = false;
+    uint32_t *accum = nullptr;       /* [hist | alpha_max | status | lf_hist]: cleared once per frame by k_frame_begin */
+    size_t accum_words = 0;
+    bool accum_stale = true;
+    bool lf_total_unpublished = false;
+    bool status_published = false;   /* nothing that can set status bits was enqueued after the last launch_publish */
     uint64_t *h_total_pinned = nullptr;
     uint32_t *h_status_pinned = nullptr;
 
@@ -564,12 +573,12 @@ void hydamd_destroy(HydAmdContext *ctx) {
         (void)hipEventDestroy(ctx->lf_ready);
     if (ctx->h_lf_total_pinned)
         (void)hipHostFree(ctx->h_lf_total_pinned);
-    void *lfdev[] = {ctx->lf_recs, ctx->lf_hist, ctx->lf_codes, ctx->lf_work, ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total};
+    void *lfdev[] = {ctx->lf_recs, ctx->lf_codes, ctx->lf_work, ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total};
     for (void *p : lfdev)
         if (p)
             (void)hipFree(p);
-    void *dev[] = {ctx->rans_aux, ctx->rans_flags, ctx->rans_final, ctx->rbits_total, ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->hist, ctx->sym_count, ctx->group_bits,
-                   ctx->offsets, ctx->total, ctx->status, ctx->alpha_max, ctx->d_jobs, ctx->in_lut8, ctx->in_lut16,
+    void *dev[] = {ctx->rans_aux, ctx->rans_flags, ctx->rans_final, ctx->rbits_total, ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->accum, ctx->sym_count, ctx->group_bits,
+                   ctx->offsets, ctx->total, ctx->d_jobs, ctx->in_lut8, ctx->in_lut16,
                    ctx->bias_lut, ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant, ctx->d_arena};
     for (void *p : dev)
         if (p)
@@ -662,16 +671,26 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipMalloc(&ctx->rbits_total, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->tables, slots * sizeof(HydkTables)));
     HIP_TRY(ctx, hipMalloc(&ctx->dc, slots * 3 * HYDK_DC_PITCH * HYDK_DC_PITCH * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->hist, slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t)));
+    {
+        /* everything a frame ACCUMULATES into (histograms, alphabet maxima, status bits, the LF coder's
+         * histograms) sits in one arena that k_frame_begin clears in the launch that stages the frame's
+         * first job descriptors: one launch where four memsets and a copy used to sit in the stream */
+        const size_t hist_words = slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET, lf_words = (slots + 1) * HYDK_LF_CODES; /* +1: the unit-test entry's scratch */
+        const size_t head_words = (slots + 1 + 3) & ~(size_t)3; /* alpha_max[slots], status, padding to 16 bytes */
+        ctx->accum_words = hist_words + head_words + ((lf_words + 3) & ~(size_t)3);
+        HIP_TRY(ctx, hipMalloc(&ctx->accum, ctx->accum_words * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemset(ctx->accum, 0, ctx->accum_words * sizeof(uint32_t)));
+        ctx->hist = ctx->accum;
+        ctx->alpha_max = ctx->accum + hist_words;
+        ctx->status = ctx->alpha_max + slots;
+        ctx->lf_hist = ctx->accum + hist_words + head_words;
+    }
     HIP_TRY(ctx, hipMalloc(&ctx->sym_count, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->group_bits, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->offsets, slots * G * sizeof(uint64_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->total, sizeof(uint64_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->status, sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->alpha_max, slots * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_jobs, slots * sizeof(HydkLfJob)));
     HIP_TRY(ctx, hipMalloc(&ctx->lf_recs, slots * HYDK_LF_SYMBOLS * sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMalloc(&ctx->lf_hist, (slots + 1) * HYDK_LF_CODES * sizeof(uint32_t))); /* +1: the unit-test entry's scratch */
     HIP_TRY(ctx, hipMalloc(&ctx->lf_codes, HYDK_LF_CODES * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->lf_work, slots * hydk::lf_work_bytes()));
     HIP_TRY(ctx, hipMalloc(&ctx->lf_streams, (slots + 1) * sizeof(HydkLfStream)));
@@ -699,7 +718,6 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_status_pinned, sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(ctx, hipMemset(ctx->group_bits, 0, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMemset(ctx->sym_count, 0, slots * G * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMemset(ctx->status, 0, sizeof(uint32_t)));
     if (debug_planes) {
         HIP_TRY(ctx, hipMalloc(&ctx->dbg_xyb, 3 * kDbgPlane * sizeof(float)));
         HIP_TRY(ctx, hipMalloc(&ctx->dbg_dct, 3 * kDbgPlane * sizeof(float)));
@@ -861,12 +879,9 @@ int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->jobs_uploaded[ctx->jobs_idx]));
     ctx->h_jobs = ctx->h_jobs_ring[ctx->jobs_idx];
     memset(ctx->h_jobs, 0, (size_t)ctx->max_slots * sizeof(HydkLfJob));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->hist, 0,
-                                (size_t)ctx->max_slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->alpha_max, 0, (size_t)ctx->max_slots * sizeof(uint32_t), ctx->stream));
+    ctx->accum_stale = true; /* cleared by the launch that stages this frame's first job descriptors */
     ctx->alpha_floor = 0;
     ctx->alpha_floor_dev = nullptr;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->status, 0, sizeof(uint32_t), ctx->stream));
     return ST_OK;
 }
 
@@ -930,8 +945,12 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
             return fail(ctx, ST_API_ERROR, "an LF-group slot of this frame was never submitted");
         mask |= 1u << ctx->h_jobs[i].fmt;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_jobs + first, ctx->h_jobs + first, (size_t)count * sizeof(HydkLfJob),
-                                hipMemcpyHostToDevice, ctx->stream));
+    ctx->status_published = false;
+    /* the descriptors travel by a kernel that reads the pinned ring; the frame's first such launch also
+     * clears what the frame accumulates into */
+    HIP_TRY(ctx, hydk::launch_frame_begin(ctx->h_jobs + first, ctx->d_jobs + first, count,
+                                          ctx->accum_stale ? ctx->accum : nullptr, ctx->accum_words, ctx->stream));
+    ctx->accum_stale = false;
     HIP_TRY(ctx, hipEventRecord(ctx->jobs_uploaded[ctx->jobs_idx], ctx->stream));
     ScopedTimer timer(ctx, HYDAMD_K_TRANSFORM);
     HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs + first, count, mask, ctx->use_luts, ctx->status, ctx->stream));
@@ -943,6 +962,7 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
  * overlaps the HF entropy stage; join_lf brings the streams back together. */
 static int lf_range(HydAmdContext *ctx, int first, int count, bool forked) {
     hipStream_t where = forked ? ctx->lf_stream : ctx->stream;
+    ctx->status_published = false;
     if (forked) {
         HIP_TRY(ctx, hipEventRecord(ctx->lf_fork, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->lf_stream, ctx->lf_fork, 0));
@@ -983,7 +1003,7 @@ int hydamd_run_transform(HydAmdContext *ctx, int num_slots) {
 
 /* the frame's LF streams are packed once all of its LF groups are coded (num_slots > 0: called from
  * the frame's closing stage); then the side stream rejoins the main one */
-static int join_lf(HydAmdContext *ctx, int num_slots) {
+static int join_lf(HydAmdContext *ctx, int num_slots, bool totals_follow = false) {
     if (num_slots > 0 && ctx->lf_on_device == 2 && num_slots > ctx->lf_coded) {
         /* in-stream mode: the whole LF coder runs here, behind the frame's packing kernels (no extra
          * stream: with many frames in flight side streams alias onto the same hardware queues) */
@@ -995,8 +1015,10 @@ static int join_lf(HydAmdContext *ctx, int num_slots) {
     if (num_slots > 0 && ctx->lf_need_gather) {
         hipStream_t where = ctx->lf_pending ? ctx->lf_stream : ctx->stream;
         HIP_TRY(ctx, hydk::launch_lf_gather(ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total, num_slots, where));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_lf_total_pinned, ctx->lf_total, sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                                    where));
+        if (totals_follow && !ctx->lf_pending) /* the caller's own publishing launch follows on the same stream */
+            ctx->lf_total_unpublished = true;
+        else /* the host may wait for the LF streams alone (lf_ready) */
+            HIP_TRY(ctx, hydk::launch_publish(nullptr, nullptr, ctx->lf_total, ctx->h_lf_total_pinned, nullptr, nullptr, where));
         HIP_TRY(ctx, hipEventRecord(ctx->lf_ready, where));
         ctx->lf_slots = num_slots;
         ctx->lf_need_gather = false;
@@ -1017,10 +1039,7 @@ static int replay_frame(HydAmdContext *ctx) {
     for (int i = 0; i < ctx->max_slots; i++)
         if (ctx->h_jobs[i].width)
             bind_slot_buffers(ctx, i);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->hist, 0, (size_t)ctx->max_slots * HYDK_MAX_CLUSTERS * HYDK_ALPHABET * sizeof(uint32_t),
-                                ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->alpha_max, 0, (size_t)ctx->max_slots * sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->status, 0, sizeof(uint32_t), ctx->stream));
+    ctx->accum_stale = true;
     const int entropy = ctx->want_entropy;
     ctx->transformed = ctx->coded = ctx->lf_coded = 0;
     ctx->results_valid = false;
@@ -1088,7 +1107,9 @@ int widen_token_records(HydAmdContext *ctx) {
 /* wait for the stream; rerun the frame if one of its buffers turned out too small */
 static int wait_for_frame(HydAmdContext *ctx) {
     for (int attempt = 0; attempt < 4; attempt++) {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status_pinned, ctx->status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (!ctx->status_published) /* stages were enqueued behind the frame's last publishing launch (or there was none) */
+            HIP_TRY(ctx, hydk::launch_publish(nullptr, nullptr, nullptr, nullptr, ctx->status, ctx->h_status_pinned, ctx->stream));
+        ctx->status_published = true;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         bool again = false;
         const int st = resolve_overflow(ctx, *ctx->h_status_pinned, &again);
@@ -1261,12 +1282,17 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
         ctx->lf_need_gather = true;
     }
     {
-        const int st = join_lf(ctx, num_slots);
+        const int st = join_lf(ctx, num_slots, true);
         if (st != ST_OK)
             return st;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_total_pinned, ctx->total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status_pinned, ctx->status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    /* one single-wave kernel writes the frame's totals and status straight into pinned host memory */
+    HIP_TRY(ctx, hydk::launch_publish(ctx->total, ctx->h_total_pinned, ctx->lf_total_unpublished ? ctx->lf_total : nullptr,
+                                      ctx->h_lf_total_pinned, ctx->status, ctx->h_status_pinned, ctx->stream));
+    if (ctx->lf_total_unpublished) /* hydamd_sync_lf waits for this event and then reads the LF total */
+        HIP_TRY(ctx, hipEventRecord(ctx->lf_ready, ctx->stream));
+    ctx->lf_total_unpublished = false;
+    ctx->status_published = true;
     ctx->slots_finished = num_slots;
     return ST_OK;
 }

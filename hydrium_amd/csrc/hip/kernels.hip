@@ -1451,6 +1451,36 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
 /* One workgroup of 256 threads: a larger one would have to wait for a compute unit with sixteen free
  * wave slots while other frames' transform workgroups keep taking whatever frees up (measured: this
  * kernel took 0.8 ms in the pipelined loop as a 1024-thread workgroup, against 15 us alone). */
+/* ==========================================================================================
+ * Frame bookkeeping that used to be runtime memsets and copies (each of those is a blit kernel of its
+ * own in the stream).
+ *   k_frame_begin: block 0 copies job descriptors from the pinned host ring into device memory; the
+ *                  other blocks clear the frame's accumulator arena when the launch is the frame's first.
+ *   k_publish:     the frame's totals and status, written by the device into pinned host memory.
+ * ======================================================================================== */
+__global__ __launch_bounds__(kThreads) void k_frame_begin(const uint32_t *__restrict__ host_jobs, uint32_t *__restrict__ d_jobs,
+                                                          uint32_t job_words, uint4 *__restrict__ accum, uint32_t quads) {
+    HYDK_URGENT();
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < job_words; i += kThreads)
+            d_jobs[i] = host_jobs[i];
+        return;
+    }
+    for (uint32_t i = (blockIdx.x - 1) * kThreads + threadIdx.x; i < quads; i += (gridDim.x - 1) * kThreads)
+        accum[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+__global__ __launch_bounds__(64) void k_publish(const uint64_t *total, uint64_t *h_total, const unsigned long long *lf_total,
+                                                unsigned long long *h_lf_total, const uint32_t *status, uint32_t *h_status) {
+    HYDK_URGENT();
+    if (threadIdx.x == 0 && total)
+        *h_total = *total;
+    if (threadIdx.x == 1 && lf_total)
+        *h_lf_total = *lf_total;
+    if (threadIdx.x == 2 && status)
+        *h_status = *status;
+}
+
 __global__ __launch_bounds__(kThreads) void k_scan_sections(const uint32_t *group_bits, int count, uint64_t *offsets,
                                                             uint64_t *total, uint8_t *payload, uint64_t payload_cap,
                                                             int clear_shared_words, uint32_t *status) {
@@ -1681,6 +1711,22 @@ hipError_t launch_rans_emit(const HydkLfJob *d_jobs, const uint32_t *sym_count, 
                             uint8_t *payload, int preset_bits, int num_slots, const uint32_t *status, hipStream_t stream) {
     hipLaunchKernelGGL(k_rans_emit, dim3(num_slots * 16), dim3(kThreads), 0, stream, d_jobs, sym_count, aux, flags, aux_pitch,
                        final_state, group_bits, offsets, payload, preset_bits, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_begin(const HydkLfJob *host_jobs, HydkLfJob *d_jobs, int count, uint32_t *accum, size_t accum_words,
+                              hipStream_t stream) {
+    const uint32_t quads = accum ? (uint32_t)(accum_words / 4) : 0u;
+    const uint32_t job_words = (uint32_t)((size_t)count * sizeof(HydkLfJob) / sizeof(uint32_t));
+    const uint32_t blocks = 1u + (quads + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(k_frame_begin, dim3(blocks < 64u ? blocks : 64u), dim3(kThreads), 0, stream, (const uint32_t *)host_jobs,
+                       (uint32_t *)d_jobs, job_words, (uint4 *)accum, quads);
+    return hipGetLastError();
+}
+
+hipError_t launch_publish(const uint64_t *total, uint64_t *h_total, const unsigned long long *lf_total,
+                          unsigned long long *h_lf_total, const uint32_t *status, uint32_t *h_status, hipStream_t stream) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, stream, total, h_total, lf_total, h_lf_total, status, h_status);
     return hipGetLastError();
 }
 

@@ -584,9 +584,7 @@ size_t lf_work_bytes() { return sizeof(LfWork); }
  * stage's launch (kernels.hip k_rans_lanes), which is why it can be left out here. */
 hipError_t launch_lf_front(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, void *work, int num_slots,
                            hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(hist, 0, (size_t)num_slots * HYDK_LF_CODES * sizeof(uint32_t), stream);
-    if (e != hipSuccess)
-        return e;
+    /* hist is zero on entry: it lives in the arena k_frame_begin clears once per frame */
     hipLaunchKernelGGL(k_lf_tokens, dim3(kMaxWindows, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist, (LfWork *)work);
     return hipGetLastError();
 }

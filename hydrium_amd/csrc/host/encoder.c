@@ -658,6 +658,8 @@ static int device_fail(HYDEncoder *e, int code) {
     /* hydamd status codes are HYDStatusCode values; keep a static string for the message */
     static const char *const generic = "GPU encode failed (see hydamd_error)";
     const char *m = hydamd_error(e->dev);
+    if (m && getenv("HYDAMD_TRACE"))
+        fprintf(stderr, "[hydrium] device error %d: %s\n", code, m);
     if (m && strstr(m, "NaN"))
         e->error = "Invalid NaN Float";
     else if (m && strstr(m, "no usable HIP device"))

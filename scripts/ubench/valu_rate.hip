@@ -49,21 +49,52 @@ typedef float float2_ __attribute__((ext_vector_type(2)));
 #define I_DPPADD(a)   asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a))
 #define I_SDWA(a)     asm volatile("v_cvt_f32_u32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(a))
 
+#define I_AND(a) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a) : "v"(u0))
+#define I_OR(a) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a) : "v"(u1))
+#define I_XOR(a) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a) : "v"(u0))
+#define I_LSHL(a) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a))
+#define I_LSHR(a) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a))
+#define I_ASHR(a) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(a))
+#define I_SUBU(a) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a) : "v"(u1))
+#define I_MINU(a) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a) : "v"(u0))
+#define I_MAXF(a) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a) : "v"(k1))
+#define I_SUBF(a) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a) : "v"(k1))
+#define I_FMAC(a) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a) : "v"(k0), "v"(k1))
+#define I_CNDONLY(a) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(u0) : "vcc")
+#define I_MOV(a) asm volatile("v_mov_b32 %0, %1" : "+v"(a) : "v"(u0))
+#define I_ANDOR(a) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a) : "v"(u0), "v"(u1))
+#define I_OR3(a) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a) : "v"(u0), "v"(u1))
+#define I_LSHLOR(a) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a) : "v"(u1))
+#define I_CMPF(a) asm volatile("v_cmp_ge_f32 vcc, %0, %1" : : "v"(a), "v"(k1) : "vcc")
+#define I_CMPFABS(a) asm volatile("v_cmp_ge_f32_e64 vcc, |%0|, %1" : : "v"(a), "v"(k1) : "vcc")
+#define I_MUL24(a) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a) : "v"(u1))
+#define I_TRUNC(a) asm volatile("v_trunc_f32 %0, %0" : "+v"(a))
+#define I_FLOOR(a) asm volatile("v_floor_f32 %0, %0" : "+v"(a))
+#define I_CVTUF(a) asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(a))
+#define I_ADDC(a) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(a) : : "vcc")
+#define I_XAD(a) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(a) : "v"(u0), "v"(u1))
+#define I_BFI(a) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a) : "v"(u0), "v"(u1))
+#define I_ALIGNBIT(a) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a) : "v"(u0))
+#define I_MULABS(a) asm volatile("v_mul_f32_e64 %0, |%0|, %1" : "+v"(a) : "v"(k0))
+#define I_MUL_LIT(a) asm volatile("v_mul_f32 %0, 0x3e318a87, %0" : "+v"(a))
+#define I_ADD_SGPR(a) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a) : "s"(k1))
+
 #define REP8(M, T) M(T[0]); M(T[1]); M(T[2]); M(T[3]); M(T[4]); M(T[5]); M(T[6]); M(T[7])
 #define REP8x2(M1, M2, T) M1(T[0]); M1(T[1]); M1(T[2]); M1(T[3]); M1(T[4]); M1(T[5]); M1(T[6]); M1(T[7]); \
                           M2(T[0]); M2(T[1]); M2(T[2]); M2(T[3]); M2(T[4]); M2(T[5]); M2(T[6]); M2(T[7])
 
 enum Kind { K_MUL_ADD, K_FMA, K_PKMUL_PKADD, K_PKFMA, K_MAD24, K_MULLO, K_MULHI, K_MULHI24, K_ADDU, K_ADD3, K_LSHLADD,
             K_BFE, K_PERM, K_CNDMASK, K_CMP, K_LSHL64, K_BCNT, K_FFBH, K_CVTFU, K_CVTIF, K_RCP, K_MED3, K_DPPSHR,
-            K_DPPADD, K_SDWA, K_MUL_ONLY, K_ADD_ONLY, K_PKMUL_ONLY, K_COUNT };
+            K_DPPADD, K_SDWA, K_MUL_ONLY, K_ADD_ONLY, K_PKMUL_ONLY, K_AND, K_OR, K_XOR, K_LSHL, K_LSHR, K_ASHR, K_SUBU, K_MINU, K_MAXF, K_SUBF, K_FMAC, K_CNDONLY, K_MOV, K_ANDOR, K_OR3, K_LSHLOR, K_CMPF, K_CMPFABS, K_MUL24, K_TRUNC, K_FLOOR, K_CVTUF, K_ADDC, K_XAD, K_BFI, K_ALIGNBIT, K_MULABS, K_MUL_LIT, K_ADD_SGPR, K_COUNT };
 static const char *kNames[K_COUNT] = {
     "v_mul_f32 + v_add_f32 (non-fused pair)", "v_fma_f32", "v_pk_mul_f32 + v_pk_add_f32", "v_pk_fma_f32", "v_mad_u32_u24",
     "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_u32_u24", "v_add_u32", "v_add3_u32", "v_lshl_add_u32", "v_bfe_u32", "v_perm_b32",
     "v_cmp_gt_u32 + v_cndmask_b32 (PAIR: halve)", "v_cmp_gt_u32 (vcc)", "v_lshlrev_b64", "v_bcnt_u32_b32", "v_ffbh_u32", "v_cvt_f32_u32", "v_cvt_i32_f32",
     "v_rcp_f32", "v_med3_i32", "v_mov_b32_dpp row_shr:1", "v_add_u32_dpp row_shr:1", "v_cvt_f32_u32_sdwa WORD_1",
-    "v_mul_f32", "v_add_f32", "v_pk_mul_f32"};
+    "v_mul_f32", "v_add_f32", "v_pk_mul_f32",
+    "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_sub_u32", "v_min_u32", "v_max_f32", "v_sub_f32", "v_fmac_f32", "v_cndmask_b32 (vcc untouched)", "v_mov_b32", "v_and_or_b32", "v_or3_b32", "v_lshl_or_b32", "v_cmp_ge_f32 (vcc)", "v_cmp_ge_f32 |x| (VOP3, vcc)", "v_mul_u32_u24", "v_trunc_f32", "v_floor_f32", "v_cvt_u32_f32", "v_addc_co_u32 (vcc in/out)", "v_xad_u32", "v_bfi_b32", "v_alignbit_b32", "v_mul_f32 |x| (VOP3)", "v_mul_f32 with 32-bit literal", "v_add_f32 with SGPR operand"};
 // lane-level arithmetic results per instruction (2 for packed forms)
-static const int kLaneOps[K_COUNT] = {1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2};
+static const int kLaneOps[K_COUNT] = {1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 template <int KIND, int CHAINS /* 8: throughput, 1: dependent latency */>
 __global__ __launch_bounds__(256) void k(float *out, long long *cyc, int iters, float seed) {
@@ -115,6 +146,35 @@ __global__ __launch_bounds__(256) void k(float *out, long long *cyc, int iters, 
         else if (KIND == K_MUL_ONLY) { BODY8(I_MUL, f) }
         else if (KIND == K_ADD_ONLY) { BODY8(I_ADD, f) }
         else if (KIND == K_PKMUL_ONLY) { BODY8(I_PKMUL, pf) }
+        else if (KIND == K_AND) { BODY8(I_AND, u) }
+        else if (KIND == K_OR) { BODY8(I_OR, u) }
+        else if (KIND == K_XOR) { BODY8(I_XOR, u) }
+        else if (KIND == K_LSHL) { BODY8(I_LSHL, u) }
+        else if (KIND == K_LSHR) { BODY8(I_LSHR, u) }
+        else if (KIND == K_ASHR) { BODY8(I_ASHR, u) }
+        else if (KIND == K_SUBU) { BODY8(I_SUBU, u) }
+        else if (KIND == K_MINU) { BODY8(I_MINU, u) }
+        else if (KIND == K_MAXF) { BODY8(I_MAXF, f) }
+        else if (KIND == K_SUBF) { BODY8(I_SUBF, f) }
+        else if (KIND == K_FMAC) { BODY8(I_FMAC, f) }
+        else if (KIND == K_CNDONLY) { BODY8(I_CNDONLY, u) }
+        else if (KIND == K_MOV) { BODY8(I_MOV, u) }
+        else if (KIND == K_ANDOR) { BODY8(I_ANDOR, u) }
+        else if (KIND == K_OR3) { BODY8(I_OR3, u) }
+        else if (KIND == K_LSHLOR) { BODY8(I_LSHLOR, u) }
+        else if (KIND == K_CMPF) { BODY8(I_CMPF, f) }
+        else if (KIND == K_CMPFABS) { BODY8(I_CMPFABS, f) }
+        else if (KIND == K_MUL24) { BODY8(I_MUL24, u) }
+        else if (KIND == K_TRUNC) { BODY8(I_TRUNC, f) }
+        else if (KIND == K_FLOOR) { BODY8(I_FLOOR, f) }
+        else if (KIND == K_CVTUF) { BODY8(I_CVTUF, u) }
+        else if (KIND == K_ADDC) { BODY8(I_ADDC, u) }
+        else if (KIND == K_XAD) { BODY8(I_XAD, u) }
+        else if (KIND == K_BFI) { BODY8(I_BFI, u) }
+        else if (KIND == K_ALIGNBIT) { BODY8(I_ALIGNBIT, u) }
+        else if (KIND == K_MULABS) { BODY8(I_MULABS, f) }
+        else if (KIND == K_MUL_LIT) { BODY8(I_MUL_LIT, f) }
+        else if (KIND == K_ADD_SGPR) { BODY8(I_ADD_SGPR, f) }
     }
     long long t1 = __builtin_readcyclecounter();
     long long w1 = wall_clock64();
@@ -203,5 +263,6 @@ int main() {
     RUN(K_MAD24) RUN(K_MULLO) RUN(K_MULHI) RUN(K_MULHI24) RUN(K_ADDU) RUN(K_ADD3) RUN(K_LSHLADD) RUN(K_BFE) RUN(K_PERM)
     RUN(K_CNDMASK) RUN(K_CMP) RUN(K_LSHL64) RUN(K_BCNT) RUN(K_FFBH) RUN(K_CVTFU) RUN(K_CVTIF) RUN(K_RCP) RUN(K_MED3)
     RUN(K_DPPSHR) RUN(K_DPPADD) RUN(K_SDWA)
+    RUN(K_AND) RUN(K_OR) RUN(K_XOR) RUN(K_LSHL) RUN(K_LSHR) RUN(K_ASHR) RUN(K_SUBU) RUN(K_MINU) RUN(K_MAXF) RUN(K_SUBF) RUN(K_FMAC) RUN(K_CNDONLY) RUN(K_MOV) RUN(K_ANDOR) RUN(K_OR3) RUN(K_LSHLOR) RUN(K_CMPF) RUN(K_CMPFABS) RUN(K_MUL24) RUN(K_TRUNC) RUN(K_FLOOR) RUN(K_CVTUF) RUN(K_ADDC) RUN(K_XAD) RUN(K_BFI) RUN(K_ALIGNBIT) RUN(K_MULABS) RUN(K_MUL_LIT) RUN(K_ADD_SGPR)
     return 0;
 }

@@ -196,7 +196,7 @@ def encode_image(lib: Library, img: np.ndarray, *, linear_light: int = 0, shift_
     tw, th = tile_dims(w, h, shift_x, shift_y)
     ntx, nty = -(-w // tw), -(-h // th)
     tiles = [(tx, ty) for ty in range(nty) for tx in range(ntx)] if order is None else list(order)
-    out = bytearray()
+    chunks = []
     with Encoder(lib) as enc:
         enc.check(enc.set_metadata(w, h, linear_light, shift_x, shift_y))
         if icc is not None:
@@ -212,8 +212,9 @@ def encode_image(lib: Library, img: np.ndarray, *, linear_light: int = 0, shift_
                 ret = enc.check(enc.flush())
                 code, n = enc.release_output()
                 enc.check(code)
-                out += C.string_at(buf, n)
+                if n:
+                    chunks.append(C.string_at(buf, n))
                 enc.check(enc.provide_output(buf))
                 if ret != HYD_NEED_MORE_OUTPUT:
                     break
-    return bytes(out)
+    return chunks[0] if len(chunks) == 1 else b"".join(chunks)

@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "hydk_common.h"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -153,6 +154,19 @@ __device__ __forceinline__ uint32_t input_lut16_eval(uint32_t i, int linear_ligh
     const float f = (float)i * kUnit16;
     return (uint32_t)(int)((linear_light ? f : linearize(f)) * 65535.f + 0.5f);
 }
+/* The same entry with the transfer-curve decision taken outside: samples above kDarkMax are on the cubic
+ * branch of linearize (format.c:15-19), so a wavefront that holds none at or below it evaluates the cubic
+ * alone — no compare, no masked second branch — and a linear-light job no curve at all.  That the branch
+ * flips exactly between kDarkMax and kDarkMax + 1 is checked for all 65536 inputs by k_lut_selftest. */
+constexpr uint32_t kDarkMax = 2650;
+constexpr int kCurveBoth = 0, kCurveNone = 1, kCurveCubic = 2;
+template <int CURVE>
+__device__ __forceinline__ uint32_t input_lut16_eval_as(uint32_t i) {
+    const float f = (float)i * kUnit16;
+    const float y = CURVE == kCurveNone ? f : CURVE == kCurveCubic
+        ? 0.003094300919832f + f * (-0.009982599f + f * (0.72007737769f + 0.2852804880f * f)) : linearize(f);
+    return (uint32_t)(int)(y * 65535.f + 0.5f);
+}
 /* floor(u / 3) for u < 2^31 in one multiply-high: u * ceil(2^32 / 3) overshoots u / 3 by less than 1/3 */
 __device__ __forceinline__ uint32_t div3(uint32_t u) { return __umulhi(u, 0x55555556u); }
 template <int XMODE>
@@ -174,14 +188,24 @@ __device__ __forceinline__ float bias_lut_eval(uint32_t i) {
     return r1 - 0.155954f;
 }
 
+/* c * x + acc for c, x below 2^24, as the one instruction it is (the compiler keeps multiply and add apart) */
+__device__ __forceinline__ uint32_t umad24(uint32_t c, uint32_t x, uint32_t acc) {
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "s"(c), "v"(x), "v"(acc));
+    return d;
+}
+
 template <int XMODE>
 __device__ __forceinline__ void lms_mix_u16(uint32_t r, uint32_t g, uint32_t b, const float *bias_lut, float &X,
                                             float &Y, float &B) {
     constexpr bool LUTS = XMODE == kXybGather;
     /* format.c:48-56: 16.16 fixed-point LMS mix, high half indexes the bias LUT */
-    const uint32_t il = (19661u * r + 40761u * g + 5112u * b) >> 16;
-    const uint32_t im = (15073u * r + 45350u * g + 5112u * b) >> 16;
-    const uint32_t is = (15953u * r + 13419u * g + 36163u * b) >> 16;
+    /* r, g, b are 16-bit LUT outputs: 24-bit multiplies are exact on them and fuse with the additions
+     * (v_mad_u32_u24), same sums modulo 2^32 as the reference's 32-bit arithmetic */
+    const uint32_t bb = __umul24(5112u, b);
+    const uint32_t il = umad24(19661u, r, umad24(40761u, g, bb)) >> 16;
+    const uint32_t im = umad24(15073u, r, umad24(45350u, g, bb)) >> 16;
+    const uint32_t is = umad24(15953u, r, umad24(13419u, g, __umul24(36163u, b))) >> 16;
     float l, m, s;
     if (LUTS) {
         l = bias_lut[il];
@@ -425,6 +449,7 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
 
     /* column / token phases: thread (block cb, horizontal frequency kh) */
     const int cb = t >> 3, kh = t & 7;
+    const uint32_t nib_row = (uint32_t)kh * (uint32_t)sizeof(kNibbleMasks.m[0]); /* 256 bytes per kh */
     /* first cluster holding coefficient contexts, by scheme (encoder.c:862-901) */
     const int coef_cl_lo = job.scheme == 0 ? 3 : job.scheme == 3 ? 0 : 1;
 
@@ -478,7 +503,23 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                 for (int k = 0; k < kWords; k++)
                     w[k] = nxt[k];
                 prefetch(s + 1);
-                if (row_ok) {
+                /* which form of the transfer curve this wavefront's 16-bit samples need (wave-uniform) */
+                int curve = kCurveBoth;
+                if (FMT == HYDK_FMT_U16 && !LUTS) {
+                    if (job.linear_light)
+                        curve = kCurveNone;
+                    else {
+                        typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+                        u16x2 mn = __builtin_bit_cast(u16x2, w[0]);
+#pragma unroll
+                        for (int k = 1; k < kWords; k++)
+                            mn = __builtin_elementwise_min(mn, __builtin_bit_cast(u16x2, w[k]));
+                        const bool dark = row_ok && (uint32_t)(mn.x < mn.y ? mn.x : mn.y) <= kDarkMax;
+                        curve = __builtin_amdgcn_ballot_w64(dark) ? kCurveBoth : kCurveCubic;
+                    }
+                }
+                auto row_to_xyb = [&](auto curve_tag) {
+                    constexpr int CURVE = decltype(curve_tag)::value;
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         uint32_t rgb[3];
@@ -489,11 +530,19 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                                 rgb[ch] = s_lut8[(w[si >> 2] >> (8 * (si & 3))) & 0xFF];
                             else {
                                 const uint32_t v = (w[si >> 1] >> (16 * (si & 1))) & 0xFFFF;
-                                rgb[ch] = LUTS ? job.in_lut16[v] : input_lut16_eval(v, job.linear_light);
+                                rgb[ch] = LUTS ? job.in_lut16[v] : input_lut16_eval_as<CURVE>(v);
                             }
                         }
                         lms_mix_u16<XMODE>(rgb[0], rgb[1], rgb[2], job.bias_lut, xv[i], yv[i], bv[i]);
                     }
+                };
+                if (row_ok) {
+                    if (curve == kCurveCubic)
+                        row_to_xyb(std::integral_constant<int, kCurveCubic>());
+                    else if (curve == kCurveNone)
+                        row_to_xyb(std::integral_constant<int, kCurveNone>());
+                    else
+                        row_to_xyb(std::integral_constant<int, kCurveBoth>());
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; i++)
@@ -575,18 +624,23 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                     for (int kv = 0; kv < 8; kv++)
                         d[kv] = v[kv];
                 }
-                uint32_t pat = 0; /* bit kv: coefficient (kv, kh) is non-zero */
+                uint32_t nlo = 0, nhi = 0; /* byte offsets into this kh's nibble-mask rows: bit 3 + b set if coefficient (4 * half + b, kh) is non-zero */
                 int q[8];
                 const float4 w03 = *(const float4 *)&s_wq[c * 64 + kh * 8], w47 = *(const float4 *)&s_wq[c * 64 + kh * 8 + 4];
                 const float wq[8] = {w03.x, w03.y, w03.z, w03.w, w47.x, w47.y, w47.z, w47.w};
 #pragma unroll
                 for (int kv = 0; kv < 8; kv++) {
                     /* encoder.c:808-811: trunc((coef * weight) * 5); +-1 is the dead zone */
-                    int qq = (int)(v[kv] * wq[kv] * 5.0f);
-                    const bool nz = (uint32_t)(qq + 1) > 2u && !(kv == 0 && kh == 0); /* the DC slot is coded by the LF path */
+                    const float scaled = v[kv] * wq[kv] * 5.0f;
+                    int qq = (int)scaled;
+                    /* |trunc(x)| >= 2 exactly when |x| >= 2 (NaN: neither, and converts to 0) */
+                    const bool nz = __builtin_fabsf(scaled) >= 2.0f && !(kv == 0 && kh == 0); /* the DC slot is coded by the LF path */
                     qq = nz ? qq : 0;
                     q[kv] = qq;
-                    pat |= (nz ? 1u : 0u) << kv;
+                    if (kv < 4)
+                        nlo |= nz ? 8u << kv : 0u;
+                    else
+                        nhi |= nz ? 8u << (kv - 4) : 0u;
                     /* the thread's own column: nobody else reads or writes these eight words */
                     ((int *)src)[kv * 8] = qq;
                 }
@@ -597,7 +651,10 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                     for (int kv = 0; kv < 8; kv++)
                         d[kv] = q[kv];
                 }
-                const unsigned long long mine = kNibbleMasks.m[kh][0][pat & 15u] | kNibbleMasks.m[kh][1][pat >> 4];
+                /* 32-bit offsets from one uniform base: the loads take an SGPR base and a VGPR offset, no 64-bit address arithmetic */
+                const char *const nib = (const char *)&kNibbleMasks.m[0][0][0];
+                const unsigned long long mine = *(const unsigned long long *)(nib + (nib_row | nlo)) |
+                                                *(const unsigned long long *)(nib + (nib_row | 128u | nhi));
                 const uint32_t lo = or_reduce8((uint32_t)mine), hi = or_reduce8((uint32_t)(mine >> 32));
                 msk[c] = ((unsigned long long)hi << 32) | lo;
                 if (kh == 0) /* LF int: trunc(dc * shift[c]) (encoder.c:573,582) */
@@ -1640,6 +1697,11 @@ __global__ void k_lut_selftest(const uint16_t *in_lut16, const float *bias_lut, 
         return;
     uint32_t bad = 0;
     if (input_lut16_eval(i, linear_light) != in_lut16[i])
+        bad++;
+    if (((float)i * kUnit16 <= 0.0404482362771082f) != (i <= kDarkMax))
+        bad++;
+    if (linear_light ? input_lut16_eval_as<kCurveNone>(i) != in_lut16[i]
+                     : (i > kDarkMax ? input_lut16_eval_as<kCurveCubic>(i) : input_lut16_eval_as<kCurveBoth>(i)) != in_lut16[i])
         bad++;
     if (__float_as_uint(bias_lut_eval<XMODE>(i)) != __float_as_uint(bias_lut[i]))
         bad++;

@@ -6,6 +6,6 @@ for i in $(seq $reps); do
   for l in "$a" "$b"; do
     HYDAMD_LIB=$PWD/$l python bench.py --steps 120 --no-cpu-baseline --no-api "$@" 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$l', d['value'], d['ms_per_step'], d['single_frame_form5']['ms_per_frame'])"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$l', d['value'], d['ms_per_step'], d['single_frame_form5']['ms_per_frame'], 'K1', d['single_frame_form5']['kernel_avg_ms']['transform_tokenize'])"
   done
 done

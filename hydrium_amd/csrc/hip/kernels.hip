@@ -410,8 +410,9 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
 
     /* [c][block][kv][kh]: row-pass output, overwritten in place by the quantised coefficients, 27.0 KiB */
     __shared__ float s_rowpass[3 * kS0Chan];
-    __shared__ uint32_t s_btot[32];                   /* symbols of each varblock of the strip (three channels) */
-    __shared__ uint32_t s_boff[4][33];                /* per wave: their exclusive prefix sums + strip total */
+    /* exclusive prefix sums of the blocks' symbol counts + strip total.  Every wave computes and writes the same
+     * 33 values (no barrier needed before it reads them back: its own stores are ordered before its loads) */
+    __shared__ uint32_t s_boff[33];
     __shared__ uint32_t s_rbits;                      /* residue bits of the group's symbols */
     /* integer input cannot produce a token above 35 (see store_record): half the histogram suffices,
      * which is what lets two of these workgroups fit beside an entropy-stage workgroup */
@@ -419,8 +420,12 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
     __shared__ uint32_t s_hist[HYDK_MAX_CLUSTERS * kHistW];
     __shared__ uint16_t s_lut8[256];
     __shared__ uint8_t s_nnz3[64];                    /* coefficient-count context offset (encoder.c:60-66) mod 3 */
-    __shared__ uint8_t s_jinfo[64][2];                /* zig-zag position j -> {natural index kv*8+kh, frequency context (encoder.c:53-58) mod 3} */
-    __shared__ unsigned long long s_below[64];        /* bits 0..j-1 */
+    __shared__ uint16_t s_jinfo[64];                  /* zig-zag position j -> natural index kv*8+kh | (frequency context (encoder.c:53-58) mod 3) << 8 */
+    /* per (varblock, visit = Y, X, B): {non-zero bitmap by zig-zag position (2 words), symbols | non-zeros << 8,
+     * word offset of the block's coefficients in s_rowpass}.  The walk's last step reads one entry past the end
+     * and never uses it (whatever follows in LDS, or zero) */
+    __shared__ uint4 s_seg[32 * 3];
+    __shared__ uint32_t s_blen[32];                   /* symbols of the block's Y | X << 8 | B << 16 runs */
     __shared__ __attribute__((aligned(16))) float s_wq[3 * 64]; /* quantisation weight [channel][kh][kv]: a thread's eight in two 16-byte reads */
 
     const int t = threadIdx.x;
@@ -440,9 +445,9 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
         /* t as a natural index (kv, kh): where it sits in zig-zag order; t as a zig-zag position: its contexts */
         const int j = t;
         s_nnz3[t] = kNnzCtx[t] % 3;
-        s_jinfo[kZigzag[t >> 3][t & 7]][0] = (uint8_t)t;
-        s_jinfo[t][1] = (uint8_t)((j < 2 ? 0 : j < 16 ? j - 1 : j < 32 ? 15 + ((j - 16) >> 1) : 23 + ((j - 32) >> 2)) % 3);
-        s_below[t] = (1ull << t) - 1ull;
+        /* two threads write the two bytes of an entry: kept apart as bytes here, read as one u16 */
+        ((uint8_t *)s_jinfo)[2 * kZigzag[t >> 3][t & 7]] = (uint8_t)t;
+        ((uint8_t *)s_jinfo)[2 * t + 1] = (uint8_t)((j < 2 ? 0 : j < 16 ? j - 1 : j < 32 ? 15 + ((j - 16) >> 1) : 23 + ((j - 32) >> 2)) % 3);
     }
     if (t < 192) /* t = (c, kh, kv) */
         s_wq[t] = (float)kQuantWeight[t >> 6][kZigzag[t & 7][(t >> 3) & 7]];
@@ -667,79 +672,112 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
         const uint32_t nY = 1u + (msk[1] ? 63u - (uint32_t)__clzll(msk[1]) : 0u);
         const uint32_t nX = 1u + (msk[0] ? 63u - (uint32_t)__clzll(msk[0]) : 0u);
         const uint32_t nB = 1u + (msk[2] ? 63u - (uint32_t)__clzll(msk[2]) : 0u);
-        const uint32_t nblock = cb < gbw ? nY + nX + nB : 0u;
-        if (kh == 0)
-            s_btot[cb] = nblock;
+        if (kh == 0) {
+            s_blen[cb] = cb < gbw ? nY | (nX << 8) | (nB << 16) : 0u;
+            const uint32_t base = (uint32_t)(cb * kS0Block);
+            s_seg[cb * 3 + 0] = make_uint4((uint32_t)msk[1], (uint32_t)(msk[1] >> 32), nY | ((uint32_t)__popcll(msk[1]) << 8), base + kS0Chan);
+            s_seg[cb * 3 + 1] = make_uint4((uint32_t)msk[0], (uint32_t)(msk[0] >> 32), nX | ((uint32_t)__popcll(msk[0]) << 8), base);
+            s_seg[cb * 3 + 2] = make_uint4((uint32_t)msk[2], (uint32_t)(msk[2] >> 32), nB | ((uint32_t)__popcll(msk[2]) << 8), base + 2 * kS0Chan);
+        }
         HYDK_PHASE_MARK(3);
         __syncthreads();
         HYDK_PHASE_MARK(4);
 
         /* ---------------- phase C1: every wave prefix-sums the 32 block totals for itself ---------------- */
         {
-            const uint32_t mine = s_btot[lane & 31];
+            const uint32_t len3 = s_blen[lane & 31];
+            const uint32_t mine = (len3 & 0xffu) + ((len3 >> 8) & 0xffu) + (len3 >> 16);
             uint32_t inc = scan16_inclusive(mine);
             inc += HYDK_DPP(inc, 0x142, 0xA); /* row_bcast:15: rows 1 and 3 add the total of the row before */
-            s_boff[wave][(lane & 31) + 1] = inc;
+            s_boff[(lane & 31) + 1] = inc;
             if (lane == 0)
-                s_boff[wave][0] = 0;
+                s_boff[0] = 0;
             __builtin_amdgcn_wave_barrier();
         }
-        const uint32_t boff = s_boff[wave][cb], strip_total = s_boff[wave][32];
+        const uint32_t strip_total = s_boff[32];
         HYDK_PHASE_MARK(5);
 
-        /* ---------------- phase C2: the block's symbols, dealt round-robin to its eight threads ---------------- */
+        /* ---------------- phase C2: the strip's symbol stream, cut into 256 equal runs ----------------
+         * Thread t emits symbols [t * L, (t + 1) * L) of the strip, L = ceil(strip symbols / 256): it finds the
+         * (block, channel, zig-zag position) its run starts at by a binary search over the block offsets, then WALKS
+         * — the non-zero count still to come and the "previous coefficient was non-zero" flag of the contexts
+         * (encoder.c:724-738) are carried from symbol to symbol instead of being recounted from the bitmap, and the
+         * work is balanced over the workgroup whatever the blocks' sizes. */
         {
-            const uint32_t tY = (uint32_t)__popcll(msk[1]), tX = (uint32_t)__popcll(msk[0]), tB = (uint32_t)__popcll(msk[2]);
-            const uint32_t first = goff + boff;
             overflowed = overflowed || goff + strip_total > job.tok_cap;
-            for (uint32_t i = (uint32_t)kh; i < (overflowed ? 0u : nblock); i += 8u) {
-                /* i-th symbol of the block: which channel, which zig-zag position */
-                const bool inX = i >= nY, inB = i >= nY + nX;
-                const int visit = (int)inX + (int)inB;
-                const uint32_t j = i - (inX ? nY : 0u) - (inB ? nX : 0u);
-                const unsigned long long m = inB ? msk[2] : inX ? msk[0] : msk[1];
-                const uint32_t nz_total = inB ? tB : inX ? tX : tY;
-                const int plane = inB ? 2 * kS0Chan : inX ? 0 : kS0Chan;
-                uint32_t value;
-                int cluster;
-                if (j == 0) {
-                    /* the non-zero count.  Its context only matters through the cluster, which
-                     * depends on the visit index alone in every scheme (encoder.c:715,865-869,882,895,900) */
-                    value = nz_total;
-                    cluster = job.scheme == 0 ? visit : 0;
-                } else {
-                    const uint32_t nat = s_jinfo[j][0];
-                    value = pack_signed(((const int *)s_rowpass)[plane + cb * kS0Block + (int)nat]);
-                    /* non-zeros still to come before this coefficient (encoder.c:732,738) */
-                    const uint32_t remaining = nz_total - (uint32_t)__popcll(m & s_below[j]);
-                    const int prev = j == 1 ? (nz_total <= 4) : (int)((m >> (j - 1)) & 1ull);
-                    /* context - 111 = 458*visit + prev + 2*(nnz_ctx[remaining] + freq_ctx[j]) (encoder.c:724,731-732);
-                     * scheme 0 needs it mod 6 = prev + 2*((visit + nnz_ctx + freq_ctx) mod 3), the others mod 2 = prev */
-                    if (job.scheme == 0) {
-                        const int u = visit + (int)s_nnz3[remaining & 63] + (int)s_jinfo[j][1]; /* 0..6 */
-                        cluster = 3 + prev + 2 * (u - 3 * ((u * 11) >> 5));
-                    } else {
-                        cluster = job.scheme == 1 ? 1 + prev : job.scheme == 2 ? 1 : 0;
+            const uint32_t per = (strip_total + (uint32_t)kThreads - 1u) / (uint32_t)kThreads;
+            uint32_t p = (uint32_t)t * per;
+            const uint32_t pend = overflowed ? 0u : min(p + per, strip_total);
+            if (p < pend) {
+                uint32_t b = 0;
+#pragma unroll
+                for (uint32_t step = 16; step; step >>= 1)
+                    b += s_boff[b + step] <= p ? step : 0u;
+                uint32_t j = p - s_boff[b]; /* position in the block's symbols, then in the channel's */
+                const uint32_t len = s_blen[b];
+                uint32_t visit = 0;
+                if (j >= (len & 0xffu)) {
+                    j -= len & 0xffu;
+                    visit = 1;
+                    if (j >= ((len >> 8) & 0xffu)) {
+                        j -= (len >> 8) & 0xffu;
+                        visit = 2;
                     }
                 }
-                /* hybrid-uint split, config (4,1,0) (entropy.c:427-444) */
-                uint32_t token, rbits, residue;
-                if (value < 16) {
-                    token = value;
-                    rbits = 0;
-                    residue = 0;
-                } else {
-                    const int n = 30 - __clz((int)value); /* floor(log2) - 1 */
-                    rbits = (uint32_t)n;
-                    residue = value & ((1u << n) - 1u);
-                    token = 16u + (((uint32_t)(n - 3) << 1) | ((value >> n) & 1u));
+                uint32_t seg_at = b * 3u + visit;
+                uint4 seg = s_seg[seg_at];
+                uint32_t n = seg.z & 0xffu, nz_total = seg.z >> 8;
+                /* non-zeros at positions >= j; whether position j - 1 holds one (encoder.c:731-738) */
+                const unsigned long long m = ((unsigned long long)seg.y << 32) | seg.x;
+                uint32_t remaining = nz_total - (uint32_t)__popcll(m & ((1ull << j) - 1ull));
+                uint32_t prev = j <= 1u ? (uint32_t)(nz_total <= 4u) : (uint32_t)(m >> (j - 1u)) & 1u;
+                /* cluster of a coefficient = coef_base + (prev & prev_mask) + (2 * ((visit + nnz ctx + freq ctx) mod 3) & ctx_mask),
+                 * of a count = visit & count_mask: the four schemes of encoder.c:862-901 without a branch */
+                const uint32_t coef_base = (uint32_t)coef_cl_lo;
+                const uint32_t prev_mask = job.scheme <= 1 ? 1u : 0u, ctx_mask = job.scheme == 0 ? 6u : 0u;
+                const uint32_t count_mask = job.scheme == 0 ? 3u : 0u;
+                for (; p < pend; p++) {
+                    const uint32_t ji = s_jinfo[j];
+                    const int coef = ((const int *)s_rowpass)[seg.w + (ji & 0xffu)];
+                    const bool is_count = j == 0u;
+                    const uint32_t value = is_count ? nz_total : pack_signed(coef);
+                    /* context - 111 = 458*visit + prev + 2*(nnz_ctx[remaining] + freq_ctx[j]) (encoder.c:724,731-732);
+                     * scheme 0 needs it mod 6 = prev + 2*((visit + nnz_ctx + freq_ctx) mod 3), the others mod 2 = prev.
+                     * u = 0..6; 2 * (u mod 3) sits at bits 2u+1, 2u+2 of 0x1248 */
+                    const uint32_t u = visit + (uint32_t)s_nnz3[remaining & 63u] + (ji >> 8);
+                    const uint32_t cluster = is_count ? (visit & count_mask)
+                                                      : coef_base + (prev & prev_mask) + ((0x1248u >> (u + u)) & ctx_mask);
+                    /* hybrid-uint split, config (4,1,0) (entropy.c:427-444) */
+                    uint32_t token, rbits, residue;
+                    if (value < 16) {
+                        token = value;
+                        rbits = 0;
+                        residue = 0;
+                    } else {
+                        const int nb = 30 - __clz((int)value); /* floor(log2) - 1 */
+                        rbits = (uint32_t)nb;
+                        residue = value & ((1u << nb) - 1u);
+                        token = 16u + (((uint32_t)(nb - 3) << 1) | ((value >> nb) & 1u));
+                    }
+                    store_record<FMT>(tok, goff + p, token, cluster, rbits, residue);
+                    rb_sum += rbits;
+                    if (token == 0 && !is_count)
+                        zero_tokens += 1ull << (10 * (cluster - coef_base)); /* at most 24 x 32 per thread and group */
+                    else
+                        atomicAdd(&s_hist[cluster * kHistW + (int)min(token, (uint32_t)kHistW - 1u)], 1u);
+                    /* walk on: the DC slot read for a count symbol is zero, so it leaves `remaining` alone */
+                    const uint32_t here = coef != 0 ? 1u : 0u;
+                    remaining -= here;
+                    prev = is_count ? (uint32_t)(nz_total <= 4u) : here;
+                    if (++j == n) { /* next channel of the block, or the next block (at most one step: every run has its count symbol) */
+                        seg_at++;
+                        visit = visit == 2u ? 0u : visit + 1u;
+                        seg = s_seg[seg_at];
+                        n = seg.z & 0xffu;
+                        nz_total = remaining = seg.z >> 8;
+                        j = 0;
+                    }
                 }
-                store_record<FMT>(tok, first + i, token, (uint32_t)cluster, rbits, residue);
-                rb_sum += rbits;
-                if (token == 0 && j != 0)
-                    zero_tokens += 1ull << (10 * (cluster - coef_cl_lo)); /* at most 24 x 32 per thread and group */
-                else
-                    atomicAdd(&s_hist[cluster * kHistW + (int)min(token, (uint32_t)kHistW - 1u)], 1u);
             }
         }
         goff += strip_total;

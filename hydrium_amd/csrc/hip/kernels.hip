@@ -611,6 +611,7 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
 
         /* ---------------- phase B: column DCT, quantise (in place in LDS), LF ints, non-zero bitmaps ---------------- */
         unsigned long long msk[3] = {0, 0, 0}; /* per channel X, Y, B: non-zero coefficients by zig-zag position */
+        int32_t lf_int[3] = {0, 0, 0};
         if (cb < gbw) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -658,13 +659,19 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                 }
                 /* 32-bit offsets from one uniform base: the loads take an SGPR base and a VGPR offset, no 64-bit address arithmetic */
                 const char *const nib = (const char *)&kNibbleMasks.m[0][0][0];
-                const unsigned long long mine = *(const unsigned long long *)(nib + (nib_row | nlo)) |
-                                                *(const unsigned long long *)(nib + (nib_row | 128u | nhi));
-                const uint32_t lo = or_reduce8((uint32_t)mine), hi = or_reduce8((uint32_t)(mine >> 32));
+                /* the loaded masks are first used after the loop: the next channel's transform runs while they travel */
+                msk[c] = *(const unsigned long long *)(nib + (nib_row | nlo)) | *(const unsigned long long *)(nib + (nib_row | 128u | nhi));
+                lf_int[c] = (int32_t)(v[0] * kLfShift[c]); /* LF int: trunc(dc * shift[c]) (encoder.c:573,582) */
+            }
+            if (kh == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    job.dc[(size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH + (size_t)((py0 >> 3) + s) * HYDK_DC_PITCH + (px0 >> 3) + cb] = lf_int[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) { /* the block's bitmap = OR over its eight threads */
+                const uint32_t lo = or_reduce8((uint32_t)msk[c]), hi = or_reduce8((uint32_t)(msk[c] >> 32));
                 msk[c] = ((unsigned long long)hi << 32) | lo;
-                if (kh == 0) /* LF int: trunc(dc * shift[c]) (encoder.c:573,582) */
-                    job.dc[(size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH + (size_t)((py0 >> 3) + s) * HYDK_DC_PITCH +
-                           (px0 >> 3) + cb] = (int32_t)(v[0] * kLfShift[c]);
             }
         }
         /* symbols per channel: the count symbol + coefficients up to the last non-zero one; visit order

@@ -414,9 +414,10 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
      * 33 values (no barrier needed before it reads them back: its own stores are ordered before its loads) */
     __shared__ uint32_t s_boff[33];
     __shared__ uint32_t s_rbits;                      /* residue bits of the group's symbols */
-    /* integer input cannot produce a token above 35 (see store_record): half the histogram suffices,
-     * which is what lets two of these workgroups fit beside an entropy-stage workgroup */
-    constexpr int kHistW = FMT == HYDK_FMT_F32 ? HYDK_ALPHABET : HYDK_ALPHABET / 2;
+    /* integer input cannot produce a token above 35 (see store_record): 40 bins per cluster suffice.  LDS is
+     * handed out in granules of 1280 bytes (measured: a 33 284-byte build lost the co-residency a 33 232-byte
+     * one has): at <= 26 granules two of these workgroups fit beside an entropy-stage workgroup (75 granules) */
+    constexpr int kHistW = FMT == HYDK_FMT_F32 ? HYDK_ALPHABET : 40;
     __shared__ uint32_t s_hist[HYDK_MAX_CLUSTERS * kHistW];
     __shared__ uint16_t s_lut8[256];
     __shared__ uint8_t s_nnz3[64];                    /* coefficient-count context offset (encoder.c:60-66) mod 3 */
@@ -503,11 +504,7 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
             const int x0 = px0 + ab * 8;
             const bool row_ok = s * 8 + ar < gh;
             if (fast) {
-                uint32_t w[kWords];
-#pragma unroll
-                for (int k = 0; k < kWords; k++)
-                    w[k] = nxt[k];
-                prefetch(s + 1);
+                uint32_t(&w)[kWords] = nxt; /* this strip's pixels, fetched a strip ago */
                 /* which form of the transfer curve this wavefront's 16-bit samples need (wave-uniform) */
                 int curve = kCurveBoth;
                 if (FMT == HYDK_FMT_U16 && !LUTS) {
@@ -553,6 +550,9 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                     for (int i = 0; i < 8; i++)
                         xv[i] = yv[i] = bv[i] = 0.0f;
                 }
+                /* the next strip's pixels travel during the transforms and the token phase; issued only now, they
+                 * take the registers this strip's pixels have just left */
+                prefetch(s + 1);
             } else {
                 const int nvalid = row_ok ? min(8, gw - ab * 8) : 0;
 #pragma unroll

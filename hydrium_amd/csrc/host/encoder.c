@@ -986,6 +986,43 @@ HYDRIUM_EXPORT HYDStatusCode hyd_set_suggested_icc_profile(HYDEncoder *e, const 
  * — on other GPUs of the node, or by several contexts — into one frame.  This is the same
  * assemble_frame() hyd_send_tile ends in; it touches no GPU.
  * ------------------------------------------------------------------------------------------- */
+/* Frame buffers handed to the callers of hydamd_frame_from_*: the last large one that came back through
+ * hydamd_free is kept for the next frame.  Its pages are mapped — a fresh 50 MB allocation is 8 ms of page
+ * faults, two thirds of what assembling a 16K frame costs.  One spare at most; hydamd_trim_cache() drops it. */
+#define LENT_MAX 8
+#define SPARE_MIN ((size_t)1 << 20)
+#define SPARE_MAX ((size_t)1 << 28)
+typedef struct LentBuf {
+    void *p;
+    size_t cap;
+} LentBuf;
+static pthread_mutex_t g_buf_lock = PTHREAD_MUTEX_INITIALIZER;
+static LentBuf g_lent[LENT_MAX], g_spare;
+
+static void take_spare_buffer(HydBits *b) {
+    pthread_mutex_lock(&g_buf_lock);
+    if (g_spare.p && !b->data) {
+        b->data = g_spare.p;
+        b->cap = g_spare.cap;
+        g_spare.p = NULL;
+        g_spare.cap = 0;
+    }
+    pthread_mutex_unlock(&g_buf_lock);
+}
+
+static void note_lent_buffer(void *p, size_t cap) {
+    if (cap < SPARE_MIN || cap > SPARE_MAX)
+        return;
+    pthread_mutex_lock(&g_buf_lock);
+    for (int i = 0; i < LENT_MAX; i++)
+        if (!g_lent[i].p) {
+            g_lent[i].p = p;
+            g_lent[i].cap = cap;
+            break;
+        }
+    pthread_mutex_unlock(&g_buf_lock);
+}
+
 static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
                             const uint32_t *tile_xy, const int32_t *const *dc, const HydAmdLfStream *lf, const uint32_t *freq,
                             const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
@@ -1002,6 +1039,8 @@ static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is
     LfgResult *res = calloc(lfg_count ? lfg_count : 1, sizeof(LfgResult));
     if (!ret && !res)
         ret = HYD_NOMEM;
+    if (!ret)
+        take_spare_buffer(&e->stream);
     if (!ret && write_header)
         ret = emit_file_header(e);
     if (!ret) {
@@ -1060,6 +1099,7 @@ static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is
         if (e->stream.data && !e->stream.failed) { /* the caller takes the stream's buffer itself (hydamd_free = free) */
             *out = e->stream.data;
             *out_len = e->stream.len;
+            note_lent_buffer(e->stream.data, e->stream.cap);
             e->stream.data = NULL;
             e->stream.len = e->stream.cap = 0;
         } else {
@@ -1201,7 +1241,24 @@ HYDRIUM_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write
     return ret;
 }
 
-HYDRIUM_EXPORT void hydamd_free(void *p) { free(p); }
+HYDRIUM_EXPORT void hydamd_free(void *p) {
+    if (!p)
+        return;
+    void *drop = p;
+    pthread_mutex_lock(&g_buf_lock);
+    for (int i = 0; i < LENT_MAX; i++)
+        if (g_lent[i].p == p) {
+            g_lent[i].p = NULL;
+            if (g_lent[i].cap > g_spare.cap) { /* keep the larger of the two */
+                drop = g_spare.p;
+                g_spare.p = p;
+                g_spare.cap = g_lent[i].cap;
+            }
+            break;
+        }
+    pthread_mutex_unlock(&g_buf_lock);
+    free(drop);
+}
 
 /* Release every device context parked by destroyed encoders (their device memory, pinned staging and
  * streams).  Encoders alive at the time keep theirs. */
@@ -1217,6 +1274,12 @@ HYDRIUM_EXPORT void hydamd_trim_cache(void) {
     pthread_mutex_unlock(&g_ctx_lock);
     for (int i = 0; i < n; i++)
         hydamd_destroy(victims[i]);
+    pthread_mutex_lock(&g_buf_lock);
+    void *spare = g_spare.p;
+    g_spare.p = NULL;
+    g_spare.cap = 0;
+    pthread_mutex_unlock(&g_buf_lock);
+    free(spare);
 }
 
 /* the CPU-only tests drive the same function through libhydrium_hosttest.so */

@@ -275,11 +275,15 @@ HYDAMD_EXPORT int hydamd_frame_from_streams(const HYDImageMetadata *md, int writ
                                             const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
                                             const uint8_t *payload, size_t payload_len, const uint8_t *icc,
                                             size_t icc_size, uint8_t **out, size_t *out_len, const char **err);
+/* Releases a buffer returned by hydamd_frame_from_*.  The library may keep the last large one for the next
+ * frame it assembles (mapped pages: a fresh 50 MB buffer costs 8 ms of page faults); at most one,
+ * hydamd_trim_cache() lets go of it. */
 HYDAMD_EXPORT void hydamd_free(void *p);
 
 /* hyd_encoder_destroy parks its device context (device memory, pinned staging, streams) for the next
  * encoder of the same shape instead of freeing it — up to HYDAMD_CONTEXT_CACHE contexts (default 4) and
- * HYDAMD_CONTEXT_CACHE_MB megabytes (default 8192) per process.  This releases whatever is parked. */
+ * HYDAMD_CONTEXT_CACHE_MB megabytes (default 8192) per process.  This releases whatever is parked, and the spare
+ * frame buffer hydamd_free may have kept. */
 HYDAMD_EXPORT void hydamd_trim_cache(void);
 
 /* ---- optional per-kernel timing with HIP events on the context's stream ---- */

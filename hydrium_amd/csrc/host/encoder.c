@@ -400,9 +400,12 @@ done:
     return ret;
 }
 
+static void take_spare_buffer(HydBits *b); /* below, with the other spare-buffer functions */
+
 static int emit_file_header(HYDEncoder *e) {
     if (e->wrote_header)
         return 0;
+    take_spare_buffer(&e->stream);
     int ret = hyd_write_file_header(&e->stream, e->metadata.width, e->metadata.height, e->level10, e->icc, e->icc_size,
                                     &e->error);
     if (ret) {
@@ -565,6 +568,82 @@ HYDRIUM_EXPORT HYDEncoder *hyd_encoder_new(void) {
     return e;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Spare stream buffers.  A frame is assembled in a growable buffer of its size (12 MB for 8K, 50 MB for
+ * 16K); fresh from malloc that is 2-8 ms of page faults per frame.  Buffers of destroyed encoders, and
+ * frame buffers that come back through hydamd_free, are kept (mapped) for the next frame instead: at most
+ * SPARE_SLOTS of them, each between 1 MB and 256 MB; hydamd_trim_cache() drops them.
+ * ------------------------------------------------------------------------------------------- */
+#define LENT_MAX 8
+#define SPARE_SLOTS 4
+#define SPARE_MIN ((size_t)1 << 20)
+#define SPARE_MAX ((size_t)1 << 28)
+typedef struct LentBuf {
+    void *p;
+    size_t cap;
+} LentBuf;
+static pthread_mutex_t g_buf_lock = PTHREAD_MUTEX_INITIALIZER;
+static LentBuf g_lent[LENT_MAX], g_spare[SPARE_SLOTS];
+
+/* an empty stream takes the largest spare buffer */
+static void take_spare_buffer(HydBits *b) {
+    if (b->data)
+        return;
+    pthread_mutex_lock(&g_buf_lock);
+    int best = -1;
+    for (int i = 0; i < SPARE_SLOTS; i++)
+        if (g_spare[i].p && (best < 0 || g_spare[i].cap > g_spare[best].cap))
+            best = i;
+    if (best >= 0) {
+        b->data = g_spare[best].p;
+        b->cap = g_spare[best].cap;
+        g_spare[best].p = NULL;
+        g_spare[best].cap = 0;
+    }
+    pthread_mutex_unlock(&g_buf_lock);
+}
+
+/* keeps p (returns 1) in a free slot or in place of a smaller spare, which is freed */
+static int offer_spare_buffer(void *p, size_t cap) {
+    if (!p || cap < SPARE_MIN || cap > SPARE_MAX)
+        return 0;
+    void *drop = NULL;
+    int kept = 0, smallest = 0;
+    pthread_mutex_lock(&g_buf_lock);
+    for (int i = 0; i < SPARE_SLOTS && !kept; i++) {
+        if (!g_spare[i].p) {
+            g_spare[i].p = p;
+            g_spare[i].cap = cap;
+            kept = 1;
+        } else if (g_spare[i].cap < g_spare[smallest].cap) {
+            smallest = i;
+        }
+    }
+    if (!kept && g_spare[smallest].cap < cap) {
+        drop = g_spare[smallest].p;
+        g_spare[smallest].p = p;
+        g_spare[smallest].cap = cap;
+        kept = 1;
+    }
+    pthread_mutex_unlock(&g_buf_lock);
+    free(drop);
+    return kept;
+}
+
+/* remember the capacity of a buffer that leaves through *out, for when it comes back through hydamd_free */
+static void note_lent_buffer(void *p, size_t cap) {
+    if (cap < SPARE_MIN || cap > SPARE_MAX)
+        return;
+    pthread_mutex_lock(&g_buf_lock);
+    for (int i = 0; i < LENT_MAX; i++)
+        if (!g_lent[i].p) {
+            g_lent[i].p = p;
+            g_lent[i].cap = cap;
+            break;
+        }
+    pthread_mutex_unlock(&g_buf_lock);
+}
+
 HYDRIUM_EXPORT HYDStatusCode hyd_encoder_destroy(HYDEncoder *e) {
     if (!e)
         return HYD_OK;
@@ -573,6 +652,8 @@ HYDRIUM_EXPORT HYDStatusCode hyd_encoder_destroy(HYDEncoder *e) {
         ctx_release(e->dev, e->dev_slots, e->dev_linear, !e->dev_failed);
         TRACE("release device context", t0);
     }
+    if (offer_spare_buffer(e->stream.data, e->stream.cap))
+        e->stream.data = NULL;
     hb_free(&e->stream);
     free(e->icc);
     free(e->sent);
@@ -986,43 +1067,6 @@ HYDRIUM_EXPORT HYDStatusCode hyd_set_suggested_icc_profile(HYDEncoder *e, const 
  * — on other GPUs of the node, or by several contexts — into one frame.  This is the same
  * assemble_frame() hyd_send_tile ends in; it touches no GPU.
  * ------------------------------------------------------------------------------------------- */
-/* Frame buffers handed to the callers of hydamd_frame_from_*: the last large one that came back through
- * hydamd_free is kept for the next frame.  Its pages are mapped — a fresh 50 MB allocation is 8 ms of page
- * faults, two thirds of what assembling a 16K frame costs.  One spare at most; hydamd_trim_cache() drops it. */
-#define LENT_MAX 8
-#define SPARE_MIN ((size_t)1 << 20)
-#define SPARE_MAX ((size_t)1 << 28)
-typedef struct LentBuf {
-    void *p;
-    size_t cap;
-} LentBuf;
-static pthread_mutex_t g_buf_lock = PTHREAD_MUTEX_INITIALIZER;
-static LentBuf g_lent[LENT_MAX], g_spare;
-
-static void take_spare_buffer(HydBits *b) {
-    pthread_mutex_lock(&g_buf_lock);
-    if (g_spare.p && !b->data) {
-        b->data = g_spare.p;
-        b->cap = g_spare.cap;
-        g_spare.p = NULL;
-        g_spare.cap = 0;
-    }
-    pthread_mutex_unlock(&g_buf_lock);
-}
-
-static void note_lent_buffer(void *p, size_t cap) {
-    if (cap < SPARE_MIN || cap > SPARE_MAX)
-        return;
-    pthread_mutex_lock(&g_buf_lock);
-    for (int i = 0; i < LENT_MAX; i++)
-        if (!g_lent[i].p) {
-            g_lent[i].p = p;
-            g_lent[i].cap = cap;
-            break;
-        }
-    pthread_mutex_unlock(&g_buf_lock);
-}
-
 static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is_last, size_t lfg_count,
                             const uint32_t *tile_xy, const int32_t *const *dc, const HydAmdLfStream *lf, const uint32_t *freq,
                             const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
@@ -1040,7 +1084,7 @@ static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is
     if (!ret && !res)
         ret = HYD_NOMEM;
     if (!ret)
-        take_spare_buffer(&e->stream);
+        take_spare_buffer(&e->stream); /* also when no header is written */
     if (!ret && write_header)
         ret = emit_file_header(e);
     if (!ret) {
@@ -1244,20 +1288,17 @@ HYDRIUM_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write
 HYDRIUM_EXPORT void hydamd_free(void *p) {
     if (!p)
         return;
-    void *drop = p;
+    size_t cap = 0;
     pthread_mutex_lock(&g_buf_lock);
     for (int i = 0; i < LENT_MAX; i++)
         if (g_lent[i].p == p) {
             g_lent[i].p = NULL;
-            if (g_lent[i].cap > g_spare.cap) { /* keep the larger of the two */
-                drop = g_spare.p;
-                g_spare.p = p;
-                g_spare.cap = g_lent[i].cap;
-            }
+            cap = g_lent[i].cap;
             break;
         }
     pthread_mutex_unlock(&g_buf_lock);
-    free(drop);
+    if (!offer_spare_buffer(p, cap))
+        free(p);
 }
 
 /* Release every device context parked by destroyed encoders (their device memory, pinned staging and
@@ -1274,12 +1315,16 @@ HYDRIUM_EXPORT void hydamd_trim_cache(void) {
     pthread_mutex_unlock(&g_ctx_lock);
     for (int i = 0; i < n; i++)
         hydamd_destroy(victims[i]);
+    void *spares[SPARE_SLOTS];
     pthread_mutex_lock(&g_buf_lock);
-    void *spare = g_spare.p;
-    g_spare.p = NULL;
-    g_spare.cap = 0;
+    for (int i = 0; i < SPARE_SLOTS; i++) {
+        spares[i] = g_spare[i].p;
+        g_spare[i].p = NULL;
+        g_spare[i].cap = 0;
+    }
     pthread_mutex_unlock(&g_buf_lock);
-    free(spare);
+    for (int i = 0; i < SPARE_SLOTS; i++)
+        free(spares[i]);
 }
 
 /* the CPU-only tests drive the same function through libhydrium_hosttest.so */

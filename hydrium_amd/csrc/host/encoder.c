@@ -39,6 +39,7 @@
  *     "I "[i - 42] with i = 41 (libhydrium.c:219-224), 4 GB past the literal, and crashes.
  */
 #define _POSIX_C_SOURCE 200809L /* clock_gettime under -std=c99 */
+#include <malloc.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -574,16 +575,15 @@ HYDRIUM_EXPORT HYDEncoder *hyd_encoder_new(void) {
  * frame buffers that come back through hydamd_free, are kept (mapped) for the next frame instead: at most
  * SPARE_SLOTS of them, each between 1 MB and 256 MB; hydamd_trim_cache() drops them.
  * ------------------------------------------------------------------------------------------- */
-#define LENT_MAX 8
 #define SPARE_SLOTS 4
 #define SPARE_MIN ((size_t)1 << 20)
 #define SPARE_MAX ((size_t)1 << 28)
-typedef struct LentBuf {
+typedef struct SpareBuf {
     void *p;
     size_t cap;
-} LentBuf;
+} SpareBuf;
 static pthread_mutex_t g_buf_lock = PTHREAD_MUTEX_INITIALIZER;
-static LentBuf g_lent[LENT_MAX], g_spare[SPARE_SLOTS];
+static SpareBuf g_spare[SPARE_SLOTS];
 
 /* an empty stream takes the largest spare buffer */
 static void take_spare_buffer(HydBits *b) {
@@ -628,20 +628,6 @@ static int offer_spare_buffer(void *p, size_t cap) {
     pthread_mutex_unlock(&g_buf_lock);
     free(drop);
     return kept;
-}
-
-/* remember the capacity of a buffer that leaves through *out, for when it comes back through hydamd_free */
-static void note_lent_buffer(void *p, size_t cap) {
-    if (cap < SPARE_MIN || cap > SPARE_MAX)
-        return;
-    pthread_mutex_lock(&g_buf_lock);
-    for (int i = 0; i < LENT_MAX; i++)
-        if (!g_lent[i].p) {
-            g_lent[i].p = p;
-            g_lent[i].cap = cap;
-            break;
-        }
-    pthread_mutex_unlock(&g_buf_lock);
 }
 
 HYDRIUM_EXPORT HYDStatusCode hyd_encoder_destroy(HYDEncoder *e) {
@@ -1143,7 +1129,6 @@ static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is
         if (e->stream.data && !e->stream.failed) { /* the caller takes the stream's buffer itself (hydamd_free = free) */
             *out = e->stream.data;
             *out_len = e->stream.len;
-            note_lent_buffer(e->stream.data, e->stream.cap);
             e->stream.data = NULL;
             e->stream.len = e->stream.cap = 0;
         } else {
@@ -1288,16 +1273,8 @@ HYDRIUM_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write
 HYDRIUM_EXPORT void hydamd_free(void *p) {
     if (!p)
         return;
-    size_t cap = 0;
-    pthread_mutex_lock(&g_buf_lock);
-    for (int i = 0; i < LENT_MAX; i++)
-        if (g_lent[i].p == p) {
-            g_lent[i].p = NULL;
-            cap = g_lent[i].cap;
-            break;
-        }
-    pthread_mutex_unlock(&g_buf_lock);
-    if (!offer_spare_buffer(p, cap))
+    /* every buffer that leaves through *out is a malloc block: the allocator knows how much of it is usable */
+    if (!offer_spare_buffer(p, malloc_usable_size(p)))
         free(p);
 }
 
@@ -1338,7 +1315,7 @@ HYDT_EXPORT int hydt_frame_from_stages(const HYDImageMetadata *md, int write_hea
     return hydamd_frame_from_results(md, write_header, is_last, lfg_count, tile_xy, dc, freq, alphabet, group_bits,
                                      max_alphabet, payload, payload_len, icc, icc_size, out, out_len, err);
 }
-HYDT_EXPORT void hydt_free(void *p) { free(p); }
+HYDT_EXPORT void hydt_free(void *p) { hydamd_free(p); }
 
 /* depth-limited code lengths of the host prefix coder (prefix.c), for comparison with the device's */
 HYDT_EXPORT int hydt_code_lengths(const uint32_t *freq, uint32_t *lengths, uint32_t n, int max_depth) {

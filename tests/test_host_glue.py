@@ -280,3 +280,19 @@ def test_frame_from_blobs_single_process_and_malformed_input(ref_lib, image):
     huge = bytearray(blobs[1])
     huge[64 + 16 + 36 + 12 + 256 + 4608 + 16:64 + 16 + 36 + 12 + 256 + 4608 + 20] = (1 << 30).to_bytes(4, "little")  # lf.offset beyond the blob
     fails([blobs[0], bytes(huge)])
+
+
+def test_frame_buffers_are_reused_without_changing_a_byte(ref_lib, image):
+    """Frames above 1 MB leave through a buffer the library may keep when it comes back (hydamd_free) and hand to the
+    next frame: a larger frame, a smaller one and the first again give the reference's bytes each time, before and
+    after hydamd_trim_cache."""
+    big = image("noise", 1024, 768, 8)       # about 1.4 MB of codestream
+    small = image("noise", 640, 512, 8)
+    tiny = image("photo", 300, 200, 8)       # below the size the library keeps
+    want = {id(a): api.encode_image(ref_lib, a, out_buf_size=1 << 22) for a in (big, small, tiny)}
+    assert len(want[id(big)]) > 1 << 20
+    for a in (big, small, tiny, big, small):
+        assert glue.encode_with_oracle_stages(a) == want[id(a)]
+    glue._lib().hydamd_trim_cache()
+    for a in (small, big):
+        assert glue.encode_with_oracle_stages(a) == want[id(a)]

@@ -335,11 +335,13 @@ extern "C" __attribute__((visibility("default"))) int hydamd_debug_phase_ticks(u
  *
  * Per strip (32 varblocks x 3 channels):
  *   A  thread (row r, block b): 8 pixels -> XYB in registers -> three 8-point row DCTs -> LDS
- *   B  thread (block cb, horizontal frequency kh): three 8-point column DCTs, quantisation; the
- *      24 quantised coefficients stay in registers; 8-lane OR gives the block's non-zero bitmap
- *   C1 one wave prefix-sums the 96 per-(block, channel) symbol counts
- *   C2 the SAME threads emit the symbols of the coefficients they hold: position inside the
- *      block's run is the zig-zag index, contexts come from the bitmap by popcount
+ *   B  thread (block cb, horizontal frequency kh): three 8-point column DCTs, quantisation, the
+ *      quantised coefficients back into the thread's own LDS column; 8-lane OR gives the block's
+ *      non-zero bitmap; one thread per block leaves a descriptor per (block, channel) in LDS
+ *   C1 every wave prefix-sums the 32 per-block symbol counts
+ *   C2 the strip's symbol stream is cut into 256 equal runs; a thread finds its run's first
+ *      (block, channel, zig-zag position) by binary search and walks it, carrying the contexts'
+ *      state from symbol to symbol
  * Token order inside a group is block raster, channels Y, X, B (encoder.c:707-745), which the
  * strip order + prefix sum reproduces.  The next strip's pixels are in flight during B and C.
  * ======================================================================================== */

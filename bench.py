@@ -398,7 +398,10 @@ def main():
     while len(ctxs) % per:
         per -= 1
     ngroups = len(ctxs) // per
-    xstate = {"cap": 0, "big": [None] * ngroups, "rows": [None] * ngroups, "work": [None] * ngroups}
+    # two blob buffers per group, used alternately: a context's next frame does not wait for the gather of its previous one
+    # (queued behind the other contexts' gathers, it ended after that frame should have started) but for the one before
+    xstate = {"cap": 0, "big": [[None, None] for _ in range(ngroups)], "rows": [None] * ngroups,
+              "work": [[None, None] for _ in range(ngroups)]}
     xt = [0.0, 0.0]  # host seconds spent issuing the export + gather
     xstream = torch.cuda.Stream() if use_dist else None
 
@@ -409,29 +412,32 @@ def main():
             ctx.encode_image_tensor(img)
             return ctx
         j = k // per
+        half = (i // len(ctxs)) & 1
         with torch.cuda.stream(ext[k]):
-            if xstate["work"][j] is not None:
-                xstate["work"][j].wait()  # device-side: this stream waits until the group's previous gather has read the blobs
+            if xstate["work"][j][half] is not None:
+                xstate["work"][j][half].wait()  # device-side: this stream waits until the gather that last read this buffer is done
             ctx.encode_image_tensor(img)
             t_b = time.perf_counter()
-            ctx.export_frame(lfg, xstate["big"][j][k % per])
+            ctx.export_frame(lfg, xstate["big"][j][half][k % per])
             xt[1] += time.perf_counter() - t_b
         if k % per == per - 1:  # the group's last frame is queued: one collective for all of its blobs
             t_b = time.perf_counter()
             for q in range(j * per, j * per + per):
                 xstream.wait_stream(ext[q])
             with torch.cuda.stream(xstream):
-                xstate["work"][j] = dist.gather(xstate["big"][j].view(-1), gather_list=xstate["rows"][j], dst=0, async_op=True)
+                xstate["work"][j][half] = dist.gather(xstate["big"][j][half].view(-1), gather_list=xstate["rows"][j], dst=0,
+                                                      async_op=True)
             xt[1] += time.perf_counter() - t_b
         return ctx
 
     def drain():
-        for j, w in enumerate(xstate["work"]):
-            if w is not None:
-                for q in range(j * per, j * per + per):
-                    with torch.cuda.stream(ext[q]):
-                        w.wait()
-                xstate["work"][j] = None
+        for j, pair in enumerate(xstate["work"]):
+            for half, w in enumerate(pair):
+                if w is not None:
+                    for q in range(j * per, j * per + per):
+                        with torch.cuda.stream(ext[q]):
+                            w.wait()
+                    pair[half] = None
 
     # initialisation, not measurement: every context codes one frame once so that its freshly
     # allocated buffers have been touched before anything is timed; then the W warm-up steps
@@ -451,7 +457,7 @@ def main():
         xstate["cap"] = (int(int(capt.item()) * 1.25) + 65536 + 15) & ~15
         del probe
         for j in range(ngroups):
-            xstate["big"][j] = torch.zeros((per, xstate["cap"]), dtype=torch.uint8, device=img.device)
+            xstate["big"][j] = [torch.zeros((per, xstate["cap"]), dtype=torch.uint8, device=img.device) for _ in range(2)]
             if rank == 0:
                 xstate["rows"][j] = [torch.empty(per * xstate["cap"], dtype=torch.uint8, device=img.device) for _ in range(world)]
     for i in range(args.warmup):

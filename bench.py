@@ -27,7 +27,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # frames in flight live on separate HIP streams; let them map to separate hardware queues
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")  # 16 contexts + RCCL's stream + the collective stream + the default stream, each on a queue of its own
+# 16 contexts + RCCL's stream + the default stream, each on a hardware queue of its own.  Measured in a world of one: an
+# auxiliary stream that lands on a context's queue costs a third of the rate (18 queues: 83 instead of 122 Gpixel/s), and
+# so did the extra stream the per-frame gather used to be issued under with 14 contexts or 22-32 queues; 24 queues: 115.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -422,9 +425,11 @@ def main():
             xt[1] += time.perf_counter() - t_b
         if k % per == per - 1:  # the group's last frame is queued: one collective for all of its blobs
             t_b = time.perf_counter()
-            for q in range(j * per, j * per + per):
-                xstream.wait_stream(ext[q])
-            with torch.cuda.stream(xstream):
+            if per > 1:
+                for q in range(j * per, j * per + per):
+                    xstream.wait_stream(ext[q])
+            # one frame per collective: issued under the context's own stream (RCCL's stream waits for it through an event)
+            with torch.cuda.stream(xstream if per > 1 else ext[k]):
                 xstate["work"][j][half] = dist.gather(xstate["big"][j][half].view(-1), gather_list=xstate["rows"][j], dst=0,
                                                       async_op=True)
             xt[1] += time.perf_counter() - t_b

@@ -1,0 +1,55 @@
+"""Seeded fuzz of the drop-in API against the reference built from /root/reference (oracle/_ref, test
+infrastructure): ragged sizes, sample types, dark 16-bit content (mixed transfer-curve branches inside a wavefront),
+tile modes, layouts.  Not part of the test suite: a longer sweep for spare GPU minutes.
+usage: python scripts/fuzz_api_parity.py [cases] [seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from hydrium_amd import api, synth
+from oracle import refprobe
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+refprobe.build()
+ref = refprobe.reference_library()
+lib = api.Library()
+rng = np.random.default_rng(seed)
+kinds = ["photo", "smooth", "noise", "ramp", "black", "white"]
+bad = 0
+t0 = time.time()
+for case in range(cases):
+    w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 1100), rng.integers(2040, 2400)]))
+    h = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 1100)]))
+    depth = int(rng.choice([8, 16, 16, 32]))
+    kind = kinds[int(rng.integers(len(kinds)))]
+    lin = int(rng.integers(4) == 0)
+    if depth == 32:
+        w, h = min(w, 500), min(h, 500)
+        img = synth.make_image_f32(kind, w, h, seed=case + 1000 * seed)
+    else:
+        img = synth.make_image(kind, w, h, depth, seed=case + 1000 * seed)
+        if depth == 16 and rng.integers(2):
+            # dark content: part of the picture at or below the transfer curve's branch point (2650)
+            img = (img >> int(rng.integers(1, 6))).astype(np.uint16)
+            if rng.integers(2):
+                img[::3] = 0
+        img = np.ascontiguousarray(img)
+    kw = dict(linear_light=lin)
+    mode = int(rng.integers(4))
+    if mode == 1:
+        kw.update(shift_x=int(rng.integers(0, 4)), shift_y=int(rng.integers(0, 4)))
+    elif mode == 2:
+        kw.update(layout="planar")
+    elif mode == 3 and depth != 32:
+        kw.update(layout="flipped")
+    want = api.encode_image(ref, img, out_buf_size=1 << 22, **kw)
+    got = api.encode_image(lib, img, out_buf_size=1 << 22, **kw)
+    if got != want:
+        bad += 1
+        print("MISMATCH", case, kind, w, h, depth, kw, len(got), len(want), flush=True)
+print(f"{cases} cases, seed {seed}: {bad} mismatches, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)

@@ -64,6 +64,7 @@ hipError_t launch_frame_begin(const HydkLfJob *host_jobs, HydkLfJob *d_jobs, int
                               hipStream_t stream);
 hipError_t launch_publish(const uint64_t *total, uint64_t *h_total, const unsigned long long *lf_total,
                           unsigned long long *h_lf_total, const uint32_t *status, uint32_t *h_status, hipStream_t stream);
+hipError_t transform_footprint(int fmt, int xmode, int *lds_bytes, int *registers);
 hipError_t launch_scan(const uint32_t *group_bits, int count, uint64_t *offsets, uint64_t *total, uint8_t *payload,
                        uint64_t payload_cap, int clear_shared_words, uint32_t *status, hipStream_t stream);
 hipError_t launch_pack(const uint32_t *bitbuf, uint32_t bit_pitch_words, const uint32_t *group_bits, const uint64_t *offsets,
@@ -1530,6 +1531,14 @@ int hydamd_read_lf_streams(HydAmdContext *ctx, int first_slot, int count, HydAmd
     for (int i = 0; i < count; i++)
         if (dst[i].error)
             return fail(ctx, ST_INTERNAL_ERROR, "LF code construction failed on the device");
+    return ST_OK;
+}
+
+int hydamd_debug_transform_footprint(HydAmdContext *ctx, int sample_fmt, int *lds_bytes, int *registers) {
+    if (!ctx || !lds_bytes || !registers || sample_fmt < 0 || sample_fmt > 2)
+        return ST_API_ERROR;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hydk::transform_footprint(sample_fmt, ctx->use_luts, lds_bytes, registers));
     return ST_OK;
 }
 

@@ -1789,6 +1789,36 @@ hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt
     return hipGetLastError();
 }
 
+hipError_t transform_footprint(int fmt, int xmode, int *lds_bytes, int *registers) {
+    const void *fn = nullptr;
+#define HYDK_K1_PTR(FMT, XM) fn = (const void *)k_transform_tokenize<FMT, XM>
+    if (fmt == HYDK_FMT_F32)
+        HYDK_K1_PTR(HYDK_FMT_F32, kXybIeeeDiv);
+    else if (fmt == HYDK_FMT_U8) {
+        if (xmode == kXybFastRcp)
+            HYDK_K1_PTR(HYDK_FMT_U8, kXybFastRcp);
+        else if (xmode == kXybIeeeDiv)
+            HYDK_K1_PTR(HYDK_FMT_U8, kXybIeeeDiv);
+        else
+            HYDK_K1_PTR(HYDK_FMT_U8, kXybGather);
+    } else {
+        if (xmode == kXybFastRcp)
+            HYDK_K1_PTR(HYDK_FMT_U16, kXybFastRcp);
+        else if (xmode == kXybIeeeDiv)
+            HYDK_K1_PTR(HYDK_FMT_U16, kXybIeeeDiv);
+        else
+            HYDK_K1_PTR(HYDK_FMT_U16, kXybGather);
+    }
+#undef HYDK_K1_PTR
+    hipFuncAttributes attr;
+    const hipError_t e = hipFuncGetAttributes(&attr, fn);
+    if (e == hipSuccess) {
+        *lds_bytes = (int)attr.sharedSizeBytes;
+        *registers = attr.numRegs;
+    }
+    return e;
+}
+
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int first_slot,
                          int num_slots, uint32_t alpha_floor, const uint32_t *alpha_floor_dev, hipStream_t stream) {
     hipLaunchKernelGGL(k_build_tables, dim3(num_slots), dim3(kThreads), 0, stream, hist, tabs, alpha_max, nclusters,

@@ -119,6 +119,8 @@ def dll(path: Optional[str] = None):
         d.hydamd_lf_payload_device.restype = vp
         d.hydamd_lf_payload_device.argtypes = [vp]
         d.hydamd_read_lf_payload.argtypes = [vp, vp, sz]
+        d.hydamd_debug_transform_footprint.restype = C.c_int
+        d.hydamd_debug_transform_footprint.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         d.hydamd_debug_lf_code.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         d.hydamd_profile.argtypes = [vp, i]
         d.hydamd_profile_read.argtypes = [vp, vp, vp]
@@ -399,6 +401,12 @@ class DeviceContext:
 
         cap = self.max_lf_groups * LF_BITWORDS * 4
         return self._device_view("lf", int(self.d.hydamd_lf_payload_device(self.h) or 0), cap)[: self.lf_payload_size()]
+
+    def transform_footprint(self, sample_fmt: int):
+        """(static LDS bytes, registers per thread) of the transform kernel instance serving `sample_fmt` (0 u8, 1 u16, 2 f32)."""
+        lds, regs = C.c_int(0), C.c_int(0)
+        self._ck(self.d.hydamd_debug_transform_footprint(self.h, int(sample_fmt), C.byref(lds), C.byref(regs)))
+        return lds.value, regs.value
 
     def debug_lf_code(self, hist: np.ndarray):
         """Device code construction for one histogram over the compact token space -> (lengths, codes, alphabet, error)."""

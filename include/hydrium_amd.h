@@ -182,6 +182,11 @@ HYDAMD_EXPORT int hydamd_debug_lf_code(HydAmdContext *ctx, const uint32_t hist[H
                                        uint8_t lengths[HYDAMD_LF_CODES], uint32_t codes[HYDAMD_LF_CODES],
                                        uint32_t *alphabet, uint32_t *error);
 
+/* Resource footprint of the transform kernel instance that serves `sample_fmt` on this context (the XYB mode the
+ * context runs): static LDS bytes and registers per thread.  LDS is allocated in granules of 1280 bytes and two
+ * transform workgroups share a CU with one entropy-stage workgroup only at <= 26 granules: a test holds that line. */
+HYDAMD_EXPORT int hydamd_debug_transform_footprint(HydAmdContext *ctx, int sample_fmt, int *lds_bytes, int *registers);
+
 /* ---- parity / debug read-backs ---- */
 HYDAMD_EXPORT int hydamd_read_symbol_counts(HydAmdContext *ctx, int slot, uint32_t counts[HYDAMD_GROUPS_PER_LFG]);
 /* token records of one group: lo = token | cluster<<8 | residue_bits<<16, hi = residue */

@@ -238,3 +238,16 @@ def test_every_cluster_scheme_on_the_device(image, num_presets, scheme, form):
             assert payload[at:at + len(res.stream)] == res.stream, f"sections of slot {slot}"
             at += len(res.stream)
         assert at == len(payload)
+
+
+def test_transform_kernel_keeps_its_place_beside_the_entropy_stage():
+    """A performance invariant with a cliff behind it: LDS comes in granules of 1280 bytes, a CU has 128 of them and a
+    lane-form entropy workgroup takes 75 — two transform workgroups fit beside it only at <= 26 granules each (a build
+    52 bytes over lost 4 % of the pipelined rate), and four of them need <= 128 registers per thread."""
+    from hydrium_amd import device
+
+    with device.DeviceContext(0, 1, 0) as ctx:
+        for fmt in (0, 1):  # the integer formats of every BASELINE config
+            lds, regs = ctx.transform_footprint(fmt)
+            assert 0 < lds <= 26 * 1280, (fmt, lds)
+            assert 0 < regs <= 128, (fmt, regs)

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
     /* integer input cannot produce a token above 35 (see store_record): 40 bins per cluster suffice.  LDS is
      * handed out in granules of 1280 bytes (measured: a 33 284-byte build lost the co-residency a 33 232-byte
      * one has): at <= 26 granules two of these workgroups fit beside an entropy-stage workgroup (75 granules) */
-    constexpr int kHistW = FMT == HYDK_FMT_F32 ? HYDK_ALPHABET : 40;
+    constexpr int kHistW = FMT == HYDK_FMT_F32 ? 72 : 40; /* float input: the (4,1,0) configuration ends at token 71 */
     __shared__ uint32_t s_hist[HYDK_MAX_CLUSTERS * kHistW];
     __shared__ uint16_t s_lut8[256];
     __shared__ uint8_t s_nnz3[64];                    /* coefficient-count context offset (encoder.c:60-66) mod 3 */

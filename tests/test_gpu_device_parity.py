@@ -247,7 +247,7 @@ def test_transform_kernel_keeps_its_place_beside_the_entropy_stage():
     from hydrium_amd import device
 
     with device.DeviceContext(0, 1, 0) as ctx:
-        for fmt in (0, 1):  # the integer formats of every BASELINE config
+        for fmt in (0, 1, 2):  # u8, u16, f32
             lds, regs = ctx.transform_footprint(fmt)
             assert 0 < lds <= 26 * 1280, (fmt, lds)
             assert 0 < regs <= 128, (fmt, regs)

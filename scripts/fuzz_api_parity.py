@@ -1,7 +1,7 @@
 """Seeded fuzz of the drop-in API against the reference built from /root/reference (oracle/_ref, test
 infrastructure): ragged sizes, sample types, dark 16-bit content (mixed transfer-curve branches inside a wavefront),
 tile modes, layouts.  Not part of the test suite: a longer sweep for spare GPU minutes.
-usage: python scripts/fuzz_api_parity.py [cases] [seed]"""
+usage: python scripts/fuzz_api_parity.py [cases] [seed] [large]"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ from oracle import refprobe
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+large = len(sys.argv) > 3 and sys.argv[3] == "large"  # several LF groups per frame: 2050-6200 px wide, up to 4200 high
 refprobe.build()
 ref = refprobe.reference_library()
 lib = api.Library()
@@ -24,6 +25,9 @@ t0 = time.time()
 for case in range(cases):
     w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 1100), rng.integers(2040, 2400)]))
     h = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 1100)]))
+    if large:
+        w = int(rng.integers(2050, 6200))
+        h = int(rng.choice([rng.integers(1, 300), rng.integers(2040, 4200)]))
     depth = int(rng.choice([8, 16, 16, 32]))
     kind = kinds[int(rng.integers(len(kinds)))]
     lin = int(rng.integers(4) == 0)

@@ -707,16 +707,19 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
         HYDK_PHASE_MARK(5);
 
         /* ---------------- phase C2: the strip's symbol stream, cut into 256 equal runs ----------------
-         * Thread t emits symbols [t * L, (t + 1) * L) of the strip, L = ceil(strip symbols / 256): it finds the
+         * Thread t emits one of 256 consecutive runs of the strip's symbols, equal in length up to one: it finds the
          * (block, channel, zig-zag position) its run starts at by a binary search over the block offsets, then WALKS
          * — the non-zero count still to come and the "previous coefficient was non-zero" flag of the contexts
          * (encoder.c:724-738) are carried from symbol to symbol instead of being recounted from the bitmap, and the
          * work is balanced over the workgroup whatever the blocks' sizes. */
         {
             overflowed = overflowed || goff + strip_total > job.tok_cap;
-            const uint32_t per = (strip_total + (uint32_t)kThreads - 1u) / (uint32_t)kThreads;
-            uint32_t p = (uint32_t)t * per;
-            const uint32_t pend = overflowed ? 0u : min(p + per, strip_total);
+            /* runs of floor(n / 256) symbols, the first n mod 256 threads one more: the longer runs sit in the first
+             * wavefronts, so the later ones leave the loop an iteration earlier */
+            static_assert(kThreads == 256, "run lengths are computed with shifts");
+            const uint32_t per = strip_total >> 8, extra = strip_total & 255u;
+            uint32_t p = (uint32_t)t * per + min((uint32_t)t, extra);
+            const uint32_t pend = overflowed ? 0u : p + per + ((uint32_t)t < extra ? 1u : 0u);
             if (p < pend) {
                 uint32_t b = 0;
 #pragma unroll

@@ -1,0 +1,671 @@
+/*
+ * assemble.hip — a frame put together where its sections are: on the GPU.
+ *
+ * What it replaces (file:line relative to /root/reference/src/libhydrium/): the closing part of
+ * hyd_encode_xyb_buffer — LF group sections around their coefficient streams (encoder.c:539-629 with the
+ * stream header of entropy.c:835-927), HFGlobal's histograms (encoder.c:959-967, entropy.c:303-369), the TOC
+ * (encoder.c:992-1005) and the concatenation of all sections behind the frame header (encoder.c:968-1005).
+ * The host used to do this from results read back piece by piece: 5.6 ms per 16384 x 16384 frame against
+ * 1.9 ms of kernels.  Here the input is the shard blobs as hydamd_export_frame leaves them in device
+ * memory (one per GPU that coded LF groups of the frame, gathered by RCCL or exported locally), the
+ * output the finished codestream in one buffer, and the host contributes a PLAN (hydk_assemble.h): the
+ * bytes that do not depend on the pixels.
+ *
+ *   k_asm_slots     one wavefront per LF group: checks its blob and slot record, writes the bits in front of
+ *                   the LF coefficient symbols (constant fields from the plan + alphabet sizes and prefix
+ *                   codes, hydk_sections.h) and the TOC sizes of its sections
+ *   k_asm_hfglobal  one workgroup: the ANS histograms of every cluster, each written by a thread at the bit
+ *                   offset a prefix sum gives it
+ *   k_asm_layout    one workgroup: TOC entries (same scheme), where every section goes, the frame's size
+ *   k_asm_copy      the frame as a list of PIECES, each the concatenation of up to three bit strings at a
+ *                   byte offset; every output word is composed from its piece's strings (funnel shifts)
+ *                   and stored once — a word that two pieces share is written byte by byte, so nothing is
+ *                   zeroed beforehand and nothing is ORed
+ *
+ * Frames of a single group are one bit-contiguous section (encoder.c:837-850,968-981 guards): they stay
+ * with the host assembler (hydamd_frame_from_blobs).
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../../include/hydrium_amd.h"
+#include "hydk_assemble.h"
+#include "hydk_common.h"
+#include "hydk_sections.h"
+
+#define ST_OK 0
+#define ST_NOMEM (-13)
+#define ST_API_ERROR (-14)
+#define ST_INTERNAL_ERROR (-15)
+
+namespace {
+
+constexpr int kHeadWords = 640;         /* bits in front of an LF group's symbols: <= 384 x 45 + fixed fields */
+constexpr int kHfgWords = 40 * 1024;    /* HFGlobal: <= 256 histograms of <= 73 words + the cluster map */
+constexpr int kTocWords = 18 * 1024;    /* <= 16579 entries of <= 32 bits */
+constexpr int kMaxPieces = 8 + HYDAMD_MAX_LF_GROUPS + HYDK_ASM_MAX_BLOBS;
+constexpr int kCopyBlocks = 1024;
+constexpr uint32_t kBlobMagic = 0x42445948u;
+
+struct Piece {
+    uint64_t dst, nbytes;
+    const uint32_t *src[3];
+    uint64_t nbits[3];
+};
+
+struct BlobArgs {
+    const uint8_t *p[HYDK_ASM_MAX_BLOBS];
+    uint64_t cap[HYDK_ASM_MAX_BLOBS];
+};
+
+struct Scratch { /* device pointers */
+    uint32_t *head;       /* [slots][kHeadWords] */
+    uint32_t *head_bits;  /* [slots] */
+    uint64_t *sizes;      /* [toc_n] section sizes in physical (TOC) order */
+    uint64_t *slot_hf;    /* [slots] bytes of each LF group's HF sections */
+    uint32_t *hfg;        /* [kHfgWords] */
+    uint32_t *toc;        /* [kTocWords] */
+    Piece *pieces;        /* [kMaxPieces] */
+    uint32_t *npieces;    /* [1] */
+    uint32_t *err;        /* [1] */
+    uint64_t *result;     /* [2] size, error */
+};
+
+__device__ __forceinline__ const HydkAsmPlan *plan_of(const uint8_t *plan) { return (const HydkAsmPlan *)plan; }
+
+/* ---- k_asm_slots: grid = LF groups of the frame (send order), block = 64 ---- */
+__global__ __launch_bounds__(64) void k_asm_slots(const uint8_t *__restrict__ planb, BlobArgs blobs, Scratch S) {
+    const HydkAsmPlan *plan = plan_of(planb);
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const HydkAsmSlot sl = ((const HydkAsmSlot *)(planb + plan->slots_off))[s];
+    __shared__ uint32_t s_head[kHeadWords];
+    __shared__ uint8_t s_len[HYDK_LF_CODES];
+    __shared__ uint32_t s_bits, s_err;
+    const uint8_t *blob = blobs.p[sl.blob];
+    const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)blob;
+    uint32_t e = 0;
+    const uint64_t cap = blobs.cap[sl.blob];
+    uint64_t lf_off = 0;
+    if (cap < sizeof(HydAmdBlobHeader) || h->magic != kBlobMagic || h->version != 1 || h->num_slots != plan->blob_slots[sl.blob] ||
+        sl.index >= h->num_slots) {
+        e |= HYDK_ASM_E_BLOB;
+    } else {
+        if (h->status & HYDAMD_BLOB_RETRY)
+            e |= HYDK_ASM_E_RETRY;
+        if (h->status & 1u)
+            e |= HYDK_ASM_E_NAN;
+        lf_off = sizeof(HydAmdBlobHeader) + (uint64_t)h->num_slots * sizeof(HydAmdBlobSlot);
+        const uint64_t hf_off = (lf_off + h->lf_bytes + 15ull) & ~15ull;
+        if (!e && (h->lf_coded != 1 || h->total_bytes > cap || h->lf_bytes > h->total_bytes || h->hf_bytes > h->total_bytes ||
+                   hf_off + h->hf_bytes != h->total_bytes))
+            e |= HYDK_ASM_E_BLOB;
+    }
+    const HydAmdBlobSlot *rec = (const HydAmdBlobSlot *)(blob + sizeof(HydAmdBlobHeader)) + sl.index;
+    if (!e) {
+        const uint64_t lf_end = (uint64_t)rec->lf.offset + (((uint64_t)rec->lf.bit_count + 7) >> 3);
+        if (rec->preset != sl.preset || rec->table_error || rec->lf.error || lf_end > h->lf_bytes || (rec->lf.offset & 3u) ||
+            rec->lf.alphabet < 1 || rec->lf.alphabet > HYDK_LF_RUN_BASE + 128u)
+            e |= HYDK_ASM_E_SLOT;
+    }
+    if (e) {
+        if (lane == 0) {
+            atomicOr(S.err, e);
+            S.head_bits[s] = 0;
+            S.slot_hf[s] = 0;
+            S.sizes[1 + s] = 0;
+        }
+        for (uint32_t g = lane; g < sl.ngroups; g += 64)
+            S.sizes[2 + plan->num_slots + sl.group_base + g] = 0;
+        return;
+    }
+    for (int i = lane; i < kHeadWords; i += 64)
+        s_head[i] = 0;
+    for (int i = lane; i < HYDK_LF_CODES; i += 64)
+        s_len[i] = rec->lf.lengths[i];
+    if (lane == 0)
+        s_err = 0;
+    __syncthreads();
+    if (lane == 0) {
+        HydkSink sink = {s_head, 0, (uint64_t)kHeadWords * 32u, 0, 0};
+        const uint32_t *pre = (const uint32_t *)(planb + plan->lfpre_off);
+        for (uint32_t done = 0; done < plan->lfpre_bits; done += 32)
+            hks_put(&sink, pre[done >> 5], plan->lfpre_bits - done < 32 ? plan->lfpre_bits - done : 32);
+        const int ret = hydk_lf_prefix_codes(&sink, s_len, rec->lf.alphabet, rec->lf.run_pairs);
+        if (ret || sink.overflow)
+            s_err = HYDK_ASM_E_HEAD;
+        s_bits = sink.overflow ? 0u : (uint32_t)sink.pos;
+    }
+    __syncthreads();
+    const uint32_t head_bits = s_bits;
+    uint32_t *dst = S.head + (size_t)s * kHeadWords;
+    for (uint32_t i = lane; i < (head_bits + 31u) >> 5; i += 64)
+        dst[i] = s_head[i];
+    /* TOC sizes of this LF group's sections */
+    uint64_t hf = 0;
+    uint32_t bad = 0;
+    {
+        const uint32_t b = rec->group_bits[lane];
+        if ((uint32_t)lane < sl.ngroups) {
+            const uint64_t n = ((uint64_t)b + 7u) >> 3;
+            S.sizes[2 + plan->num_slots + sl.group_base + lane] = n;
+            hf = n;
+        } else if (b) {
+            bad = 1; /* a group the frame's geometry does not have */
+        }
+    }
+#pragma unroll
+    for (int d = 32; d; d >>= 1) {
+        hf += __shfl_xor(hf, d);
+        bad |= (uint32_t)__shfl_xor((int)bad, d);
+    }
+    if (lane == 0) {
+        const uint64_t sec_bits = (uint64_t)head_bits + rec->lf.bit_count + plan->tail_bits[sl.tail];
+        S.head_bits[s] = head_bits;
+        S.sizes[1 + s] = (sec_bits + 7) >> 3;
+        S.slot_hf[s] = hf;
+        const uint32_t ee = s_err | (bad ? HYDK_ASM_E_SIZE : 0u);
+        if (ee)
+            atomicOr(S.err, ee);
+    }
+}
+
+/* block-wide exclusive prefix sum over 256 threads; returns the thread's offset, *total the sum */
+__device__ __forceinline__ uint64_t block_scan256(uint64_t v, uint64_t *s_wave /* [4] */, uint64_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(inc, d);
+        if (lane >= d)
+            inc += t;
+    }
+    __syncthreads(); /* s_wave may still be read from an earlier call */
+    if (lane == 63)
+        s_wave[wave] = inc;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+    for (int w = 0; w < 4; w++) {
+        before += w < wave ? s_wave[w] : 0;
+        all += s_wave[w];
+    }
+    *total = all;
+    return before + inc - v;
+}
+
+__device__ __forceinline__ const HydAmdBlobSlot *slot_record(const uint8_t *planb, const BlobArgs &blobs, uint32_t s) {
+    const HydkAsmPlan *plan = plan_of(planb);
+    const HydkAsmSlot sl = ((const HydkAsmSlot *)(planb + plan->slots_off))[s];
+    return (const HydAmdBlobSlot *)(blobs.p[sl.blob] + sizeof(HydAmdBlobHeader)) + sl.index;
+}
+
+/* ---- k_asm_hfglobal: one workgroup of 256 ---- */
+__global__ __launch_bounds__(256) void k_asm_hfglobal(const uint8_t *__restrict__ planb, BlobArgs blobs, Scratch S) {
+    const HydkAsmPlan *plan = plan_of(planb);
+    __shared__ uint64_t s_wave[4];
+    __shared__ uint32_t s_max;
+    const int t = threadIdx.x;
+    if (*S.err) /* a blob could not be read: nothing below may follow its pointers */
+        return;
+    const uint32_t per = plan->clusters_per_preset, C = plan->num_presets * per;
+    if (t == 0)
+        s_max = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (uint32_t s = t; s < plan->num_slots; s += 256)
+        mx = max(mx, slot_record(planb, blobs, s)->running_max_alphabet);
+    if (mx)
+        atomicMax(&s_max, mx);
+    /* pass 1: how long each histogram is */
+    const uint32_t *freq = nullptr;
+    uint32_t alphabet = 0;
+    uint64_t nb = 0;
+    if ((uint32_t)t < C) {
+        const uint32_t p = (uint32_t)t / per, k = (uint32_t)t % per;
+        const uint32_t slot = ((const uint32_t *)(planb + plan->preset_slot_off))[p];
+        const HydAmdBlobSlot *rec = slot_record(planb, blobs, slot);
+        freq = rec->freq[k];
+        alphabet = rec->alphabet[k] > HYDAMD_ALPHABET ? HYDAMD_ALPHABET : rec->alphabet[k];
+        HydkSink count = {nullptr, 0, ~0ull, 0, 0};
+        hydk_put_ans_distribution(&count, freq, alphabet);
+        nb = count.pos;
+    }
+    uint64_t total = 0;
+    const uint64_t off = block_scan256(nb, s_wave, &total);
+    const uint32_t max_alpha = s_max;
+    int log_alpha = max_alpha > 1 ? hks_clog2(max_alpha) : 0;
+    log_alpha = log_alpha < 5 ? 5 : log_alpha;
+    const uint32_t cfg_bits = (uint32_t)hks_clog2(1u + (uint32_t)log_alpha) + 3u + 2u; /* split 4, msb 1 in clog2(5), lsb 0 in clog2(4) bits */
+    const uint64_t base = (uint64_t)plan->hfpre_bits + 2u + (uint64_t)C * cfg_bits;
+    const uint64_t bits = base + total;
+    const uint64_t words = (bits + 31) >> 5;
+    if (words > (uint64_t)kHfgWords || log_alpha > 8) {
+        if (t == 0)
+            atomicOr(S.err, HYDK_ASM_E_SCRATCH);
+        return;
+    }
+    for (uint64_t i = t; i < words; i += 256)
+        S.hfg[i] = 0;
+    __threadfence();
+    __syncthreads();
+    HydkSink sink = {S.hfg, 0, (uint64_t)kHfgWords * 32u, 0, 1};
+    if (t == 0) {
+        const uint32_t *pre = (const uint32_t *)(planb + plan->hfpre_off);
+        for (uint32_t done = 0; done < plan->hfpre_bits; done += 32)
+            hks_put(&sink, pre[done >> 5], plan->hfpre_bits - done < 32 ? plan->hfpre_bits - done : 32);
+        hks_put(&sink, (uint32_t)(log_alpha - 5), 2);
+        S.sizes[1 + plan->num_slots] = (bits + 7) >> 3;
+        S.result[1] = bits; /* scratch use: the layout kernel reads HFGlobal's bit count from here */
+    }
+    if ((uint32_t)t < C) {
+        /* hybrid-uint configuration (4, 1, 0) of cluster t (encoder.c:908, entropy.c:169-182) */
+        sink.pos = (uint64_t)plan->hfpre_bits + 2u + (uint64_t)t * cfg_bits;
+        hks_put(&sink, 4, cfg_bits - 5u);
+        hks_put(&sink, 1, 3);
+        hks_put(&sink, 0, 2);
+        sink.pos = base + off;
+        hydk_put_ans_distribution(&sink, freq, alphabet);
+    }
+}
+
+/* ---- k_asm_layout: one workgroup of 256 ---- */
+__global__ __launch_bounds__(256) void k_asm_layout(const uint8_t *__restrict__ planb, BlobArgs blobs, Scratch S, uint64_t out_cap,
+                                                    uint64_t *h_result /* pinned host [2] */) {
+    const HydkAsmPlan *plan = plan_of(planb);
+    __shared__ uint64_t s_wave[4];
+    const int t = threadIdx.x;
+    const uint32_t n = plan->toc_n, nslots = plan->num_slots;
+    uint32_t err = *S.err;
+    if (err) {
+        if (t == 0) {
+            S.result[0] = 0;
+            S.result[1] = err;
+            h_result[0] = 0;
+            h_result[1] = err;
+        }
+        return;
+    }
+    const uint64_t hfg_bits = S.result[1];
+    if (t == 0)
+        S.sizes[0] = plan->lfglobal_bytes;
+    __threadfence();
+    __syncthreads();
+    /* TOC: entry widths, where each goes, the entries */
+    const uint32_t per = (n + 255u) / 256u;
+    const uint32_t lo = min(n, (uint32_t)t * per), hi = min(n, lo + per);
+    uint64_t mine = 0;
+    uint32_t bad = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        uint64_t v;
+        const uint32_t w = hydk_toc_entry(S.sizes[i], &v);
+        bad |= w == 0;
+        mine += w;
+    }
+    uint64_t toc_bits = 0;
+    const uint64_t start = block_scan256(mine, s_wave, &toc_bits);
+    const uint64_t toc_words = (toc_bits + 31) >> 5;
+    if (toc_words > (uint64_t)kTocWords)
+        bad |= 2;
+    if (__syncthreads_or((int)bad)) {
+        if (t == 0) {
+            const uint32_t e = (bad & 2) ? HYDK_ASM_E_SCRATCH : HYDK_ASM_E_SIZE;
+            atomicOr(S.err, e);
+            S.result[0] = 0;
+            S.result[1] = e;
+            h_result[0] = 0;
+            h_result[1] = e;
+        }
+        return;
+    }
+    for (uint64_t i = t; i < toc_words; i += 256)
+        S.toc[i] = 0;
+    __threadfence();
+    __syncthreads();
+    {
+        HydkSink sink = {S.toc, start, (uint64_t)kTocWords * 32u, 0, 1};
+        for (uint32_t i = lo; i < hi; i++) {
+            uint64_t v;
+            const uint32_t w = hydk_toc_entry(S.sizes[i], &v);
+            hks_put64(&sink, v, w);
+        }
+    }
+    const uint64_t toc_bytes = (toc_bits + 7) >> 3;
+    const uint64_t body = (uint64_t)plan->prefix_bytes + toc_bytes;
+    /* LF group sections: thread t owns slot t */
+    uint64_t lf_mine = (uint32_t)t < nslots ? S.sizes[1 + t] : 0, lf_total = 0;
+    const uint64_t lf_off = block_scan256(lf_mine, s_wave, &lf_total);
+    const uint64_t lf_base = body + plan->lfglobal_bytes;
+    const uint64_t hfg_dst = lf_base + lf_total, hfg_bytes = (hfg_bits + 7) >> 3;
+    /* HF sections: one piece per blob, in blob order; each blob's byte count must be what its slots add up to */
+    uint64_t hf_mine = 0;
+    uint32_t mismatch = 0;
+    if ((uint32_t)t < plan->num_blobs) {
+        const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)blobs.p[t];
+        hf_mine = h->hf_bytes;
+        uint64_t sum = 0;
+        for (uint32_t s = plan->blob_first[t]; s < plan->blob_first[t] + plan->blob_slots[t]; s++)
+            sum += S.slot_hf[s];
+        mismatch = sum != hf_mine;
+    }
+    uint64_t hf_total = 0;
+    const uint64_t hf_off = block_scan256(hf_mine, s_wave, &hf_total);
+    const uint64_t hf_base = hfg_dst + hfg_bytes;
+    const uint64_t total = hf_base + hf_total;
+    Piece *P = S.pieces;
+    const Piece none = {0, 0, {nullptr, nullptr, nullptr}, {0, 0, 0}};
+    if (t == 0) {
+        Piece p = none;
+        p.dst = 0;
+        p.nbytes = plan->prefix_bytes;
+        p.src[0] = (const uint32_t *)(planb + plan->prefix_off);
+        p.nbits[0] = (uint64_t)plan->prefix_bytes * 8u;
+        P[0] = p;
+        p.dst = plan->prefix_bytes;
+        p.nbytes = toc_bytes;
+        p.src[0] = S.toc;
+        p.nbits[0] = toc_bits;
+        P[1] = p;
+        p.dst = body;
+        p.nbytes = plan->lfglobal_bytes;
+        p.src[0] = (const uint32_t *)(planb + plan->lfglobal_off);
+        p.nbits[0] = (uint64_t)plan->lfglobal_bytes * 8u;
+        P[2] = p;
+        p.dst = hfg_dst;
+        p.nbytes = hfg_bytes;
+        p.src[0] = S.hfg;
+        p.nbits[0] = hfg_bits;
+        P[3 + nslots] = p;
+        *S.npieces = 4 + nslots + plan->num_blobs;
+    }
+    if ((uint32_t)t < nslots) {
+        const HydkAsmSlot sl = ((const HydkAsmSlot *)(planb + plan->slots_off))[t];
+        const uint8_t *blob = blobs.p[sl.blob];
+        const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)blob;
+        const HydAmdBlobSlot *rec = (const HydAmdBlobSlot *)(blob + sizeof(HydAmdBlobHeader)) + sl.index;
+        const uint64_t lf_bytes_off = sizeof(HydAmdBlobHeader) + (uint64_t)h->num_slots * sizeof(HydAmdBlobSlot);
+        Piece p = none;
+        p.dst = lf_base + lf_off;
+        p.nbytes = lf_mine;
+        p.src[0] = S.head + (size_t)t * kHeadWords;
+        p.nbits[0] = S.head_bits[t];
+        p.src[1] = (const uint32_t *)(blob + lf_bytes_off + rec->lf.offset);
+        p.nbits[1] = rec->lf.bit_count;
+        p.src[2] = (const uint32_t *)(planb + plan->tail_off[sl.tail]);
+        p.nbits[2] = plan->tail_bits[sl.tail];
+        P[3 + t] = p;
+    }
+    if ((uint32_t)t < plan->num_blobs) {
+        const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)blobs.p[t];
+        Piece p = none;
+        p.dst = hf_base + hf_off;
+        p.nbytes = hf_mine;
+        p.src[0] = (const uint32_t *)(blobs.p[t] + (h->total_bytes - h->hf_bytes));
+        p.nbits[0] = hf_mine * 8u;
+        P[4 + nslots + t] = p;
+    }
+    const int any_mismatch = __syncthreads_or((int)mismatch);
+    if (t == 0) {
+        uint32_t e = any_mismatch ? HYDK_ASM_E_SIZE : 0u;
+        if (!e && total > out_cap)
+            e = HYDK_ASM_E_SPACE;
+        if (e)
+            atomicOr(S.err, e);
+        S.result[0] = e == HYDK_ASM_E_SPACE ? total : e ? 0 : total;
+        S.result[1] = e;
+        h_result[0] = S.result[0];
+        h_result[1] = e;
+    }
+}
+
+/* ---- k_asm_copy ---- */
+__device__ __forceinline__ uint32_t word_of(const uint32_t *w, uint64_t nbits, long long i) {
+    if (i < 0 || (uint64_t)i * 32u >= nbits)
+        return 0;
+    uint32_t v = w[i];
+    const uint64_t rem = nbits - (uint64_t)i * 32u;
+    if (rem < 32)
+        v &= (1u << rem) - 1u;
+    return v;
+}
+/* bits [q, q + 32) of a bit string of nbits bits; zero outside it */
+__device__ __forceinline__ uint32_t bits_at(const uint32_t *w, uint64_t nbits, long long q) {
+    if (!nbits || q <= -32 || q >= (long long)nbits)
+        return 0;
+    const long long i = q >> 5;
+    const uint32_t sh = (uint32_t)(q & 31);
+    const uint32_t lo = word_of(w, nbits, i);
+    if (!sh)
+        return lo;
+    const uint32_t hi = word_of(w, nbits, i + 1);
+    return (lo >> sh) | (hi << (32u - sh));
+}
+/* output word W as piece p sees it (zero where p has nothing) */
+__device__ __forceinline__ uint32_t piece_word(const Piece &p, uint64_t W) {
+    long long q = (long long)(W * 32u) - (long long)(p.dst * 8u);
+    uint32_t v = bits_at(p.src[0], p.nbits[0], q);
+    if (p.nbits[1]) {
+        q -= (long long)p.nbits[0];
+        v |= bits_at(p.src[1], p.nbits[1], q);
+    } else {
+        q -= (long long)p.nbits[0];
+    }
+    if (p.nbits[2]) {
+        q -= (long long)p.nbits[1];
+        v |= bits_at(p.src[2], p.nbits[2], q);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_asm_copy(Scratch S, uint8_t *__restrict__ out) {
+    __shared__ uint64_t s_start[kMaxPieces];
+    __shared__ uint64_t s_end[kMaxPieces];
+    const uint64_t total = S.result[0];
+    if (!total || S.result[1])
+        return;
+    const uint32_t np = *S.npieces;
+    for (uint32_t i = threadIdx.x; i < np; i += 256) {
+        s_start[i] = S.pieces[i].dst;
+        s_end[i] = S.pieces[i].dst + S.pieces[i].nbytes;
+    }
+    __syncthreads();
+    auto find = [&](uint64_t byte) { /* the last piece that starts at or before `byte`: empty pieces sort in front of their successor */
+        uint32_t lo = 0, hi = np - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (s_start[mid] <= byte)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        return lo;
+    };
+    const uint64_t words = (total + 3) >> 2;
+    uint32_t *out32 = (uint32_t *)out;
+    for (uint64_t W = (uint64_t)blockIdx.x * 256u + threadIdx.x; W < words; W += (uint64_t)gridDim.x * 256u) {
+        const uint64_t b0 = W * 4u;
+        const uint32_t pi = find(b0);
+        if (b0 + 4 <= s_end[pi]) {
+            out32[W] = piece_word(S.pieces[pi], W);
+            continue;
+        }
+        /* a word that several sections share, or the frame's last: byte by byte, each from its own piece */
+        for (uint32_t j = 0; j < 4 && b0 + j < total; j++) {
+            const uint32_t pj = find(b0 + j);
+            out[b0 + j] = (uint8_t)(piece_word(S.pieces[pj], W) >> (8u * j));
+        }
+    }
+}
+
+} // namespace
+
+struct HydkAsm {
+    int device = 0;
+    char error[256] = "";
+    uint8_t *plan = nullptr; /* device copy */
+    size_t plan_cap = 0;
+    HydkAsmPlan hplan;       /* host copy of the header */
+    bool have_plan = false;
+    Scratch S = {};
+    uint64_t *h_result = nullptr; /* pinned */
+};
+
+namespace {
+int afail(HydkAsm *a, int code, const char *what, hipError_t e = hipSuccess) {
+    if (a) {
+        if (e != hipSuccess)
+            snprintf(a->error, sizeof(a->error), "%s: %s", what, hipGetErrorString(e));
+        else
+            snprintf(a->error, sizeof(a->error), "%s", what);
+    }
+    return code;
+}
+#define ASM_TRY(a, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess)                                                                        \
+            return afail(a, e__ == hipErrorOutOfMemory ? ST_NOMEM : ST_INTERNAL_ERROR, #call, e__);   \
+    } while (0)
+} // namespace
+
+extern "C" {
+
+const char *hydk_asm_error(HydkAsm *a) { return a ? a->error : "null assembler"; }
+
+void hydk_asm_destroy(HydkAsm *a) {
+    if (!a)
+        return;
+    (void)hipSetDevice(a->device);
+    void *dev[] = {a->plan, a->S.head, a->S.head_bits, a->S.sizes, a->S.slot_hf, a->S.hfg, a->S.toc, a->S.pieces, a->S.npieces,
+                   a->S.err, a->S.result};
+    for (void *p : dev)
+        if (p)
+            (void)hipFree(p);
+    if (a->h_result)
+        (void)hipHostFree(a->h_result);
+    delete a;
+}
+
+static int asm_alloc(HydkAsm *a) {
+    const size_t slots = HYDAMD_MAX_LF_GROUPS;
+    const size_t toc_max = 2 + slots + slots * HYDK_GROUPS_PER_LFG;
+    ASM_TRY(a, hipSetDevice(a->device));
+    ASM_TRY(a, hipMalloc(&a->S.head, slots * kHeadWords * sizeof(uint32_t)));
+    ASM_TRY(a, hipMalloc(&a->S.head_bits, slots * sizeof(uint32_t)));
+    ASM_TRY(a, hipMalloc(&a->S.sizes, toc_max * sizeof(uint64_t)));
+    ASM_TRY(a, hipMalloc(&a->S.slot_hf, slots * sizeof(uint64_t)));
+    ASM_TRY(a, hipMalloc(&a->S.hfg, (size_t)kHfgWords * sizeof(uint32_t)));
+    ASM_TRY(a, hipMalloc(&a->S.toc, (size_t)kTocWords * sizeof(uint32_t)));
+    ASM_TRY(a, hipMalloc(&a->S.pieces, (size_t)kMaxPieces * sizeof(Piece)));
+    ASM_TRY(a, hipMalloc(&a->S.npieces, sizeof(uint32_t)));
+    ASM_TRY(a, hipMalloc(&a->S.err, sizeof(uint32_t)));
+    ASM_TRY(a, hipMalloc(&a->S.result, 2 * sizeof(uint64_t)));
+    ASM_TRY(a, hipHostMalloc((void **)&a->h_result, 2 * sizeof(uint64_t), hipHostMallocDefault));
+    a->h_result[0] = a->h_result[1] = 0;
+    return ST_OK;
+}
+
+int hydk_asm_create(int device, HydkAsm **out) {
+    int n = 0;
+    if (!out)
+        return ST_API_ERROR;
+    *out = nullptr;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n)
+        return ST_INTERNAL_ERROR;
+    HydkAsm *a = new (std::nothrow) HydkAsm();
+    if (!a)
+        return ST_NOMEM;
+    a->device = device;
+    const int st = asm_alloc(a);
+    if (st != ST_OK) {
+        hydk_asm_destroy(a);
+        return st;
+    }
+    *out = a;
+    return ST_OK;
+}
+
+int hydk_asm_set_plan(HydkAsm *a, const void *plan, size_t bytes) {
+    if (!a || !plan || bytes < sizeof(HydkAsmPlan))
+        return afail(a, ST_API_ERROR, "bad plan");
+    const HydkAsmPlan *hp = (const HydkAsmPlan *)plan;
+    if (hp->magic != HYDK_ASM_PLAN_MAGIC || hp->total_bytes != bytes || hp->num_slots < 1 || hp->num_slots > HYDAMD_MAX_LF_GROUPS ||
+        hp->num_blobs < 1 || hp->num_blobs > HYDK_ASM_MAX_BLOBS || hp->num_presets * hp->clusters_per_preset > 256 ||
+        hp->toc_n != 2 + hp->num_slots + hp->frame_groups || hp->ntails > HYDK_ASM_MAX_TAILS)
+        return afail(a, ST_API_ERROR, "inconsistent plan");
+    ASM_TRY(a, hipSetDevice(a->device));
+    if (bytes > a->plan_cap) {
+        ASM_TRY(a, hipDeviceSynchronize()); /* an earlier frame may still be reading the old plan */
+        if (a->plan)
+            (void)hipFree(a->plan);
+        a->plan = nullptr;
+        a->plan_cap = 0;
+        ASM_TRY(a, hipMalloc(&a->plan, bytes + 16)); /* + 16: the copy kernel reads whole words */
+        a->plan_cap = bytes;
+    } else {
+        ASM_TRY(a, hipDeviceSynchronize());
+    }
+    ASM_TRY(a, hipMemcpy(a->plan, plan, bytes, hipMemcpyHostToDevice));
+    a->hplan = *hp;
+    a->have_plan = true;
+    return ST_OK;
+}
+
+int hydk_asm_run(HydkAsm *a, const void *const *blobs, const uint64_t *blob_caps, void *stream, void *out, uint64_t out_cap) {
+    if (!a || !a->have_plan || !blobs || !blob_caps || !out)
+        return afail(a, ST_API_ERROR, "assembler not ready");
+    ASM_TRY(a, hipSetDevice(a->device));
+    hipStream_t st = (hipStream_t)stream;
+    BlobArgs args;
+    memset(&args, 0, sizeof(args));
+    for (uint32_t b = 0; b < a->hplan.num_blobs; b++) {
+        if (!blobs[b])
+            return afail(a, ST_API_ERROR, "null blob");
+        args.p[b] = (const uint8_t *)blobs[b];
+        args.cap[b] = blob_caps[b];
+    }
+    ASM_TRY(a, hipMemsetAsync(a->S.err, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_asm_slots, dim3(a->hplan.num_slots), dim3(64), 0, st, (const uint8_t *)a->plan, args, a->S);
+    hipLaunchKernelGGL(k_asm_hfglobal, dim3(1), dim3(256), 0, st, (const uint8_t *)a->plan, args, a->S);
+    hipLaunchKernelGGL(k_asm_layout, dim3(1), dim3(256), 0, st, (const uint8_t *)a->plan, args, a->S, out_cap, a->h_result);
+    hipLaunchKernelGGL(k_asm_copy, dim3(kCopyBlocks), dim3(256), 0, st, a->S, (uint8_t *)out);
+    ASM_TRY(a, hipGetLastError());
+    return ST_OK;
+}
+
+int hydk_asm_result(HydkAsm *a, uint64_t *size, uint32_t *err) {
+    if (!a)
+        return ST_API_ERROR;
+    if (size)
+        *size = a->h_result[0];
+    if (err)
+        *err = (uint32_t)a->h_result[1];
+    return ST_OK;
+}
+
+int hydk_asm_debug(HydkAsm *a, uint32_t slot, uint32_t *head_bits, uint32_t *head_words, size_t head_cap, uint32_t *hfg_bits,
+                   uint32_t *hfg_words, size_t hfg_cap) {
+    if (!a || slot >= HYDAMD_MAX_LF_GROUPS)
+        return ST_API_ERROR;
+    ASM_TRY(a, hipSetDevice(a->device));
+    ASM_TRY(a, hipDeviceSynchronize());
+    if (head_bits)
+        ASM_TRY(a, hipMemcpy(head_bits, a->S.head_bits + slot, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (head_words)
+        ASM_TRY(a, hipMemcpy(head_words, a->S.head + (size_t)slot * kHeadWords,
+                             (head_cap < (size_t)kHeadWords ? head_cap : (size_t)kHeadWords) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (hfg_bits) {
+        uint64_t sz = 0;
+        ASM_TRY(a, hipMemcpy(&sz, a->S.sizes + 1 + a->hplan.num_slots, sizeof(uint64_t), hipMemcpyDeviceToHost));
+        *hfg_bits = (uint32_t)(sz * 8u);
+    }
+    if (hfg_words)
+        ASM_TRY(a, hipMemcpy(hfg_words, a->S.hfg, (hfg_cap < (size_t)kHfgWords ? hfg_cap : (size_t)kHfgWords) * sizeof(uint32_t),
+                             hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+} /* extern "C" */

@@ -1270,6 +1270,27 @@ HYDRIUM_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write
     return ret;
 }
 
+/* ---- internal entry points of the device-side assembler's planner (assembler.c); not exported ---- */
+
+/* the file header hyd_send_tile writes in front of this image's first frame */
+int hyd_internal_file_header(const HYDImageMetadata *md, const uint8_t *icc, size_t icc_size, HydBits *out, const char **err) {
+    HYDEncoder *e = hyd_encoder_new();
+    if (!e)
+        return HYD_NOMEM;
+    int ret = hyd_set_metadata(e, md);
+    if (!ret && icc)
+        ret = hyd_set_suggested_icc_profile(e, icc, icc_size);
+    if (!ret)
+        ret = hyd_write_file_header(out, e->metadata.width, e->metadata.height, e->level10, e->icc, e->icc_size, &e->error);
+    if (err)
+        *err = e->error;
+    hyd_encoder_destroy(e);
+    return ret;
+}
+
+/* the geometry-only bits that close an LF group section (cached per shape for the life of the process) */
+const HydBits *hyd_internal_lf_tail(size_t vbw, size_t vbh) { return lf_tail(vbw, vbh); }
+
 HYDRIUM_EXPORT void hydamd_free(void *p) {
     if (!p)
         return;

@@ -402,6 +402,7 @@ int hyd_write_lf_group_coded(HydBits *out, size_t vbw, size_t vbh, const HydLfCo
     static const uint8_t map[2] = {0, 1};
     static const HydUintConfig config[2] = {{7, 1, 1}, {7, 1, 1}};
     const uint16_t alphabet[2] = {(uint16_t)lf->alphabet, (uint16_t)(lf->run_pairs ? 2 : 0)};
+    /* (hyd_write_lf_group_fixed_head below writes the same layout's fixed fields for the device-side assembler) */
     uint32_t *lengths = calloc((size_t)alphabet[0] + alphabet[1], sizeof(uint32_t));
     if (!lengths)
         return ST_NOMEM;
@@ -426,6 +427,23 @@ int hyd_write_lf_group_coded(HydBits *out, size_t vbw, size_t vbh, const HydLfCo
         if (ret)
             return ret;
     }
+    return out->failed ? ST_NOMEM : 0;
+}
+
+/* Everything of an LF group section in front of its first data-dependent bit: modular header, MA tree
+ * and the fixed fields of the LF-coefficient stream's header (the layout hyd_write_lf_group_coded uses).
+ * The device-side assembler (csrc/hip/assemble.hip) continues from there with hydk_lf_prefix_codes. */
+int hyd_write_lf_group_fixed_head(HydBits *out, const char **err) {
+    int ret = lf_group_prologue(out, err);
+    if (ret)
+        return ret;
+    static const uint8_t map[2] = {0, 1};
+    static const HydUintConfig config[2] = {{7, 1, 1}, {7, 1, 1}};
+    static const uint16_t alphabet[2] = {0, 0};
+    const HydPrefixLayout lay = {HYD_LF_RUN_BASE, 3, map, 2, 2, config, alphabet};
+    ret = hps_write_header_fixed(out, &lay, err);
+    if (ret)
+        return ret;
     return out->failed ? ST_NOMEM : 0;
 }
 
@@ -514,9 +532,9 @@ static void put_ans_distribution(HydBits *out, const uint32_t *freq, uint32_t al
     }
 }
 
-int hyd_write_hf_global(HydBits *out, unsigned num_presets, size_t num_frame_groups,
-                        const uint32_t (*freq)[HYD_FRAME_MAX_CLUSTERS][HYD_FRAME_ALPHABET],
-                        const uint32_t (*alphabet)[HYD_FRAME_MAX_CLUSTERS], unsigned max_alphabet, const char **err) {
+/* HFGlobal up to and including "ANS, not prefix codes": depends on the frame's geometry only */
+int hyd_write_hf_global_fixed(HydBits *out, unsigned num_presets, size_t num_frame_groups, int *clusters_per_preset,
+                              const char **err) {
     hb_bool(out, 1);                                                 /* default dequant matrices */
     hb_put(out, num_presets - 1, clog2_u64(num_frame_groups));       /* number of HF presets */
     hb_put(out, 2, 2);                                               /* coefficient order: default */
@@ -527,15 +545,28 @@ int hyd_write_hf_global(HydBits *out, unsigned num_presets, size_t num_frame_gro
         return ST_NOMEM;
     const int per = hyd_hf_cluster_map(map, num_presets);
     const size_t num_clusters = (size_t)per * num_presets;
-    int log_alpha = max_alphabet > 1 ? clog2_u64(max_alphabet) : 0;
-    if (log_alpha < 5)
-        log_alpha = 5;
     hb_bool(out, 0); /* no LZ77 */
     int ret = hps_write_cluster_map(map, (size_t)1485 * num_presets, num_clusters, out, err);
     free(map);
     if (ret)
         return ret;
     hb_bool(out, 0); /* ANS, not prefix codes */
+    if (clusters_per_preset)
+        *clusters_per_preset = per;
+    return out->failed ? ST_NOMEM : 0;
+}
+
+int hyd_write_hf_global(HydBits *out, unsigned num_presets, size_t num_frame_groups,
+                        const uint32_t (*freq)[HYD_FRAME_MAX_CLUSTERS][HYD_FRAME_ALPHABET],
+                        const uint32_t (*alphabet)[HYD_FRAME_MAX_CLUSTERS], unsigned max_alphabet, const char **err) {
+    int per = 0;
+    int ret = hyd_write_hf_global_fixed(out, num_presets, num_frame_groups, &per, err);
+    if (ret)
+        return ret;
+    const size_t num_clusters = (size_t)per * num_presets;
+    int log_alpha = max_alphabet > 1 ? clog2_u64(max_alphabet) : 0;
+    if (log_alpha < 5)
+        log_alpha = 5;
     hb_put(out, (uint64_t)(log_alpha - 5), 2);
     const HydUintConfig cfg = {4, 1, 0}; /* encoder.c:908 */
     for (size_t c = 0; c < num_clusters; c++)
@@ -545,3 +576,126 @@ int hyd_write_hf_global(HydBits *out, unsigned num_presets, size_t num_frame_gro
             put_ans_distribution(out, freq[p][c], alphabet[p][c]);
     return out->failed ? ST_NOMEM : 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * CPU-only test hooks (libhydrium_hosttest.so): the field writers the device-side assembler runs
+ * (csrc/hip/hydk_sections.h, compiled here for the host) next to the host functions they restate.
+ * ------------------------------------------------------------------------------------------- */
+#ifdef HYD_TEST_HOOKS
+#include "../hip/hydk_sections.h"
+#define HYDT_EXPORT __attribute__((visibility("default")))
+
+static int hydt_take_bits(HydBits *b, uint8_t *out, size_t cap, uint64_t *nbits) {
+    *nbits = hb_bit_count(b);
+    hb_align(b);
+    const int ok = !b->failed && b->len <= cap;
+    if (ok)
+        memcpy(out, b->data, b->len);
+    hb_free(b);
+    return ok ? 0 : ST_NOMEM;
+}
+
+/* an LF group section up to its first symbol bit, by the host path (hyd_write_lf_group_coded's first half) ... */
+HYDT_EXPORT int hydt_lf_head_host(const uint8_t *lengths, uint32_t alphabet0, uint32_t run_pairs, uint8_t *out, size_t cap,
+                                  uint64_t *nbits) {
+    HydBits b;
+    const char *err = NULL;
+    hb_init(&b);
+    int ret = lf_group_prologue(&b, &err);
+    if (ret)
+        return ret;
+    static const uint8_t map[2] = {0, 1};
+    static const HydUintConfig config[2] = {{7, 1, 1}, {7, 1, 1}};
+    const uint16_t alphabet[2] = {(uint16_t)alphabet0, (uint16_t)(run_pairs ? 2 : 0)};
+    uint32_t *len = calloc((size_t)alphabet[0] + alphabet[1] + 1, sizeof(uint32_t));
+    if (!len)
+        return ST_NOMEM;
+    for (uint32_t t = 0; t < alphabet0; t++) {
+        if (t < 256)
+            len[t] = lengths[t];
+        else if (t >= HYD_LF_RUN_BASE)
+            len[t] = lengths[256 + (t - HYD_LF_RUN_BASE)];
+    }
+    const HydPrefixLayout lay = {HYD_LF_RUN_BASE, 3, map, 2, 2, config, alphabet};
+    ret = hps_write_header(&b, &lay, len, &err);
+    free(len);
+    if (ret) {
+        hb_free(&b);
+        return ret;
+    }
+    return hydt_take_bits(&b, out, cap, nbits);
+}
+
+/* ... and by the assembler's: fixed head from the plan + hydk_lf_prefix_codes */
+HYDT_EXPORT int hydt_lf_head_sections(const uint8_t *lengths, uint32_t alphabet0, uint32_t run_pairs, uint8_t *out, size_t cap,
+                                      uint64_t *nbits) {
+    HydBits b;
+    const char *err = NULL;
+    hb_init(&b);
+    int ret = hyd_write_lf_group_fixed_head(&b, &err);
+    if (ret)
+        return ret;
+    const uint64_t fixed = hb_bit_count(&b);
+    hb_align(&b);
+    uint32_t *words = calloc(cap / 4 + 2, sizeof(uint32_t));
+    if (!words) {
+        hb_free(&b);
+        return ST_NOMEM;
+    }
+    memcpy(words, b.data, b.len);
+    hb_free(&b);
+    HydkSink sink = {words, fixed, (uint64_t)(cap / 4) * 32u, 0, 0};
+    ret = hydk_lf_prefix_codes(&sink, lengths, alphabet0, run_pairs);
+    if (!ret && sink.overflow)
+        ret = ST_NOMEM;
+    *nbits = sink.pos;
+    if (!ret)
+        memcpy(out, words, (size_t)((sink.pos + 7) >> 3));
+    free(words);
+    return ret;
+}
+
+HYDT_EXPORT int hydt_ans_distribution_host(const uint32_t *freq, uint32_t alphabet, uint8_t *out, size_t cap, uint64_t *nbits) {
+    HydBits b;
+    hb_init(&b);
+    put_ans_distribution(&b, freq, alphabet);
+    return hydt_take_bits(&b, out, cap, nbits);
+}
+
+HYDT_EXPORT int hydt_ans_distribution_sections(const uint32_t *freq, uint32_t alphabet, uint8_t *out, size_t cap, uint64_t *nbits) {
+    uint32_t *words = calloc(cap / 4 + 2, sizeof(uint32_t));
+    if (!words)
+        return ST_NOMEM;
+    HydkSink sink = {words, 0, (uint64_t)(cap / 4) * 32u, 0, 0};
+    hydk_put_ans_distribution(&sink, freq, alphabet);
+    HydkSink count = {NULL, 0, ~UINT64_C(0), 0, 0};
+    hydk_put_ans_distribution(&count, freq, alphabet);
+    const int ret = sink.overflow || count.pos != sink.pos ? ST_INTERNAL : 0;
+    *nbits = sink.pos;
+    if (!ret)
+        memcpy(out, words, (size_t)((sink.pos + 7) >> 3));
+    free(words);
+    return ret;
+}
+
+/* one TOC entry both ways: returns 0 when they agree */
+HYDT_EXPORT int hydt_toc_entry_check(uint64_t size) {
+    HydBits b;
+    hb_init(&b);
+    const int host_fail = size > UINT32_MAX || hb_u32(&b, &kTocEntry, (uint32_t)size);
+    const uint64_t nbits = hb_bit_count(&b);
+    hb_align(&b);
+    uint64_t v = 0, hv = 0;
+    const uint32_t w = hydk_toc_entry(size, &v);
+    for (size_t i = 0; i < b.len && i < 8; i++)
+        hv |= (uint64_t)b.data[i] << (8 * i);
+    hb_free(&b);
+    if (host_fail)
+        return w == 0 ? 0 : 1;
+    return w == nbits && v == hv ? 0 : 1;
+}
+
+HYDT_EXPORT int hydt_small_code_lengths(const uint32_t *freq, uint32_t *lengths, uint32_t n, int max_depth) {
+    return n <= HYDK_SMALL_N ? hydk_small_code_lengths(freq, lengths, n, max_depth) : ST_API;
+}
+#endif /* HYD_TEST_HOOKS */

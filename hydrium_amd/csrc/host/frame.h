@@ -62,7 +62,12 @@ typedef struct HydLfCoded {
 int hyd_write_lf_group_coded(HydBits *out, size_t vbw, size_t vbh, const HydLfCoded *lf, const HydBits *tail,
                              const char **err);
 int hyd_write_lf_group_tail(HydBits *out, size_t vbw, size_t vbh, const char **err);
+/* the bits of an LF group section in front of its first data-dependent one (device-side assembler) */
+int hyd_write_lf_group_fixed_head(HydBits *out, const char **err);
 
+/* HFGlobal's geometry-only fields, up to and including "ANS, not prefix codes" (device-side assembler) */
+int hyd_write_hf_global_fixed(HydBits *out, unsigned num_presets, size_t num_frame_groups, int *clusters_per_preset,
+                              const char **err);
 /* HF context -> cluster map of a frame with num_presets presets (encoder.c:852-901); returns clusters per preset */
 int hyd_hf_cluster_map(uint8_t *map, unsigned num_presets);
 

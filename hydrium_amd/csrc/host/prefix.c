@@ -453,20 +453,29 @@ static void swap_pick(Pick *a, Pick *b) {
  * header (entropy.c:546-575, log_alphabet_size = 0), the alphabet sizes (entropy.c:835-844) and one
  * code per cluster in the simple or the complex form (entropy.c:846-927).  `lengths` holds the code
  * lengths of cluster c at offset sum(alphabet[0..c)). */
-int hps_write_header(HydBits *out, const HydPrefixLayout *lay, const uint32_t *lengths, const char **err) {
-    int ret = 0;
+int hps_write_header_fixed(HydBits *out, const HydPrefixLayout *lay, const char **err) {
     hb_bool(out, lay->rle_min_symbol != 0);
     if (lay->rle_min_symbol) {
         hb_u32(out, &kRleMinSymbol, lay->rle_min_symbol);
         hb_u32(out, &kRleMinLength, lay->rle_min_length);
         hps_write_uint_config(out, &kRunLengthConfig, 8);
     }
-    ret = hps_write_cluster_map(lay->cluster_map, lay->num_dists, lay->num_clusters, out, err);
-    if (ret)
-        goto done;
+    const int ret = hps_write_cluster_map(lay->cluster_map, lay->num_dists, lay->num_clusters, out, err);
+    if (ret) {
+        if (err && !*err)
+            *err = ret == ST_NOMEM ? "out of memory in prefix coder" : "prefix coder internal error";
+        return ret;
+    }
     hb_bool(out, 1); /* prefix codes */
     for (size_t c = 0; c < lay->num_clusters; c++)
         hps_write_uint_config(out, &lay->config[c], 15);
+    return 0;
+}
+
+int hps_write_header(HydBits *out, const HydPrefixLayout *lay, const uint32_t *lengths, const char **err) {
+    int ret = hps_write_header_fixed(out, lay, err);
+    if (ret)
+        return ret;
 
     for (size_t c = 0; c < lay->num_clusters; c++) {
         if (lay->alphabet[c] <= 1) {

@@ -67,6 +67,9 @@ typedef struct HydPrefixLayout {
     const uint16_t *alphabet;
 } HydPrefixLayout;
 int hps_write_header(HydBits *out, const HydPrefixLayout *lay, const uint32_t *lengths, const char **err);
+/* its fields in front of the alphabet sizes and codes — everything that does not depend on the symbols
+ * (LZ77 parameters, cluster map, "prefix codes", hybrid-uint configurations) */
+int hps_write_header_fixed(HydBits *out, const HydPrefixLayout *lay, const char **err);
 
 /* pieces shared with the ANS stream header written by frame.c */
 void hps_hybridize(uint32_t value, const HydUintConfig *cfg, HydSym *out);

@@ -122,6 +122,14 @@ def dll(path: Optional[str] = None):
         d.hydamd_debug_transform_footprint.restype = C.c_int
         d.hydamd_debug_transform_footprint.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         d.hydamd_debug_lf_code.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        d.hydamd_assembler_create.restype = vp
+        d.hydamd_assembler_create.argtypes = [i, C.POINTER(i)]
+        d.hydamd_assembler_destroy.argtypes = [vp]
+        d.hydamd_assembler_error.restype = C.c_char_p
+        d.hydamd_assembler_error.argtypes = [vp]
+        d.hydamd_assembler_plan.argtypes = [vp, C.POINTER(api.HYDImageMetadata), i, i, sz, vp, vp, C.c_char_p, sz]
+        d.hydamd_assembler_run.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), vp, vp, sz]
+        d.hydamd_assembler_result.argtypes = [vp, C.POINTER(sz)]
         d.hydamd_profile.argtypes = [vp, i]
         d.hydamd_profile_read.argtypes = [vp, vp, vp]
         if path is not None:
@@ -493,6 +501,60 @@ def frame_from_blobs(md: "api.HYDImageMetadata", blobs, *, write_header=True, is
     data = C.string_at(out.value, out_len.value)
     d.hydamd_free(out)
     return data
+
+
+class Assembler:
+    """Device-side frame assembly (hydamd_assembler_*): shard blobs in device memory -> the finished one-frame
+    codestream in one device-accessible buffer.  One assembler serves one frame at a time."""
+
+    def __init__(self, device: int = 0):
+        self.d = dll()
+        st = C.c_int(0)
+        self.h = self.d.hydamd_assembler_create(device, C.byref(st))
+        if not self.h:
+            raise DeviceError(st.value, "assembler could not be created")
+
+    def close(self):
+        if self.h:
+            self.d.hydamd_assembler_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, code: int):
+        if code != 0:
+            raise DeviceError(code, (self.d.hydamd_assembler_error(self.h) or b"").decode())
+
+    def plan(self, md: "api.HYDImageMetadata", blob_lf_ids, *, write_header=True, is_last=True, icc: Optional[bytes] = None):
+        """blob_lf_ids[b] = raster ids of the LF groups blob b carries, in its slot order (cheap when it repeats)."""
+        counts = np.array([len(ids) for ids in blob_lf_ids], np.uint32)
+        flat = np.array([lf for ids in blob_lf_ids for lf in ids], np.uint32)
+        self._ck(self.d.hydamd_assembler_plan(self.h, C.byref(md), int(write_header), int(is_last), len(counts), counts.ctypes.data,
+                                              flat.ctypes.data, icc, len(icc) if icc else 0))
+        self.nblobs = len(counts)
+
+    def run(self, blob_ptrs, blob_caps, out_ptr: int, out_cap: int, stream_ptr: int):
+        """Enqueue on `stream_ptr` (a hipStream_t): blob_ptrs are device pointers, out_ptr any device-accessible buffer."""
+        n = len(blob_ptrs)
+        ptrs = (C.c_void_p * n)(*blob_ptrs)
+        caps = (C.c_size_t * n)(*blob_caps)
+        self._ck(self.d.hydamd_assembler_run(self.h, ptrs, caps, stream_ptr, out_ptr, out_cap))
+
+    def run_tensors(self, blobs, out, stream=None):
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream()
+        self.run([b.data_ptr() for b in blobs], [b.numel() for b in blobs], out.data_ptr(), out.numel(), st.cuda_stream)
+
+    def result(self) -> int:
+        """After the stream has been synchronised: bytes of the frame (raises on a device-side failure)."""
+        n = C.c_size_t(0)
+        self._ck(self.d.hydamd_assembler_result(self.h, C.byref(n)))
+        return int(n.value)
 
 
 def decode_token_records(rec: np.ndarray):

@@ -174,15 +174,66 @@ class GpuShardEngine:
         """Wait for the shard; a frame that outgrew the context's buffers is rerun in here (hydamd_sync)."""
         if self.n:
             self.shard.ctx.sync()
+        else:
+            self.stream.synchronize()
+
+    def overflow_reruns(self) -> int:
+        return self.shard.ctx.overflow_reruns() if self.n else 0
 
     def alphabet_device(self):
         return self.device
 
 
-def enqueue_frame(engine, parts, capacity: int, group=None, to_rank=0):
+class FrameAssembly:
+    """What the assembling rank needs to build frames where the blobs are (device.Assembler): the
+    assembler, the frame's description and an output buffer — pinned host memory by default, so that the
+    finished codestream lands on the host with the assembly itself and no copy follows."""
+
+    def __init__(self, dev_index: int, width: int, height: int, capacity: Optional[int] = None, linear_light: int = 0,
+                 pinned: bool = True, icc: Optional[bytes] = None):
+        self.asm = device.Assembler(dev_index)
+        self.md = api.HYDImageMetadata(width, height, linear_light, -1, -1)
+        self.icc = icc
+        self.dev_index, self.pinned = dev_index, pinned
+        self.out = None
+        if capacity:
+            self._allocate(capacity)
+        self.size = 0
+
+    def _allocate(self, capacity: int):
+        import torch
+
+        self.out = (torch.empty(capacity, dtype=torch.uint8).pin_memory() if self.pinned
+                    else torch.empty(capacity, dtype=torch.uint8, device=torch.device("cuda", self.dev_index)))
+
+    @staticmethod
+    def supports(width: int, height: int) -> bool:
+        """Frames of a single 256 x 256 group are one bit-contiguous section: the host assembler takes those."""
+        return (-(-width // 256)) * (-(-height // 256)) > 1
+
+    def enqueue(self, rows, parts):
+        """On torch's current stream, behind whatever fills `rows` (the gathered blobs, rank order)."""
+        keep = [(r, p) for r, p in zip(rows, parts) if len(p)]  # a rank without LF groups sends an empty blob
+        need = sum(r.numel() for r, _ in keep) + (1 << 20)     # no frame is larger than its blobs plus its headers
+        if self.out is None or self.out.numel() < need:
+            self._allocate(need)
+        self.asm.plan(self.md, [list(p) for _, p in keep], icc=self.icc)
+        self.asm.run_tensors([r for r, _ in keep], self.out)
+
+    def finish(self):
+        """After the stream has been synchronised: the frame as a uint8 view of the output buffer (no copy when pinned)."""
+        self.size = self.asm.result()
+        return self.out[:self.size]
+
+    def close(self):
+        self.asm.close()
+
+
+def enqueue_frame(engine, parts, capacity: int, group=None, to_rank=0, assembly: Optional["FrameAssembly"] = None):
     """Everything a frame needs from this rank, enqueued without a host wait: transform stage ->
     all-gather of the per-LF-group alphabet maxima (one int32 per LF group, on the device) -> entropy
-    stage with this rank's floor -> the shard's blob -> one gather of the blobs to ``to_rank``.
+    stage with this rank's floor -> the shard's blob -> one gather of the blobs to ``to_rank`` -> with an
+    ``assembly``, the frame itself, built on ``to_rank``'s GPU from the gathered blobs (device.Assembler).
     ``capacity`` is the blob size every rank sends (all ranks must pass the same value).  Returns a
     handle for ``collect_frame``.  Reference: presets are numbered across the whole frame
     (encoder.c:852-901) and the alphabet maximum runs over LF groups in send order
@@ -192,6 +243,7 @@ def enqueue_frame(engine, parts, capacity: int, group=None, to_rank=0):
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     most = max(max(len(p) for p in parts), 1)
+    reruns = engine.overflow_reruns() if hasattr(engine, "overflow_reruns") else None
     engine.enqueue_transform()
     mine = engine.alphabet_maxima()
     padded = torch.zeros(most, dtype=torch.int32, device=mine.device)
@@ -206,24 +258,42 @@ def enqueue_frame(engine, parts, capacity: int, group=None, to_rank=0):
     engine.export_blob(blob)
     rows = [torch.empty(cap, dtype=torch.uint8, device=mine.device) for _ in range(world)] if rank == to_rank else None
     dist.gather(blob, gather_list=rows, dst=to_rank, group=group)
-    return dict(engine=engine, blob=blob, rows=rows, to_rank=to_rank, rank=rank, keep=(every, padded, floor))
+    if assembly is not None and rank == to_rank:
+        assembly.enqueue(rows, parts)
+    return dict(engine=engine, blob=blob, rows=rows, to_rank=to_rank, rank=rank, keep=(every, padded, floor),
+                assembly=assembly if rank == to_rank else None, reruns=reruns)
 
 
 def collect_frame(handle):
     """Wait for this rank's part of a frame queued by ``enqueue_frame``.  Returns (retry, rows): ``retry``
-    says this rank's blob is incomplete (its frame outgrew a buffer and was rerun inside the wait, or the
+    says a blob is incomplete (a shard's frame outgrew a buffer and was rerun inside the wait, or its
     blob did not fit ``capacity``) — every rank then has to run the frame again; ``rows`` are the
-    gathered blobs as device tensors on the assembling rank, None elsewhere."""
-    handle["engine"].finish()
+    gathered blobs as device tensors on the assembling rank, None elsewhere.  With an assembly the frame
+    is in ``handle["frame"]`` afterwards (a view of the assembly's output buffer) and nothing is read back
+    here: this rank's own rerun shows in the context's counter, anyone's incomplete blob in the
+    assembler's verdict."""
+    engine = handle["engine"]
+    engine.finish()
+    asm = handle.get("assembly")
+    if asm is not None:
+        try:
+            handle["frame"] = asm.finish()
+            return False, handle["rows"]
+        except device.DeviceError as e:
+            if "incomplete" in e.message:
+                return True, handle["rows"]
+            raise
+    if handle.get("reruns") is not None and handle["rank"] != handle["to_rank"]:
+        return engine.overflow_reruns() != handle["reruns"], handle["rows"]
     head = device.blob_header(handle["blob"][:device.BLOB_HEADER_DTYPE.itemsize].cpu().numpy().tobytes())
     return bool(int(head["status"]) & device.BLOB_RETRY), handle["rows"]
 
 
-def choreograph_frame(engine, parts, group=None, capacity=None, to_rank=0):
+def choreograph_frame(engine, parts, group=None, capacity=None, to_rank=0, assembly: Optional["FrameAssembly"] = None):
     """One frame over the ranks of ``group`` (enqueue_frame + collect_frame, rerun if a shard says so).
-    Returns the list of blobs (bytes, rank order) on ``to_rank``, ``None`` elsewhere.  ``engine`` is a
-    GpuShardEngine or anything with its methods; ``parts`` the LF-group partition
-    (sharding.partition_lf_groups)."""
+    Returns the list of blobs (bytes, rank order) on ``to_rank`` — or, with an ``assembly``, the frame
+    itself as bytes — and ``None`` elsewhere.  ``engine`` is a GpuShardEngine or anything with its
+    methods; ``parts`` the LF-group partition (sharding.partition_lf_groups)."""
     import torch
     import torch.distributed as dist
 
@@ -233,13 +303,15 @@ def choreograph_frame(engine, parts, group=None, capacity=None, to_rank=0):
         # every rank sends the same number of bytes: the largest bound any of them reports
         cap = torch.tensor([capacity or engine.blob_bound()], dtype=torch.int64, device=dev)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
-        handle = enqueue_frame(engine, parts, int(cap.item()), group, to_rank)
+        handle = enqueue_frame(engine, parts, int(cap.item()), group, to_rank, assembly)
         again, rows = collect_frame(handle)
         retry = torch.tensor([1 if again else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(retry, op=dist.ReduceOp.MAX, group=group)
         if not int(retry.item()):
             if rank != to_rank:
                 return None
+            if assembly is not None:
+                return bytes(handle["frame"].cpu().numpy())
             out = []
             for r in rows:
                 host = r.cpu().numpy()
@@ -250,10 +322,12 @@ def choreograph_frame(engine, parts, group=None, capacity=None, to_rank=0):
 
 
 def encode_distributed(slab_tensor, width: int, height: int, origin_lf_pixels, group=None, linear_light: int = 0,
-                       lib=None):
+                       lib=None, assemble_on_device: bool = True):
     """One process per GPU: this rank codes its LF groups out of ``slab_tensor`` (its part of the
-    picture, already in its HBM); rank 0 returns the codestream, the others ``None``.  Nothing but the
-    final blobs crosses to the host, and only on rank 0."""
+    picture, already in its HBM); rank 0 returns the codestream, the others ``None``.  The frame is put
+    together on rank 0's GPU from the gathered blobs and written straight into pinned host memory
+    (``assemble_on_device=False``: the blobs cross to the host and hydamd_frame_from_blobs builds it there,
+    which is also what a frame of a single group gets)."""
     import torch
     import torch.distributed as dist
 
@@ -262,14 +336,19 @@ def encode_distributed(slab_tensor, width: int, height: int, origin_lf_pixels, g
     n_lf = lfx * (-(-height // 2048))
     parts = sharding.partition_lf_groups(n_lf, world)
     shard = Shard(torch.cuda.current_device(), parts[rank], width, height, linear_light)
+    assembly = None
     try:
         engine = GpuShardEngine(shard, slab_tensor, origin_lf_pixels)
+        if assemble_on_device and rank == 0 and FrameAssembly.supports(width, height):
+            assembly = FrameAssembly(torch.cuda.current_device(), width, height, None, linear_light)
         with torch.cuda.stream(engine.stream):
-            blobs = choreograph_frame(engine, parts, group)
-        if blobs is None:
-            return None
+            blobs = choreograph_frame(engine, parts, group, assembly=assembly)
+        if blobs is None or assembly is not None:
+            return blobs
         return device.frame_from_blobs(api.HYDImageMetadata(width, height, linear_light, -1, -1), blobs, lib=lib)
     finally:
+        if assembly is not None:
+            assembly.close()
         # torch's caching allocator pools the blocks it handed out under the context's stream by that
         # stream: give them back to the driver before the stream is destroyed with the context
         engine = None

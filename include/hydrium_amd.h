@@ -251,6 +251,37 @@ HYDAMD_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write_
                                           size_t icc_size, uint8_t **out, size_t *out_len, const char **err);
 
 /*
+ * The same assembly ON THE DEVICE: the blobs stay where hydamd_export_frame (or an RCCL gather) left
+ * them, kernels write every section into place — LF group sections around their coefficient streams
+ * (reference encoder.c:539-629), HFGlobal's histograms (encoder.c:959-967), the TOC (encoder.c:992-1005)
+ * — and the finished one-frame codestream lands in one buffer: one copy to the host instead of
+ * per-section read-backs and a host-side splice.  The host contributes the bytes that do not depend on
+ * the pixels (file and frame header, LFGlobal, constant sub-streams), once per frame description.
+ *   hydamd_assembler_plan    describe the frame: which LF groups (raster ids, `lf_ids`) each of the
+ *                            `nblobs` blobs carries, blob by blob, slot by slot — this order becomes the
+ *                            frame's section order.  Cheap when the description repeats.
+ *   hydamd_assembler_run     enqueue the assembly on `hip_stream` (behind whatever fills the blobs):
+ *                            `blobs_dev[b]` is a device pointer to blob b (`blob_caps[b]` readable bytes),
+ *                            `out` any device-accessible buffer of `out_cap` bytes (device memory, or
+ *                            pinned host memory for frames that should land on the host directly).
+ *   hydamd_assembler_result  after the stream has been synchronised: the frame's size; HYD_NEED_MORE_OUTPUT
+ *                            (with *size = bytes needed) if `out_cap` was too small; HYD_API_ERROR for a
+ *                            blob that is malformed, incomplete (rerun the shard) or carries NaN input.
+ * Frames of a single 256x256 group are one bit-contiguous section and stay with hydamd_frame_from_blobs.
+ * One assembler serves one frame at a time (its scratch is reused by the next hydamd_assembler_run).
+ */
+typedef struct HydAmdAssembler HydAmdAssembler;
+HYDAMD_EXPORT HydAmdAssembler *hydamd_assembler_create(int device, int *status);
+HYDAMD_EXPORT void hydamd_assembler_destroy(HydAmdAssembler *a);
+HYDAMD_EXPORT const char *hydamd_assembler_error(HydAmdAssembler *a);
+HYDAMD_EXPORT int hydamd_assembler_plan(HydAmdAssembler *a, const HYDImageMetadata *md, int write_header, int is_last,
+                                        size_t nblobs, const uint32_t *blob_slots, const uint32_t *lf_ids, const uint8_t *icc,
+                                        size_t icc_size);
+HYDAMD_EXPORT int hydamd_assembler_run(HydAmdAssembler *a, const void *const *blobs_dev, const size_t *blob_caps, void *hip_stream,
+                                       void *out, size_t out_cap);
+HYDAMD_EXPORT int hydamd_assembler_result(HydAmdAssembler *a, size_t *size);
+
+/*
  * Wrap LF-group results — from this or other GPUs — into codestream bytes (host only, no GPU).
  *   md            image metadata, as for hyd_set_metadata (one-frame mode: every LF group must be present)
  *   tile_xy       [lfg_count][2] tile coordinates, in the order the sections appear in `payload`

@@ -511,6 +511,9 @@ struct HydkAsm {
     bool have_plan = false;
     Scratch S = {};
     uint64_t *h_result = nullptr; /* pinned */
+    uint8_t *own_out = nullptr;   /* output buffer for callers that bring none (hydk_asm_run with out == NULL) */
+    size_t own_cap = 0;
+    uint8_t *last_out = nullptr;  /* where the last run wrote */
 };
 
 namespace {
@@ -539,7 +542,7 @@ void hydk_asm_destroy(HydkAsm *a) {
     if (!a)
         return;
     (void)hipSetDevice(a->device);
-    void *dev[] = {a->plan, a->S.head, a->S.head_bits, a->S.sizes, a->S.slot_hf, a->S.hfg, a->S.toc, a->S.pieces, a->S.npieces,
+    void *dev[] = {a->own_out, a->plan, a->S.head, a->S.head_bits, a->S.sizes, a->S.slot_hf, a->S.hfg, a->S.toc, a->S.pieces, a->S.npieces,
                    a->S.err, a->S.result};
     for (void *p : dev)
         if (p)
@@ -615,10 +618,27 @@ int hydk_asm_set_plan(HydkAsm *a, const void *plan, size_t bytes) {
 }
 
 int hydk_asm_run(HydkAsm *a, const void *const *blobs, const uint64_t *blob_caps, void *stream, void *out, uint64_t out_cap) {
-    if (!a || !a->have_plan || !blobs || !blob_caps || !out)
+    if (!a || !a->have_plan || !blobs || !blob_caps)
         return afail(a, ST_API_ERROR, "assembler not ready");
     ASM_TRY(a, hipSetDevice(a->device));
     hipStream_t st = (hipStream_t)stream;
+    if (!out) { /* the assembler's own device buffer: no frame is larger than its blobs plus its headers */
+        size_t need = (size_t)1 << 20;
+        for (uint32_t b = 0; b < a->hplan.num_blobs; b++)
+            need += (size_t)blob_caps[b];
+        if (need > a->own_cap) {
+            ASM_TRY(a, hipStreamSynchronize(st));
+            if (a->own_out)
+                (void)hipFree(a->own_out);
+            a->own_out = nullptr;
+            a->own_cap = 0;
+            ASM_TRY(a, hipMalloc(&a->own_out, need));
+            a->own_cap = need;
+        }
+        out = a->own_out;
+        out_cap = a->own_cap;
+    }
+    a->last_out = (uint8_t *)out;
     BlobArgs args;
     memset(&args, 0, sizeof(args));
     for (uint32_t b = 0; b < a->hplan.num_blobs; b++) {
@@ -643,6 +663,17 @@ int hydk_asm_result(HydkAsm *a, uint64_t *size, uint32_t *err) {
         *size = a->h_result[0];
     if (err)
         *err = (uint32_t)a->h_result[1];
+    return ST_OK;
+}
+
+/* after the stream has been synchronised: the frame's bytes, copied out of device memory */
+int hydk_asm_read(HydkAsm *a, uint8_t *dst, size_t capacity) {
+    if (!a || !dst || !a->last_out)
+        return afail(a, ST_API_ERROR, "nothing to read");
+    if (a->h_result[1] || !a->h_result[0] || a->h_result[0] > capacity)
+        return afail(a, ST_API_ERROR, "no finished frame of that size");
+    ASM_TRY(a, hipSetDevice(a->device));
+    ASM_TRY(a, hipMemcpy(dst, a->last_out, (size_t)a->h_result[0], hipMemcpyDeviceToHost));
     return ST_OK;
 }
 

@@ -206,6 +206,11 @@ struct HydAmdContext {
     uint64_t *h_total_pinned = nullptr;
     uint32_t *h_status_pinned = nullptr;
 
+    /* the drop-in API's frame assembly on the device (hydamd_export_frame_owned, hydamd_context_assembler) */
+    void *own_blob = nullptr;
+    size_t own_blob_cap = 0;
+    HydAmdAssembler *assembler = nullptr;
+
     /* profiling */
     bool profiling = false;
     std::vector<TimedLaunch> timed;
@@ -262,6 +267,16 @@ void host_input_lut(uint16_t *lut, size_t size, int linear_light) {
 }
 
 size_t sample_size(int fmt) { return fmt == HYDK_FMT_U8 ? 1 : fmt == HYDK_FMT_U16 ? 2 : 4; }
+
+/* forms 1-3 (several chains per wavefront, by rows) were replaced by form 5: select it, and say so once */
+int retired_rans_form(int waves) {
+    static bool told = false;
+    if (!told) {
+        told = true;
+        fprintf(stderr, "[hydrium] entropy-stage form %d no longer exists: using form 5 (one lane per group), its successor\n", waves);
+    }
+    return 1;
+}
 
 struct ScopedTimer {
     HydAmdContext *ctx;
@@ -555,6 +570,10 @@ void hydamd_destroy(HydAmdContext *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->assembler)
+        hydamd_assembler_destroy(ctx->assembler);
+    if (ctx->own_blob)
+        (void)hipFree(ctx->own_blob);
     drain_timers(ctx);
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
@@ -756,6 +775,8 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
         const int w = atoi(env);
         if (w == 4 || w == 5)
             ctx->rans_lanes = w == 5;
+        else if (w >= 1 && w <= 3)
+            ctx->rans_lanes = retired_rans_form(w);
     }
     if (const char *env = getenv("HYDAMD_LF_CODER")) /* 0: leave the LF ints to the host coder (A/B measurements) */
         ctx->lf_on_device = atoi(env) == 2 ? 2 : atoi(env) != 0;
@@ -831,6 +852,10 @@ int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode) {
 int hydamd_set_rans_waves(HydAmdContext *ctx, int waves) {
     if (!ctx)
         return ST_API_ERROR;
+    if (waves >= 1 && waves <= 3) { /* round 1's row forms: callers that still name one get their successor */
+        ctx->rans_lanes = retired_rans_form(waves);
+        return ST_OK;
+    }
     if (waves != 4 && waves != 5)
         return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group) or 5 (lane per group)");
     ctx->rans_lanes = waves == 5;
@@ -1063,6 +1088,10 @@ static int resolve_overflow(HydAmdContext *ctx, uint32_t status, bool *again) {
         return ST_OK;
     if (status & HYDK_STATUS_LAYOUT)
         return fail(ctx, ST_INTERNAL_ERROR, "float LF group in a context laid out for integer token records");
+    /* the LF coder forked onto its side stream may still be reading the LF ints and adding into the
+     * histograms the replay clears and rewrites: it has to be done before anything is re-laid or rerun */
+    if (ctx->lf_stream)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->lf_stream));
     size_t payload_cap = ctx->payload_cap;
     if (status & HYDK_STATUS_TOKENS) {
         if (ctx->tok_cap >= HYDK_TOKENS_PER_GROUP)
@@ -1174,6 +1203,42 @@ int hydamd_export_frame(HydAmdContext *ctx, int num_slots, void *device_dst, siz
                                      (const uint8_t *)ctx->lf_packed, ctx->lf_total, ctx->status, num_slots,
                                      ctx->lf_on_device ? 1 : 0, (uint8_t *)device_dst, capacity, ctx->stream));
     return ST_OK;
+}
+
+int hydamd_export_frame_owned(HydAmdContext *ctx, int num_slots, const void **blob_dev, size_t *capacity) {
+    if (!ctx || !blob_dev || !capacity)
+        return ST_API_ERROR;
+    const size_t need = hydamd_blob_bound(ctx, num_slots);
+    if (!need)
+        return fail(ctx, ST_API_ERROR, "slot count out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (need > ctx->own_blob_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* an assembly of the previous frame may still be reading the old one */
+        if (ctx->own_blob)
+            (void)hipFree(ctx->own_blob);
+        ctx->own_blob = nullptr;
+        ctx->own_blob_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->own_blob, need));
+        ctx->own_blob_cap = need;
+    }
+    const int st = hydamd_export_frame(ctx, num_slots, ctx->own_blob, ctx->own_blob_cap);
+    if (st != ST_OK)
+        return st;
+    *blob_dev = ctx->own_blob;
+    *capacity = ctx->own_blob_cap;
+    return ST_OK;
+}
+
+HydAmdAssembler *hydamd_context_assembler(HydAmdContext *ctx) {
+    if (!ctx)
+        return nullptr;
+    if (!ctx->assembler) {
+        int st = ST_OK;
+        ctx->assembler = hydamd_assembler_create(ctx->device, &st);
+        if (!ctx->assembler)
+            (void)fail(ctx, st, "frame assembler could not be created");
+    }
+    return ctx->assembler;
 }
 
 /* K2 + the rANS chains for slots [first, first + count); with_lf_codes: the lane-form launch also builds the

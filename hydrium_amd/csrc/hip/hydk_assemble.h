@@ -60,6 +60,8 @@ int hydk_asm_set_plan(HydkAsm *a, const void *plan, size_t bytes);
 int hydk_asm_run(HydkAsm *a, const void *const *blobs, const uint64_t *blob_caps, void *stream, void *out, uint64_t out_cap);
 /* after the stream has been synchronised: bytes of the frame (0 on failure) and the device's error word */
 int hydk_asm_result(HydkAsm *a, uint64_t *size, uint32_t *err);
+/* ... and the frame itself, copied from where the last run wrote it (out == NULL in hydk_asm_run: the assembler's own buffer) */
+int hydk_asm_read(HydkAsm *a, uint8_t *dst, size_t capacity);
 /* debugging / tests: the scratch the kernels left (host copies; any pointer may be NULL) */
 int hydk_asm_debug(HydkAsm *a, uint32_t slot, uint32_t *head_bits, uint32_t *head_words, size_t head_cap,
                    uint32_t *hfg_bits, uint32_t *hfg_words, size_t hfg_cap);

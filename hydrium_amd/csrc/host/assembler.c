@@ -297,11 +297,18 @@ HYDRIUM_EXPORT int hydamd_assembler_plan(HydAmdAssembler *a, const HYDImageMetad
     }
     for (uint32_t t = 0; t < plan.ntails; t++) {
         const HydBits *tail = hyd_internal_lf_tail(tail_vbw[t], tail_vbh[t]);
-        if (!tail) {
-            ret = AFAIL(a, HYD_NOMEM, "LF group tail could not be coded");
+        if (tail) {
+            plan.tail_off[t] = (uint32_t)buf_add_bits(&buf, tail, &plan.tail_bits[t]);
+            continue;
+        }
+        /* the process-wide cache of tails is full (it holds 32 shapes): code this one here */
+        hb_reset(&bits);
+        ret = hyd_write_lf_group_tail(&bits, tail_vbw[t], tail_vbh[t], &a->error);
+        if (ret || bits.failed) {
+            ret = AFAIL(a, ret ? ret : HYD_NOMEM, "LF group tail could not be coded");
             goto done;
         }
-        plan.tail_off[t] = (uint32_t)buf_add_bits(&buf, tail, &plan.tail_bits[t]);
+        plan.tail_off[t] = (uint32_t)buf_add_bits(&buf, &bits, &plan.tail_bits[t]);
     }
     if (buf.failed || bits.failed) {
         ret = AFAIL(a, HYD_NOMEM, "out of memory");
@@ -328,7 +335,7 @@ done:
 
 HYDRIUM_EXPORT int hydamd_assembler_run(HydAmdAssembler *a, const void *const *blobs_dev, const size_t *blob_caps, void *hip_stream,
                                         void *out, size_t out_cap) {
-    if (!a || !blobs_dev || !blob_caps || !out)
+    if (!a || !blobs_dev || !blob_caps)
         return a ? AFAIL(a, HYD_API_ERROR, "null argument") : HYD_API_ERROR;
     a->error = NULL;
     if (!a->key)
@@ -360,4 +367,11 @@ HYDRIUM_EXPORT int hydamd_assembler_result(HydAmdAssembler *a, size_t *size) {
     if (err & (HYDK_ASM_E_BLOB | HYDK_ASM_E_SLOT))
         return AFAIL(a, HYD_API_ERROR, "malformed LF-group blob");
     return AFAIL(a, HYD_INTERNAL_ERROR, "frame assembly failed on the device");
+}
+
+HYDRIUM_EXPORT int hydamd_assembler_read(HydAmdAssembler *a, uint8_t *dst, size_t capacity) {
+    if (!a || !dst)
+        return HYD_API_ERROR;
+    a->error = NULL;
+    return hydk_asm_read(a->dev, dst, capacity);
 }

@@ -402,11 +402,14 @@ done:
 }
 
 static void take_spare_buffer(HydBits *b); /* below, with the other spare-buffer functions */
+static void take_spare_buffer_for(HydBits *b, size_t want);
 
 static int emit_file_header(HYDEncoder *e) {
     if (e->wrote_header)
         return 0;
-    take_spare_buffer(&e->stream);
+    /* a byte per four pixels is more than photographic content needs; an encoder for a small image does not
+     * walk off with the 256 MB buffer a 16K frame left behind */
+    take_spare_buffer_for(&e->stream, (size_t)e->metadata.width * e->metadata.height / 4 + 65536);
     int ret = hyd_write_file_header(&e->stream, e->metadata.width, e->metadata.height, e->level10, e->icc, e->icc_size,
                                     &e->error);
     if (ret) {
@@ -531,13 +534,10 @@ static size_t ctx_pool_megabytes(void) {
 
 static void ctx_release(HydAmdContext *c, size_t slots, int linear, int healthy) {
     const int cap = ctx_pool_size();
-    size_t parked_mb = 0;
-    pthread_mutex_lock(&g_ctx_lock);
-    for (int i = 0; i < CTX_POOL_MAX; i++)
-        if (g_pool[i].ctx)
-            parked_mb += ctx_megabytes(g_pool[i].ctx, g_pool[i].slots);
-    pthread_mutex_unlock(&g_ctx_lock);
-    if (healthy && cap > 0 && parked_mb + ctx_megabytes(c, slots) <= ctx_pool_megabytes() && hydamd_sync(c) == HYD_OK) {
+    /* the wait for the context's stream happens before the lock; the budget check and the insertion under
+     * ONE acquisition of it, so that two encoders destroyed at the same time cannot both pass the check */
+    if (healthy && cap > 0 && hydamd_sync(c) == HYD_OK) {
+        const size_t mine = ctx_megabytes(c, slots);
         pthread_mutex_lock(&g_ctx_lock);
         int where = -1;
         for (int i = 0; i < cap && where < 0; i++)
@@ -549,10 +549,16 @@ static void ctx_release(HydAmdContext *c, size_t slots, int linear, int healthy)
                 if (g_pool[i].stamp < g_pool[where].stamp)
                     where = i;
         }
-        HydAmdContext *evicted = g_pool[where].ctx;
-        g_pool[where] = (ParkedCtx){c, slots, linear, ++g_stamp};
+        size_t parked_mb = 0;
+        for (int i = 0; i < CTX_POOL_MAX; i++)
+            if (g_pool[i].ctx && i != where)
+                parked_mb += ctx_megabytes(g_pool[i].ctx, g_pool[i].slots);
+        if (parked_mb + mine <= ctx_pool_megabytes()) {
+            HydAmdContext *evicted = g_pool[where].ctx;
+            g_pool[where] = (ParkedCtx){c, slots, linear, ++g_stamp};
+            c = evicted;
+        }
         pthread_mutex_unlock(&g_ctx_lock);
-        c = evicted;
     }
     if (c)
         hydamd_destroy(c);
@@ -585,15 +591,23 @@ typedef struct SpareBuf {
 static pthread_mutex_t g_buf_lock = PTHREAD_MUTEX_INITIALIZER;
 static SpareBuf g_spare[SPARE_SLOTS];
 
-/* an empty stream takes the largest spare buffer */
-static void take_spare_buffer(HydBits *b) {
+/* an empty stream takes a spare buffer: the smallest one that holds `want` bytes (0: unknown), else the largest */
+static void take_spare_buffer_for(HydBits *b, size_t want) {
     if (b->data)
         return;
     pthread_mutex_lock(&g_buf_lock);
     int best = -1;
-    for (int i = 0; i < SPARE_SLOTS; i++)
-        if (g_spare[i].p && (best < 0 || g_spare[i].cap > g_spare[best].cap))
+    for (int i = 0; i < SPARE_SLOTS; i++) {
+        if (!g_spare[i].p)
+            continue;
+        if (best < 0) {
             best = i;
+            continue;
+        }
+        const int fits = want && g_spare[i].cap >= want, best_fits = want && g_spare[best].cap >= want;
+        if (fits ? (!best_fits || g_spare[i].cap < g_spare[best].cap) : (!best_fits && g_spare[i].cap > g_spare[best].cap))
+            best = i;
+    }
     if (best >= 0) {
         b->data = g_spare[best].p;
         b->cap = g_spare[best].cap;
@@ -602,6 +616,7 @@ static void take_spare_buffer(HydBits *b) {
     }
     pthread_mutex_unlock(&g_buf_lock);
 }
+static void take_spare_buffer(HydBits *b) { take_spare_buffer_for(b, 0); }
 
 /* keeps p (returns 1) in a free slot or in place of a smaller spare, which is freed */
 static int offer_spare_buffer(void *p, size_t cap) {
@@ -738,11 +753,78 @@ static int device_fail(HYDEncoder *e, int code) {
     return code;
 }
 
+/* HYDAMD_HOST_ASSEMBLY=1: build frames on the host from read-back results, as round 2 did (A/B measurements, and the
+ * path every frame of a single group and every tile-mode frame still takes) */
+static int host_assembly_forced(void) {
+    static int on = -1;
+    if (on < 0) {
+        const char *v = getenv("HYDAMD_HOST_ASSEMBLY");
+        on = v && *v && *v != '0';
+    }
+    return on;
+}
+
+/* The frame put together on the GPU (csrc/hip/assemble.hip): the context exports its results as one blob in
+ * device memory, the assembler's kernels write every section into place behind the entropy stage, and the
+ * finished frame comes back in ONE copy — where the host used to read back tables, section sizes and LF
+ * streams slot by slot, code the LF group sections itself and splice everything together. */
+static int finish_frame_on_device(HYDEncoder *e, const HydFrameShape *shape) {
+    const size_t n = shape->lfg_count;
+    double t0 = now_ms();
+    int ret = hydamd_finish_frame(e->dev, (int)n);
+    if (ret)
+        return device_fail(e, ret);
+    HydAmdAssembler *as = hydamd_context_assembler(e->dev);
+    if (!as)
+        return device_fail(e, HYD_INTERNAL_ERROR);
+    uint32_t lf_ids[HYDAMD_MAX_LF_GROUPS];
+    for (size_t s = 0; s < n; s++)
+        lf_ids[s] = (uint32_t)shape->lfg[s].raster_id;
+    const uint32_t slots = (uint32_t)n;
+    ret = hydamd_assembler_plan(as, &e->metadata, 0, 1, 1, &slots, lf_ids, NULL, 0);
+    if (ret)
+        return FAIL(e, ret, "frame description rejected by the assembler");
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const void *blob = NULL;
+        size_t cap = 0, size = 0;
+        ret = hydamd_export_frame_owned(e->dev, (int)n, &blob, &cap);
+        if (!ret)
+            ret = hydamd_assembler_run(as, &blob, &cap, hydamd_get_stream(e->dev), NULL, 0);
+        if (ret)
+            return device_fail(e, ret);
+        ret = hydamd_sync(e->dev); /* a frame that outgrew the context's buffers is rerun in here: its blob is then stale */
+        if (ret)
+            return device_fail(e, ret);
+        TRACE("GPU hot path + assembly", t0);
+        t0 = now_ms();
+        ret = hydamd_assembler_result(as, &size);
+        if (ret) {
+            const char *m = hydamd_assembler_error(as);
+            if (m && strstr(m, "incomplete"))
+                continue; /* export the rerun frame's results and assemble again */
+            if (m && strstr(m, "NaN"))
+                return FAIL(e, HYD_API_ERROR, "Invalid NaN Float");
+            e->dev_failed = 1;
+            return FAIL(e, ret < HYD_ERROR_START ? ret : HYD_INTERNAL_ERROR, "GPU frame assembly failed");
+        }
+        uint8_t *dst = hb_extend(&e->stream, size);
+        if (!dst)
+            return FAIL(e, HYD_NOMEM, "out of memory");
+        ret = hydamd_assembler_read(as, dst, size);
+        TRACE("frame to the host", t0);
+        return ret ? device_fail(e, ret) : 0;
+    }
+    e->dev_failed = 1;
+    return FAIL(e, HYD_INTERNAL_ERROR, "frame still does not fit after enlarging its buffers");
+}
+
 /* read back everything the frame assembler needs and write the frame */
 static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
     const size_t n = shape->lfg_count;
     const size_t fg = ((shape->frame_width + 255) >> 8) * ((shape->frame_height + 255) >> 8);
     const int lf_on_gpu = hydamd_lf_coder(e->dev);
+    if (shape->one_frame && fg > 1 && lf_on_gpu && !host_assembly_forced())
+        return finish_frame_on_device(e, shape);
     /* With more than one group the LF groups are byte-aligned sections of their own: the LF coder is
      * then put in front of the entropy stage, so that its streams can be read back and wrapped
      * into sections on the host while the (2 ms, latency-bound) entropy stage is still running. */
@@ -1070,7 +1152,7 @@ static int frame_from_parts(const HYDImageMetadata *md, int write_header, int is
     if (!ret && !res)
         ret = HYD_NOMEM;
     if (!ret)
-        take_spare_buffer(&e->stream); /* also when no header is written */
+        take_spare_buffer_for(&e->stream, payload_len + (payload_len >> 3) + 65536); /* also when no header is written */
     if (!ret && write_header)
         ret = emit_file_header(e);
     if (!ret) {
@@ -1175,6 +1257,11 @@ HYDRIUM_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write
             *err = "null argument";
         return HYD_API_ERROR;
     }
+    if (!md->width || !md->height) { /* before the LF-group grid below divides by its width */
+        if (err)
+            *err = "invalid zero-width or zero-height";
+        return HYD_API_ERROR;
+    }
     size_t slots = 0, hf_total = 0;
     for (size_t b = 0; b < nblobs; b++) {
         const HydAmdBlobHeader *h = blobs[b];
@@ -1187,8 +1274,11 @@ HYDRIUM_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write
             return HYD_API_ERROR;
         }
         const uint64_t lf_off = sizeof(*h) + (uint64_t)h->num_slots * sizeof(HydAmdBlobSlot);
-        const uint64_t hf_off = (lf_off + h->lf_bytes + 15u) & ~(uint64_t)15u;
-        if (lf_off > h->total_bytes || hf_off + h->hf_bytes != h->total_bytes) {
+        /* every size is checked against the blob's own length before it enters a sum: a damaged lf_bytes near
+         * 2^64 must not wrap hf_off back into range */
+        const int sane = lf_off <= h->total_bytes && h->lf_bytes <= h->total_bytes - lf_off && h->hf_bytes <= h->total_bytes;
+        const uint64_t hf_off = sane ? (lf_off + h->lf_bytes + 15u) & ~(uint64_t)15u : 0;
+        if (!sane || hf_off > h->total_bytes || hf_off + h->hf_bytes != h->total_bytes) {
             if (err)
                 *err = bad;
             return HYD_API_ERROR;

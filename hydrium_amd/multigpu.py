@@ -153,7 +153,8 @@ class GpuShardEngine:
 
     def enqueue_entropy(self, floor_tensor):
         if self.n:
-            self.shard.ctx.set_alphabet_floor_device(floor_tensor)
+            if floor_tensor is not None:  # None: no LF group of the frame is coded before this shard's
+                self.shard.ctx.set_alphabet_floor_device(floor_tensor)
             self.shard.ctx.run_entropy(self.n)
 
     def blob_bound(self) -> int:
@@ -225,11 +226,37 @@ class FrameAssembly:
         self.size = self.asm.result()
         return self.out[:self.size]
 
+    def start_copy(self):
+        """Device output: start the one D2H copy of the finished frame on a stream of its own (the frame is
+        complete: finish() came after the stream's synchronisation), so that it overlaps the next frames' kernels."""
+        import torch
+
+        if self.pinned:
+            return
+        if getattr(self, "_host", None) is None or self._host.numel() < self.size:
+            self._host = torch.empty(max(self.size, self.out.numel()), dtype=torch.uint8).pin_memory()
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=torch.device("cuda", self.dev_index))
+        with torch.cuda.stream(self._copy_stream):
+            self._host[:self.size].copy_(self.out[:self.size], non_blocking=True)
+
+    def to_host(self):
+        """The finished frame in pinned host memory: the output buffer itself, or the copy start_copy() began
+        (started here if it was not)."""
+        if self.pinned:
+            return self.out[:self.size]
+        if getattr(self, "_copy_stream", None) is None or getattr(self, "_host", None) is None:
+            self.start_copy()
+        self._copy_stream.synchronize()
+        return self._host[:self.size]
+
     def close(self):
         self.asm.close()
+        self.out = self._host = self._copy_stream = None  # device blocks torch handed out under a context's stream go back before that stream dies
 
 
-def enqueue_frame(engine, parts, capacity: int, group=None, to_rank=0, assembly: Optional["FrameAssembly"] = None):
+def enqueue_frame(engine, parts, capacity: int, group=None, to_rank=0, assembly: Optional["FrameAssembly"] = None,
+                  exchange: Optional[bool] = None):
     """Everything a frame needs from this rank, enqueued without a host wait: transform stage ->
     all-gather of the per-LF-group alphabet maxima (one int32 per LF group, on the device) -> entropy
     stage with this rank's floor -> the shard's blob -> one gather of the blobs to ``to_rank`` -> with an
@@ -237,27 +264,38 @@ def enqueue_frame(engine, parts, capacity: int, group=None, to_rank=0, assembly:
     ``capacity`` is the blob size every rank sends (all ranks must pass the same value).  Returns a
     handle for ``collect_frame``.  Reference: presets are numbered across the whole frame
     (encoder.c:852-901) and the alphabet maximum runs over LF groups in send order
-    (entropy.c:459-460,952)."""
+    (entropy.c:459-460,952).  ``exchange``: run the two collectives even in a world of one (None: only
+    when there is someone to exchange with — a lone rank's floor is zero and its blob already is where
+    the assembler reads it)."""
     import torch
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    collectives = world > 1 if exchange is None else bool(exchange)
     most = max(max(len(p) for p in parts), 1)
     reruns = engine.overflow_reruns() if hasattr(engine, "overflow_reruns") else None
     engine.enqueue_transform()
     mine = engine.alphabet_maxima()
-    padded = torch.zeros(most, dtype=torch.int32, device=mine.device)
-    padded[:mine.numel()] = mine
-    every = torch.empty(world * most, dtype=torch.int32, device=mine.device)
-    dist.all_gather_into_tensor(every, padded, group=group)
-    before = every.view(world, -1)[:rank]
-    floor = (before.max() if before.numel() else torch.zeros((), dtype=torch.int32, device=mine.device)).reshape(1)
-    engine.enqueue_entropy(floor.to(torch.int32).contiguous())
+    every = padded = None
+    if collectives:
+        padded = torch.zeros(most, dtype=torch.int32, device=mine.device)
+        padded[:mine.numel()] = mine
+        every = torch.empty(world * most, dtype=torch.int32, device=mine.device)
+        dist.all_gather_into_tensor(every, padded, group=group)
+        before = every.view(world, -1)[:rank]
+        floor = (before.max() if before.numel() else torch.zeros((), dtype=torch.int32, device=mine.device)).reshape(1)
+        floor = floor.to(torch.int32).contiguous()
+    else:
+        floor = None  # no LF group is coded before this rank's
+    engine.enqueue_entropy(floor)
     cap = (int(capacity) + 15) & ~15
-    blob = torch.zeros(cap, dtype=torch.uint8, device=mine.device)
+    blob = torch.empty(cap, dtype=torch.uint8, device=mine.device)
     engine.export_blob(blob)
-    rows = [torch.empty(cap, dtype=torch.uint8, device=mine.device) for _ in range(world)] if rank == to_rank else None
-    dist.gather(blob, gather_list=rows, dst=to_rank, group=group)
+    if collectives:
+        rows = [torch.empty(cap, dtype=torch.uint8, device=mine.device) for _ in range(world)] if rank == to_rank else None
+        dist.gather(blob, gather_list=rows, dst=to_rank, group=group)
+    else:
+        rows = [blob]
     if assembly is not None and rank == to_rank:
         assembly.enqueue(rows, parts)
     return dict(engine=engine, blob=blob, rows=rows, to_rank=to_rank, rank=rank, keep=(every, padded, floor),
@@ -289,7 +327,8 @@ def collect_frame(handle):
     return bool(int(head["status"]) & device.BLOB_RETRY), handle["rows"]
 
 
-def choreograph_frame(engine, parts, group=None, capacity=None, to_rank=0, assembly: Optional["FrameAssembly"] = None):
+def choreograph_frame(engine, parts, group=None, capacity=None, to_rank=0, assembly: Optional["FrameAssembly"] = None,
+                      exchange: Optional[bool] = None):
     """One frame over the ranks of ``group`` (enqueue_frame + collect_frame, rerun if a shard says so).
     Returns the list of blobs (bytes, rank order) on ``to_rank`` — or, with an ``assembly``, the frame
     itself as bytes — and ``None`` elsewhere.  ``engine`` is a GpuShardEngine or anything with its
@@ -303,7 +342,7 @@ def choreograph_frame(engine, parts, group=None, capacity=None, to_rank=0, assem
         # every rank sends the same number of bytes: the largest bound any of them reports
         cap = torch.tensor([capacity or engine.blob_bound()], dtype=torch.int64, device=dev)
         dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
-        handle = enqueue_frame(engine, parts, int(cap.item()), group, to_rank, assembly)
+        handle = enqueue_frame(engine, parts, int(cap.item()), group, to_rank, assembly, exchange)
         again, rows = collect_frame(handle)
         retry = torch.tensor([1 if again else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(retry, op=dist.ReduceOp.MAX, group=group)
@@ -322,7 +361,7 @@ def choreograph_frame(engine, parts, group=None, capacity=None, to_rank=0, assem
 
 
 def encode_distributed(slab_tensor, width: int, height: int, origin_lf_pixels, group=None, linear_light: int = 0,
-                       lib=None, assemble_on_device: bool = True):
+                       lib=None, assemble_on_device: bool = True, exchange: Optional[bool] = None):
     """One process per GPU: this rank codes its LF groups out of ``slab_tensor`` (its part of the
     picture, already in its HBM); rank 0 returns the codestream, the others ``None``.  The frame is put
     together on rank 0's GPU from the gathered blobs and written straight into pinned host memory
@@ -342,7 +381,7 @@ def encode_distributed(slab_tensor, width: int, height: int, origin_lf_pixels, g
         if assemble_on_device and rank == 0 and FrameAssembly.supports(width, height):
             assembly = FrameAssembly(torch.cuda.current_device(), width, height, None, linear_light)
         with torch.cuda.stream(engine.stream):
-            blobs = choreograph_frame(engine, parts, group, assembly=assembly)
+            blobs = choreograph_frame(engine, parts, group, assembly=assembly, exchange=exchange)
         if blobs is None or assembly is not None:
             return blobs
         return device.frame_from_blobs(api.HYDImageMetadata(width, height, linear_light, -1, -1), blobs, lib=lib)

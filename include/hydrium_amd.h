@@ -87,7 +87,9 @@ HYDAMD_EXPORT int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode);
  *   5   one LANE per group: a single wavefront walks the 64 chains of an LF group and a second, wave-
  *       parallel kernel writes the bits straight into the payload; a fifteenth of the instructions and
  *       a sixty-fourth of the wavefronts of form 4 — best when many frames are in flight.  LF groups
- *       with float samples are still coded by form 4. */
+ *       with float samples are still coded by form 4.
+ * Round 1's row forms 1-3 are gone: asking for one of them (here or through HYDAMD_RANS_WAVES) selects
+ * form 5, which replaced them, and says so once on stderr. */
 HYDAMD_EXPORT int hydamd_set_rans_waves(HydAmdContext *ctx, int waves);
 
 /* Start a frame of `num_presets` presets (= LF groups, at most 255): clears histograms and the running alphabet. */
@@ -280,6 +282,14 @@ HYDAMD_EXPORT int hydamd_assembler_plan(HydAmdAssembler *a, const HYDImageMetada
 HYDAMD_EXPORT int hydamd_assembler_run(HydAmdAssembler *a, const void *const *blobs_dev, const size_t *blob_caps, void *hip_stream,
                                        void *out, size_t out_cap);
 HYDAMD_EXPORT int hydamd_assembler_result(HydAmdAssembler *a, size_t *size);
+/* `out` == NULL in hydamd_assembler_run: the frame goes to a device buffer the assembler owns (sized from the
+ * blob capacities), and this copies it to host memory once hydamd_assembler_result has said how large it is. */
+HYDAMD_EXPORT int hydamd_assembler_read(HydAmdAssembler *a, uint8_t *dst, size_t capacity);
+/* A context's own way to both: the blob of slots [0, num_slots) exported into a device buffer the context
+ * keeps (and grows) for the purpose, and an assembler that lives and is parked with the context.
+ * hyd_send_tile builds its frames with these. */
+HYDAMD_EXPORT int hydamd_export_frame_owned(HydAmdContext *ctx, int num_slots, const void **blob_dev, size_t *capacity);
+HYDAMD_EXPORT HydAmdAssembler *hydamd_context_assembler(HydAmdContext *ctx);
 
 /*
  * Wrap LF-group results — from this or other GPUs — into codestream bytes (host only, no GPU).
@@ -311,15 +321,17 @@ HYDAMD_EXPORT int hydamd_frame_from_streams(const HYDImageMetadata *md, int writ
                                             const uint32_t *alphabet, const uint32_t *group_bits, unsigned max_alphabet,
                                             const uint8_t *payload, size_t payload_len, const uint8_t *icc,
                                             size_t icc_size, uint8_t **out, size_t *out_len, const char **err);
-/* Releases a buffer returned by hydamd_frame_from_*.  The library may keep the last large one for the next
- * frame it assembles (mapped pages: a fresh 50 MB buffer costs 8 ms of page faults); at most one,
- * hydamd_trim_cache() lets go of it. */
+/* Releases a buffer returned by hydamd_frame_from_*.  The library may keep it for the next frame it
+ * assembles (mapped pages: a fresh 50 MB buffer costs 8 ms of page faults): up to four buffers of 1 MB to
+ * 256 MB each per process, i.e. at most 1 GB of host memory; the next frame or encoder takes the smallest
+ * one that fits it.  The buffer behind *out may therefore be larger than out_len.  hydamd_trim_cache()
+ * lets go of all of them. */
 HYDAMD_EXPORT void hydamd_free(void *p);
 
 /* hyd_encoder_destroy parks its device context (device memory, pinned staging, streams) for the next
  * encoder of the same shape instead of freeing it — up to HYDAMD_CONTEXT_CACHE contexts (default 4) and
  * HYDAMD_CONTEXT_CACHE_MB megabytes (default 8192) per process.  This releases whatever is parked, and the spare
- * frame buffer hydamd_free may have kept. */
+ * frame buffers hydamd_free may have kept. */
 HYDAMD_EXPORT void hydamd_trim_cache(void);
 
 /* ---- optional per-kernel timing with HIP events on the context's stream ---- */

@@ -38,7 +38,7 @@ class OracleShardEngine:
         return torch.tensor(self.maxima, dtype=torch.int32)
 
     def enqueue_entropy(self, floor_tensor):
-        running = int(floor_tensor.item())
+        running = int(floor_tensor.item()) if floor_tensor is not None else 0
         self.results = []
         for lf in self.lf_ids:
             r, running = self._code(lf, running)

@@ -158,7 +158,13 @@ def test_encode_distributed_over_rccl_world_of_one(image, kind, w, h, depth):
     t = _cuda(img)
     dist = _nccl_world_of_one()
     try:
-        got = multigpu.encode_distributed(t, w, h, lambda lf: ((lf // (-(-w // 2048))) * 2048, (lf % (-(-w // 2048))) * 2048))
+        origin = lambda lf: ((lf // (-(-w // 2048))) * 2048, (lf % (-(-w // 2048))) * 2048)
+        got = multigpu.encode_distributed(t, w, h, origin, exchange=True)  # the collectives, although nobody else is there
+        torch.cuda.synchronize()
+        # the same frame put together by rank 0's host from the gathered blobs (round 2's path), and with the exchange
+        # left out as a lone rank does by default
+        assert multigpu.encode_distributed(t, w, h, origin, exchange=True, assemble_on_device=False) == got
+        assert multigpu.encode_distributed(t, w, h, origin) == got
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()

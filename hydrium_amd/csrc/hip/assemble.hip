@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64) void k_asm_slots(const uint8_t *__restrict__ pl
     const HydkAsmSlot sl = ((const HydkAsmSlot *)(planb + plan->slots_off))[s];
     __shared__ uint32_t s_head[kHeadWords];
     __shared__ uint8_t s_len[HYDK_LF_CODES];
+    __shared__ HydkLfHeadScratch s_scratch;
     __shared__ uint32_t s_bits, s_err;
     const uint8_t *blob = blobs.p[sl.blob];
     const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)blob;
@@ -130,15 +131,21 @@ __global__ __launch_bounds__(64) void k_asm_slots(const uint8_t *__restrict__ pl
     if (lane == 0)
         s_err = 0;
     __syncthreads();
-    if (lane == 0) {
-        HydkSink sink = {s_head, 0, (uint64_t)kHeadWords * 32u, 0, 0};
+    {
+        /* the plan's constant bits first (whole words; the bits of the last one beyond lfpre_bits are zero), then the
+         * stream header's data-dependent part, written by the whole wavefront (hydk_sections.h) */
         const uint32_t *pre = (const uint32_t *)(planb + plan->lfpre_off);
-        for (uint32_t done = 0; done < plan->lfpre_bits; done += 32)
-            hks_put(&sink, pre[done >> 5], plan->lfpre_bits - done < 32 ? plan->lfpre_bits - done : 32);
-        const int ret = hydk_lf_prefix_codes(&sink, s_len, rec->lf.alphabet, rec->lf.run_pairs);
-        if (ret || sink.overflow)
-            s_err = HYDK_ASM_E_HEAD;
-        s_bits = sink.overflow ? 0u : (uint32_t)sink.pos;
+        for (uint32_t i = lane; i < (plan->lfpre_bits + 31u) >> 5; i += 64)
+            s_head[i] = pre[i];
+        __syncthreads();
+        uint64_t end = 0;
+        const int ret = hydk_lf_prefix_codes_wave(s_head, (uint64_t)kHeadWords * 32u, plan->lfpre_bits, s_len, rec->lf.alphabet,
+                                                  rec->lf.run_pairs, &s_scratch, &end);
+        if (lane == 0) {
+            if (ret)
+                s_err = HYDK_ASM_E_HEAD;
+            s_bits = ret ? 0u : (uint32_t)end;
+        }
     }
     __syncthreads();
     const uint32_t head_bits = s_bits;

@@ -442,6 +442,242 @@ HYDK_HD int hydk_lf_prefix_codes(HydkSink *s, const uint8_t *lengths, uint32_t a
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * The same header written by a WAVEFRONT: hydk_lf_prefix_codes costs one lane 0.35 ms per LF group (three
+ * walks over 384 code lengths, a bit at a time), and that sits on the critical path of every frame the device
+ * assembles.  Here the 384 compact entries are dealt to 64 lanes, six consecutive ones each; the phases below
+ * read only what earlier phases wrote, so on the device a phase is one pass of all lanes (wave_sync between
+ * phases) and on the host — where the CPU tests compare it with the serial writer and with prefix.c — a loop
+ * over the lanes.  Scans go through the scratch arrays: 64 short serial sums per lane, no cross-lane intrinsics.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct HydkLfHeadScratch {
+    uint32_t last_tok[64]; /* per lane: token + 1 of its last coded entry (0: it has none) */
+    uint32_t bits[64];     /* per lane: bits its entries take in the complex form */
+    uint32_t space[64];    /* per lane: Kraft weights (32768 >> length) of its entries */
+    uint32_t nonzero[64];  /* per lane: coded entries */
+    uint32_t l1_freq[18], l1_len[18], l1_bits[18];
+    uint32_t used, p0, err;
+} HydkLfHeadScratch;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HKS_LANES(l) for (int l = (int)threadIdx.x, hks_once_ = 1; hks_once_; hks_once_ = 0)
+#define HKS_SYNC()                                             \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+#define HKS_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#else
+#define HKS_LANES(l) for (int l = 0; l < 64; l++)
+#define HKS_SYNC() \
+    do {           \
+    } while (0)
+#define HKS_ATOMIC_ADD(p, v) (*(p) += (v))
+#endif
+
+/* the (value, width) one coded entry of the complex form sends: its zero run, then its length's code */
+HYDK_HD uint32_t hks_entry_bits(const uint32_t *l1_bits, const uint32_t *l1_len, uint32_t run, uint32_t len, uint64_t *value) {
+    HydkSink one = {(uint32_t *)0, 0, 64, 0, 0};
+    uint32_t w[2] = {0, 0};
+    one.w = w;
+    hks_zero_run(&one, l1_bits, l1_len, run);
+    hks_put(&one, l1_bits[len], l1_len[len]);
+    *value = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    return (uint32_t)one.pos; /* <= 5 x (5 + 3) + 5 = 45 */
+}
+
+/* Called by all 64 lanes of one wavefront (device) / once (host).  `words` (zeroed, `cap_bits` long) already holds
+ * `start` bits; lengths[] is the compact array of hydk_lf_prefix_codes.  Returns the bit position behind the header
+ * through *end (valid for every lane / the caller) and 0, or a non-zero error. */
+HYDK_HD int hydk_lf_prefix_codes_wave(uint32_t *words, uint64_t cap_bits, uint64_t start, const uint8_t *lengths,
+                                      uint32_t alphabet0, uint32_t run_pairs, HydkLfHeadScratch *S, uint64_t *end) {
+    /* phase 1: what every lane holds */
+    HKS_LANES(l) {
+        uint32_t last = 0, nz = 0, space = 0;
+        for (uint32_t k = 0; k < 6; k++) {
+            const uint32_t ci = (uint32_t)l * 6u + k, len = lengths[ci], tok = hks_lf_token(ci);
+            if (!len || tok >= alphabet0)
+                continue;
+            last = tok + 1;
+            nz++;
+            space += 32768u >> len;
+        }
+        S->last_tok[l] = last;
+        S->nonzero[l] = nz;
+        S->space[l] = space;
+        if (l < 18)
+            S->l1_freq[l] = 0;
+        if (l == 0)
+            S->err = 0;
+    }
+    HKS_SYNC();
+    uint32_t used_all = 0;
+    for (int i = 0; i < 64; i++)
+        used_all += S->nonzero[i];
+    if (used_all <= 4 || alphabet0 <= 1) {
+        /* at most four symbols: the simple form, a handful of fields — one lane writes the whole header */
+        HKS_LANES(l) {
+            if (l == 0) {
+                HydkSink sink = {words, start, cap_bits, 0, 0};
+                const int ret = hydk_lf_prefix_codes(&sink, lengths, alphabet0, run_pairs);
+                S->err = ret ? (uint32_t)ret : sink.overflow ? 100u : 0u;
+                S->p0 = (uint32_t)sink.pos;
+            }
+        }
+        HKS_SYNC();
+        *end = S->p0;
+        return (int)S->err;
+    }
+    /* phase 2: the histogram of the 18-symbol alphabet (zero runs, code lengths) */
+    HKS_LANES(l) {
+        uint32_t prev = 0;
+        for (int i = 0; i < l; i++)
+            prev = S->last_tok[i] ? S->last_tok[i] : prev;
+        for (uint32_t k = 0; k < 6; k++) {
+            const uint32_t ci = (uint32_t)l * 6u + k, len = lengths[ci], tok = hks_lf_token(ci);
+            if (!len || tok >= alphabet0)
+                continue;
+            uint32_t run = tok - prev;
+            if (run >= 3) {
+                uint32_t n17 = 1;
+                while (run > 10) {
+                    n17++;
+                    run = (run + 13) / 8;
+                }
+                HKS_ATOMIC_ADD(&S->l1_freq[17], n17);
+            } else if (run) {
+                HKS_ATOMIC_ADD(&S->l1_freq[0], run);
+            }
+            HKS_ATOMIC_ADD(&S->l1_freq[len], 1u);
+            prev = tok + 1;
+        }
+    }
+    HKS_SYNC();
+    /* phase 3: one lane — alphabet sizes, hskip, the code of code lengths */
+    HKS_LANES(l) {
+        if (l == 0) {
+            const uint8_t order[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+            const uint8_t lol_bits[6] = {0, 7, 3, 2, 1, 15}, lol_len[6] = {2, 4, 3, 2, 2, 4};
+            HydkSink sink = {words, start, cap_bits, 0, 0};
+            const uint32_t alphabet[2] = {alphabet0, run_pairs ? 2u : 0u};
+            for (int c = 0; c < 2; c++) {
+                if (alphabet[c] <= 1) {
+                    hks_put(&sink, 0, 1);
+                    continue;
+                }
+                hks_put(&sink, 1, 1);
+                const int n = hks_ilog2(alphabet[c] - 1u);
+                hks_put(&sink, (uint32_t)n, 4);
+                hks_put(&sink, alphabet[c] - 1u, (uint32_t)n);
+            }
+            hks_put(&sink, 0, 2); /* hskip = 0 */
+            uint32_t f[18], ln[18], bt[18];
+            for (int i = 0; i < 18; i++) {
+                f[i] = S->l1_freq[i];
+                ln[i] = bt[i] = 0;
+            }
+            int ret = hydk_small_code_lengths(f, ln, 18, 5);
+            uint32_t space = 0;
+            for (int j = 0; j < 18 && !ret; j++) {
+                const uint32_t len = ln[order[j]];
+                hks_put(&sink, lol_bits[len], lol_len[len]);
+                if (len)
+                    space += 32u >> len;
+                if (space >= 32)
+                    break;
+            }
+            if (!ret && space && space != 32)
+                ret = 4;
+            if (!ret)
+                ret = hydk_small_codes(ln, 18, bt);
+            for (int i = 0; i < 18; i++) {
+                S->l1_len[i] = ln[i];
+                S->l1_bits[i] = bt[i];
+            }
+            S->err = ret ? (uint32_t)ret : sink.overflow ? 100u : 0u;
+            S->p0 = (uint32_t)sink.pos;
+        }
+    }
+    HKS_SYNC();
+    if (S->err) {
+        *end = S->p0;
+        return (int)S->err;
+    }
+    /* phase 4: how many bits each lane's entries take.  A code is complete where its Kraft sum reaches 32768:
+     * nothing behind that entry is sent (entropy.c:797-799) — for the complete codes the LF coder builds that is
+     * its last entry */
+    HKS_LANES(l) {
+        uint32_t prev = 0, before = 0;
+        for (int i = 0; i < l; i++) {
+            prev = S->last_tok[i] ? S->last_tok[i] : prev;
+            before += S->space[i];
+        }
+        uint32_t bits = 0;
+        for (uint32_t k = 0; k < 6 && before < 32768u; k++) {
+            const uint32_t ci = (uint32_t)l * 6u + k, len = lengths[ci], tok = hks_lf_token(ci);
+            if (!len || tok >= alphabet0)
+                continue;
+            uint64_t v;
+            bits += hks_entry_bits(S->l1_bits, S->l1_len, tok - prev, len, &v);
+            before += 32768u >> len;
+            prev = tok + 1;
+        }
+        S->bits[l] = bits;
+    }
+    HKS_SYNC();
+    /* phase 5: every lane writes its entries at its offset */
+    HKS_LANES(l) {
+        uint32_t prev = 0, before = 0;
+        uint64_t pos = S->p0;
+        for (int i = 0; i < l; i++) {
+            prev = S->last_tok[i] ? S->last_tok[i] : prev;
+            before += S->space[i];
+            pos += S->bits[i];
+        }
+        HydkSink sink = {words, pos, cap_bits, 0, 1};
+        for (uint32_t k = 0; k < 6 && before < 32768u; k++) {
+            const uint32_t ci = (uint32_t)l * 6u + k, len = lengths[ci], tok = hks_lf_token(ci);
+            if (!len || tok >= alphabet0)
+                continue;
+            uint64_t v;
+            const uint32_t n = hks_entry_bits(S->l1_bits, S->l1_len, tok - prev, len, &v);
+            hks_put64(&sink, v, n);
+            before += 32768u >> len;
+            prev = tok + 1;
+        }
+        if (sink.overflow)
+            S->err = 100u;
+    }
+    HKS_SYNC();
+    /* phase 6: one lane — the zeros behind an incomplete code, then the distance cluster's code */
+    HKS_LANES(l) {
+        if (l == 0) {
+            uint64_t pos = S->p0;
+            uint32_t prev = 0, space = 0;
+            for (int i = 0; i < 64; i++) {
+                pos += S->bits[i];
+                prev = S->last_tok[i] ? S->last_tok[i] : prev;
+                space += S->space[i];
+            }
+            HydkSink sink = {words, pos, cap_bits, 0, 0};
+            if (space < 32768u)
+                hks_zero_run(&sink, S->l1_bits, S->l1_len, alphabet0 - prev);
+            if (run_pairs) { /* alphabet 2, no lengths: the lone-symbol form names symbol 1 in one bit */
+                hks_put(&sink, 1, 2);
+                hks_put(&sink, 0, 2);
+                hks_put(&sink, 1, 1);
+            }
+            if (sink.overflow)
+                S->err = 100u;
+            S->p0 = (uint32_t)sink.pos;
+        }
+    }
+    HKS_SYNC();
+    *end = S->p0;
+    return (int)S->err;
+}
+
+/* ---------------------------------------------------------------------------------------------
  * one TOC entry (encoder.c:117-120,994-1003): value and width; width 0 = the size cannot be signalled
  * ------------------------------------------------------------------------------------------- */
 HYDK_HD uint32_t hydk_toc_entry(uint64_t size, uint64_t *value) {

@@ -655,6 +655,37 @@ HYDT_EXPORT int hydt_lf_head_sections(const uint8_t *lengths, uint32_t alphabet0
     return ret;
 }
 
+/* ... and by the wavefront form of the same writer (on the host its 64 lanes run one after another) */
+HYDT_EXPORT int hydt_lf_head_wave(const uint8_t *lengths, uint32_t alphabet0, uint32_t run_pairs, uint8_t *out, size_t cap,
+                                  uint64_t *nbits) {
+    HydBits b;
+    const char *err = NULL;
+    hb_init(&b);
+    int ret = hyd_write_lf_group_fixed_head(&b, &err);
+    if (ret)
+        return ret;
+    const uint64_t fixed = hb_bit_count(&b);
+    hb_align(&b);
+    uint32_t *words = calloc(cap / 4 + 2, sizeof(uint32_t));
+    HydkLfHeadScratch *scratch = calloc(1, sizeof(*scratch));
+    if (!words || !scratch) {
+        free(words);
+        free(scratch);
+        hb_free(&b);
+        return ST_NOMEM;
+    }
+    memcpy(words, b.data, b.len);
+    hb_free(&b);
+    uint64_t end = 0;
+    ret = hydk_lf_prefix_codes_wave(words, (uint64_t)(cap / 4) * 32u, fixed, lengths, alphabet0, run_pairs, scratch, &end);
+    *nbits = end;
+    if (!ret)
+        memcpy(out, words, (size_t)((end + 7) >> 3));
+    free(words);
+    free(scratch);
+    return ret;
+}
+
 HYDT_EXPORT int hydt_ans_distribution_host(const uint32_t *freq, uint32_t alphabet, uint8_t *out, size_t cap, uint64_t *nbits) {
     HydBits b;
     hb_init(&b);

@@ -218,6 +218,12 @@ class FrameAssembly:
         need = sum(r.numel() for r, _ in keep) + (1 << 20)     # no frame is larger than its blobs plus its headers
         if self.out is None or self.out.numel() < need:
             self._allocate(need)
+        if getattr(self, "_copy_stream", None) is not None:
+            # the copy of the previous frame out of this buffer (start_copy) may still be running: the kernels that
+            # overwrite it wait for it on the device
+            import torch
+
+            torch.cuda.current_stream().wait_stream(self._copy_stream)
         self.asm.plan(self.md, [list(p) for _, p in keep], icc=self.icc)
         self.asm.run_tensors([r for r, _ in keep], self.out)
 
@@ -229,9 +235,11 @@ class FrameAssembly:
     def start_copy(self):
         """Device output: start the one D2H copy of the finished frame on a stream of its own (the frame is
         complete: finish() came after the stream's synchronisation), so that it overlaps the next frames' kernels."""
+        import os
+
         import torch
 
-        if self.pinned:
+        if self.pinned or os.environ.get("HYDAMD_BENCH_SKIP_D2H"):  # (the switch exists to measure what the copy costs)
             return
         if getattr(self, "_host", None) is None or self._host.numel() < self.size:
             self._host = torch.empty(max(self.size, self.out.numel()), dtype=torch.uint8).pin_memory()
@@ -247,6 +255,8 @@ class FrameAssembly:
             return self.out[:self.size]
         if getattr(self, "_copy_stream", None) is None or getattr(self, "_host", None) is None:
             self.start_copy()
+        if getattr(self, "_copy_stream", None) is None:
+            return self.out[:self.size]
         self._copy_stream.synchronize()
         return self._host[:self.size]
 

@@ -16,7 +16,7 @@ i=0
 for set in "${sets[@]}"; do
   i=$((i+1))
   rm -rf /tmp/pmc/p$i
-  rocprofv3 --pmc $set --kernel-include-regex "k_transform|k_rans|k_build|k_pack|k_scan|k_lf|k_frame_begin|k_publish" -d /tmp/pmc/p$i -o p -- "$@" > /tmp/pmc/log$i.txt 2>&1
+  rocprofv3 --pmc $set --kernel-include-regex "k_transform|k_rans|k_build|k_pack|k_scan|k_lf|k_frame_begin|k_publish|k_asm|k_export" -d /tmp/pmc/p$i -o p -- "$@" > /tmp/pmc/log$i.txt 2>&1
   db=$(find /tmp/pmc/p$i -name "*.db" | head -1)
   if [ -n "$db" ]; then python scripts/pmc_summary.py "$db" > "$out/pmc_set$i.txt" 2>&1; else tail -5 /tmp/pmc/log$i.txt > "$out/pmc_set$i.txt"; fi
 done

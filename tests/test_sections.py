@@ -16,7 +16,7 @@ LF_CODES, RUN_BASE = 384, 16384
 def lib():
     hbuild.build()
     d = C.CDLL(hbuild.HOSTTEST_PATH)
-    for name in ("hydt_lf_head_host", "hydt_lf_head_sections"):
+    for name in ("hydt_lf_head_host", "hydt_lf_head_sections", "hydt_lf_head_wave"):
         getattr(d, name).restype = C.c_int
         getattr(d, name).argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
     for name in ("hydt_ans_distribution_host", "hydt_ans_distribution_sections"):
@@ -95,9 +95,11 @@ def test_lf_stream_header(lib, case):
     for run_pairs in {pairs, 0 if n <= RUN_BASE else pairs}:
         a = _bits(lib.hydt_lf_head_host, lens.ctypes.data, n, run_pairs)
         b = _bits(lib.hydt_lf_head_sections, lens.ctypes.data, n, run_pairs)
-        assert a[0] == 0 and b[0] == 0
+        w = _bits(lib.hydt_lf_head_wave, lens.ctypes.data, n, run_pairs)
+        assert a[0] == 0 and b[0] == 0 and w[0] == 0
         assert a[1] == b[1], f"bit counts differ: host {a[1]} sections {b[1]}"
         assert a[2] == b[2]
+        assert w == a, "the wavefront form of the header writer differs from the host's"
         assert b[1] <= 640 * 32  # the assembler's per-slot scratch
 
 
@@ -113,7 +115,8 @@ def test_lf_stream_header_random(lib):
         lens, n, pairs = _lengths_for(lib, h)
         a = _bits(lib.hydt_lf_head_host, lens.ctypes.data, n, pairs)
         b = _bits(lib.hydt_lf_head_sections, lens.ctypes.data, n, pairs)
-        assert a == b and a[0] == 0
+        w = _bits(lib.hydt_lf_head_wave, lens.ctypes.data, n, pairs)
+        assert a == b == w and a[0] == 0
 
 
 def test_small_code_lengths(lib):

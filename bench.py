@@ -825,12 +825,14 @@ def main():
     # sharded over the GPUs, assembled on the device) and configs[4] (a batch of 4K frames through the drop-in API) ----
     legs = {}
     if not args.no_legs:
-        if not dist.is_initialized():
-            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
-                os.environ.setdefault(k, v)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        for name, fn in (("shard_16k", lambda: shard_leg(args, 40, 4, 16384, assemble=args.assemble)),
-                         ("batch_4k", lambda: batch_leg(args, args.frames, args.threads))):
+        def shard_16k():
+            if not dist.is_initialized():  # a lone rank needs the process group for this leg only: it comes last
+                for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                    os.environ.setdefault(k, v)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            return shard_leg(args, 40, 4, 16384, assemble=args.assemble)
+
+        for name, fn in (("batch_4k", lambda: batch_leg(args, args.frames, args.threads)), ("shard_16k", shard_16k)):
             try:
                 t_leg = time.perf_counter()
                 r = fn()

@@ -2,7 +2,7 @@
 infrastructure): ragged sizes, sample types, dark 16-bit content (mixed transfer-curve branches inside a wavefront),
 tile modes, layouts.  tests/test_gpu_fuzz.py runs a few hundred cases of it in the suite; as a script it is the longer
 sweep for spare GPU minutes.
-usage: python scripts/fuzz_api_parity.py [cases] [seed] [large]"""
+usage: [FUZZ_BUDGET_S=seconds] python scripts/fuzz_api_parity.py [cases] [seed] [large]"""
 import os
 import sys
 import time
@@ -69,7 +69,8 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
-    ran, bad = sweep(n, sd, len(sys.argv) > 3 and sys.argv[3] == "large")
+    budget = float(os.environ["FUZZ_BUDGET_S"]) if os.environ.get("FUZZ_BUDGET_S") else None
+    ran, bad = sweep(n, sd, len(sys.argv) > 3 and sys.argv[3] == "large", budget_s=budget)
     for b in bad:
         print("MISMATCH", b, flush=True)
     print(f"{ran} cases, seed {sd}: {len(bad)} mismatches, {time.time() - t0:.0f} s")

@@ -117,3 +117,16 @@ def test_without_a_gpu_the_product_fails_loudly(lib):
     with pytest.raises(api.HydriumError) as ei:
         api.encode_image(lib, img)
     assert ei.value.code == api.HYD_INTERNAL_ERROR and "no CPU fallback" in ei.value.message
+
+
+def test_the_device_assembler_has_no_cpu_fallback_either(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    d = lib.dll
+    d.hydamd_assembler_create.restype = C.c_void_p
+    d.hydamd_assembler_create.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    st = C.c_int(0)
+    assert not d.hydamd_assembler_create(0, C.byref(st))
+    assert st.value == api.HYD_INTERNAL_ERROR

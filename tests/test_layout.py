@@ -130,3 +130,38 @@ def test_the_device_assembler_has_no_cpu_fallback_either(lib):
     st = C.c_int(0)
     assert not d.hydamd_assembler_create(0, C.byref(st))
     assert st.value == api.HYD_INTERNAL_ERROR
+
+
+def test_frame_from_blobs_rejects_damaged_sizes_without_reading_past_the_blob(lib):
+    """lf_bytes near 2^64 must not wrap the HF offset back into range; zero-sized images are refused before
+    the LF-group grid divides by their width.  Host-only entry point: no GPU needed."""
+    import numpy as np
+
+    from hydrium_amd import device
+
+    d = lib.dll
+    d.hydamd_frame_from_blobs.restype = C.c_int
+    d.hydamd_frame_from_blobs.argtypes = [C.POINTER(api.HYDImageMetadata), C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)]
+    slot = device.BLOB_SLOT_DTYPE.itemsize
+    blob = np.zeros(64 + slot + 64, np.uint8)
+    head = blob[:64].view(device.BLOB_HEADER_DTYPE)
+    head["magic"], head["version"], head["num_slots"], head["lf_coded"] = device.BLOB_MAGIC, 1, 1, 1
+    head["total_bytes"] = blob.size
+
+    def call(md):
+        ptrs = (C.c_void_p * 1)(blob.ctypes.data)
+        sizes = (C.c_size_t * 1)(blob.size)
+        out, n, err = C.c_void_p(0), C.c_size_t(0), C.c_char_p(None)
+        return d.hydamd_frame_from_blobs(C.byref(md), 1, 1, 1, ptrs, sizes, None, 0, C.byref(out), C.byref(n), C.byref(err)), err.value
+
+    md = api.HYDImageMetadata(300, 200, 0, -1, -1)
+    lf_off = 64 + slot
+    for lf_bytes, hf_bytes in ((2 ** 64 - lf_off - 16, 64), (2 ** 64 - 1, 0), (32, 2 ** 63), (blob.size, 0)):
+        head["lf_bytes"], head["hf_bytes"] = lf_bytes, hf_bytes
+        code, msg = call(md)
+        assert code == api.HYD_API_ERROR and msg == b"malformed LF-group blob", (lf_bytes, hf_bytes, code, msg)
+    head["lf_bytes"], head["hf_bytes"] = 48, 0  # consistent sizes: 64 + slot + 48 -> HF at the next multiple of 16 = the end
+    code, msg = call(api.HYDImageMetadata(0, 200, 0, -1, -1))
+    assert code == api.HYD_API_ERROR and msg == b"invalid zero-width or zero-height"

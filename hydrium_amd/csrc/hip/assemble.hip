@@ -11,12 +11,14 @@
  * output the finished codestream in one buffer, and the host contributes a PLAN (hydk_assemble.h): the
  * bytes that do not depend on the pixels.
  *
- *   k_asm_slots     one wavefront per LF group: checks its blob and slot record, writes the bits in front of
- *                   the LF coefficient symbols (constant fields from the plan + alphabet sizes and prefix
- *                   codes, hydk_sections.h) and the TOC sizes of its sections
- *   k_asm_hfglobal  one workgroup: the ANS histograms of every cluster, each written by a thread at the bit
- *                   offset a prefix sum gives it
- *   k_asm_layout    one workgroup: TOC entries (same scheme), where every section goes, the frame's size
+ *   k_asm_prepare   one launch of (LF groups + 1) workgroups:
+ *       asm_slot      one per LF group: checks its blob and slot record, writes the bits in front of the LF
+ *                     coefficient symbols (constant fields from the plan + alphabet sizes and prefix codes, written
+ *                     by a wavefront, hydk_sections.h) and the TOC sizes of its sections
+ *       asm_hfglobal  the one behind them: the ANS histograms of every cluster, each written by a thread at the
+ *                     bit offset a prefix sum gives it
+ *       asm_layout    whichever workgroup finishes last: TOC entries (same scheme), where every section goes, the
+ *                     frame's size
  *   k_asm_copy      the frame as a list of PIECES, each the concatenation of up to three bit strings at a
  *                   byte offset; every output word is composed from its piece's strings (funnel shifts)
  *                   and stored once — a word that two pieces share is written byte by byte, so nothing is
@@ -73,15 +75,57 @@ struct Scratch { /* device pointers */
     Piece *pieces;        /* [kMaxPieces] */
     uint32_t *npieces;    /* [1] */
     uint32_t *err;        /* [1] */
+    uint32_t *done;       /* [1] workgroups of k_asm_prepare that have finished their part */
     uint64_t *result;     /* [2] size, error */
 };
 
+/* a blob whose two byte strings stay where the context keeps them (hydamd_export_frame_owned): header.lf_coded carries
+ * this mark and header.reserved[1..4] the device addresses of the packed LF streams and of the packed HF sections */
+constexpr uint32_t kLfCodedView = 0x101u;
+__device__ __forceinline__ const uint8_t *blob_lf_bytes(const uint8_t *blob) {
+    const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)blob;
+    if (h->lf_coded == kLfCodedView)
+        return (const uint8_t *)(((uint64_t)h->reserved[2] << 32) | h->reserved[1]);
+    return blob + sizeof(HydAmdBlobHeader) + (uint64_t)h->num_slots * sizeof(HydAmdBlobSlot);
+}
+__device__ __forceinline__ const uint8_t *blob_hf_bytes(const uint8_t *blob) {
+    const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)blob;
+    if (h->lf_coded == kLfCodedView)
+        return (const uint8_t *)(((uint64_t)h->reserved[4] << 32) | h->reserved[3]);
+    return blob + (h->total_bytes - h->hf_bytes);
+}
+/* header sane and consistent with the plan?  (0, or HYDK_ASM_E_* bits; nothing behind the header is touched) */
+__device__ __forceinline__ uint32_t blob_check(const uint8_t *blob, uint64_t cap, uint32_t want_slots) {
+    const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)blob;
+    if (cap < sizeof(HydAmdBlobHeader) || h->magic != kBlobMagic || h->version != 1 || h->num_slots != want_slots)
+        return HYDK_ASM_E_BLOB;
+    uint32_t e = 0;
+    if (h->status & HYDAMD_BLOB_RETRY)
+        e |= HYDK_ASM_E_RETRY;
+    if (h->status & 1u)
+        e |= HYDK_ASM_E_NAN;
+    if (e)
+        return e;
+    const uint64_t lf_off = sizeof(HydAmdBlobHeader) + (uint64_t)h->num_slots * sizeof(HydAmdBlobSlot);
+    if (h->lf_coded == kLfCodedView) {
+        if (h->total_bytes != lf_off || lf_off > cap || !(h->reserved[1] | h->reserved[2]) || !(h->reserved[3] | h->reserved[4]) ||
+            ((h->reserved[1] | h->reserved[3]) & 15u))
+            return HYDK_ASM_E_BLOB;
+        return 0;
+    }
+    const uint64_t hf_off = (lf_off + h->lf_bytes + 15ull) & ~15ull;
+    if (h->lf_coded != 1 || h->total_bytes > cap || lf_off > h->total_bytes || h->lf_bytes > h->total_bytes || h->hf_bytes > h->total_bytes ||
+        hf_off + h->hf_bytes != h->total_bytes)
+        return HYDK_ASM_E_BLOB;
+    return 0;
+}
+
 __device__ __forceinline__ const HydkAsmPlan *plan_of(const uint8_t *plan) { return (const HydkAsmPlan *)plan; }
 
-/* ---- k_asm_slots: grid = LF groups of the frame (send order), block = 64 ---- */
-__global__ __launch_bounds__(64) void k_asm_slots(const uint8_t *__restrict__ planb, BlobArgs blobs, Scratch S) {
+/* ---- one LF group (workgroup s of k_asm_prepare, 256 threads; the header itself is one wavefront's work) ---- */
+__device__ void asm_slot(const uint8_t *__restrict__ planb, const BlobArgs &blobs, const Scratch &S, int s) {
     const HydkAsmPlan *plan = plan_of(planb);
-    const int s = blockIdx.x, lane = threadIdx.x;
+    const int t = threadIdx.x;
     const HydkAsmSlot sl = ((const HydkAsmSlot *)(planb + plan->slots_off))[s];
     __shared__ uint32_t s_head[kHeadWords];
     __shared__ uint8_t s_len[HYDK_LF_CODES];
@@ -89,23 +133,9 @@ __global__ __launch_bounds__(64) void k_asm_slots(const uint8_t *__restrict__ pl
     __shared__ uint32_t s_bits, s_err;
     const uint8_t *blob = blobs.p[sl.blob];
     const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)blob;
-    uint32_t e = 0;
-    const uint64_t cap = blobs.cap[sl.blob];
-    uint64_t lf_off = 0;
-    if (cap < sizeof(HydAmdBlobHeader) || h->magic != kBlobMagic || h->version != 1 || h->num_slots != plan->blob_slots[sl.blob] ||
-        sl.index >= h->num_slots) {
-        e |= HYDK_ASM_E_BLOB;
-    } else {
-        if (h->status & HYDAMD_BLOB_RETRY)
-            e |= HYDK_ASM_E_RETRY;
-        if (h->status & 1u)
-            e |= HYDK_ASM_E_NAN;
-        lf_off = sizeof(HydAmdBlobHeader) + (uint64_t)h->num_slots * sizeof(HydAmdBlobSlot);
-        const uint64_t hf_off = (lf_off + h->lf_bytes + 15ull) & ~15ull;
-        if (!e && (h->lf_coded != 1 || h->total_bytes > cap || h->lf_bytes > h->total_bytes || h->hf_bytes > h->total_bytes ||
-                   hf_off + h->hf_bytes != h->total_bytes))
-            e |= HYDK_ASM_E_BLOB;
-    }
+    uint32_t e = blob_check(blob, blobs.cap[sl.blob], plan->blob_slots[sl.blob]);
+    if (!e && sl.index >= h->num_slots)
+        e = HYDK_ASM_E_BLOB;
     const HydAmdBlobSlot *rec = (const HydAmdBlobSlot *)(blob + sizeof(HydAmdBlobHeader)) + sl.index;
     if (!e) {
         const uint64_t lf_end = (uint64_t)rec->lf.offset + (((uint64_t)rec->lf.bit_count + 7) >> 3);
@@ -114,63 +144,63 @@ __global__ __launch_bounds__(64) void k_asm_slots(const uint8_t *__restrict__ pl
             e |= HYDK_ASM_E_SLOT;
     }
     if (e) {
-        if (lane == 0) {
+        if (t == 0) {
             atomicOr(S.err, e);
             S.head_bits[s] = 0;
             S.slot_hf[s] = 0;
             S.sizes[1 + s] = 0;
         }
-        for (uint32_t g = lane; g < sl.ngroups; g += 64)
+        for (uint32_t g = t; g < sl.ngroups; g += 256)
             S.sizes[2 + plan->num_slots + sl.group_base + g] = 0;
         return;
     }
-    for (int i = lane; i < kHeadWords; i += 64)
+    for (int i = t; i < kHeadWords; i += 256)
         s_head[i] = 0;
-    for (int i = lane; i < HYDK_LF_CODES; i += 64)
+    for (int i = t; i < HYDK_LF_CODES; i += 256)
         s_len[i] = rec->lf.lengths[i];
-    if (lane == 0)
+    if (t == 0)
         s_err = 0;
     __syncthreads();
     {
         /* the plan's constant bits first (whole words; the bits of the last one beyond lfpre_bits are zero), then the
-         * stream header's data-dependent part, written by the whole wavefront (hydk_sections.h) */
+         * stream header's data-dependent part, written by one wavefront (hydk_sections.h) */
         const uint32_t *pre = (const uint32_t *)(planb + plan->lfpre_off);
-        for (uint32_t i = lane; i < (plan->lfpre_bits + 31u) >> 5; i += 64)
+        for (uint32_t i = t; i < (plan->lfpre_bits + 31u) >> 5; i += 256)
             s_head[i] = pre[i];
-        __syncthreads();
+    }
+    __syncthreads();
+    uint64_t hf = 0;
+    uint32_t bad = 0;
+    if (t < 64) {
         uint64_t end = 0;
         const int ret = hydk_lf_prefix_codes_wave(s_head, (uint64_t)kHeadWords * 32u, plan->lfpre_bits, s_len, rec->lf.alphabet,
                                                   rec->lf.run_pairs, &s_scratch, &end);
-        if (lane == 0) {
+        if (t == 0) {
             if (ret)
                 s_err = HYDK_ASM_E_HEAD;
             s_bits = ret ? 0u : (uint32_t)end;
+        }
+        /* TOC sizes of this LF group's sections */
+        const uint32_t b = rec->group_bits[t];
+        if ((uint32_t)t < sl.ngroups) {
+            const uint64_t n = ((uint64_t)b + 7u) >> 3;
+            S.sizes[2 + plan->num_slots + sl.group_base + t] = n;
+            hf = n;
+        } else if (b) {
+            bad = 1; /* a group the frame's geometry does not have */
+        }
+#pragma unroll
+        for (int d = 32; d; d >>= 1) {
+            hf += __shfl_xor(hf, d);
+            bad |= (uint32_t)__shfl_xor((int)bad, d);
         }
     }
     __syncthreads();
     const uint32_t head_bits = s_bits;
     uint32_t *dst = S.head + (size_t)s * kHeadWords;
-    for (uint32_t i = lane; i < (head_bits + 31u) >> 5; i += 64)
+    for (uint32_t i = t; i < (head_bits + 31u) >> 5; i += 256)
         dst[i] = s_head[i];
-    /* TOC sizes of this LF group's sections */
-    uint64_t hf = 0;
-    uint32_t bad = 0;
-    {
-        const uint32_t b = rec->group_bits[lane];
-        if ((uint32_t)lane < sl.ngroups) {
-            const uint64_t n = ((uint64_t)b + 7u) >> 3;
-            S.sizes[2 + plan->num_slots + sl.group_base + lane] = n;
-            hf = n;
-        } else if (b) {
-            bad = 1; /* a group the frame's geometry does not have */
-        }
-    }
-#pragma unroll
-    for (int d = 32; d; d >>= 1) {
-        hf += __shfl_xor(hf, d);
-        bad |= (uint32_t)__shfl_xor((int)bad, d);
-    }
-    if (lane == 0) {
+    if (t == 0) {
         const uint64_t sec_bits = (uint64_t)head_bits + rec->lf.bit_count + plan->tail_bits[sl.tail];
         S.head_bits[s] = head_bits;
         S.sizes[1 + s] = (sec_bits + 7) >> 3;
@@ -210,14 +240,20 @@ __device__ __forceinline__ const HydAmdBlobSlot *slot_record(const uint8_t *plan
     return (const HydAmdBlobSlot *)(blobs.p[sl.blob] + sizeof(HydAmdBlobHeader)) + sl.index;
 }
 
-/* ---- k_asm_hfglobal: one workgroup of 256 ---- */
-__global__ __launch_bounds__(256) void k_asm_hfglobal(const uint8_t *__restrict__ planb, BlobArgs blobs, Scratch S) {
+/* ---- HFGlobal (the workgroup behind the LF groups' in k_asm_prepare, 256 threads) ---- */
+__device__ void asm_hfglobal(const uint8_t *__restrict__ planb, const BlobArgs &blobs, const Scratch &S) {
     const HydkAsmPlan *plan = plan_of(planb);
     __shared__ uint64_t s_wave[4];
     __shared__ uint32_t s_max;
     const int t = threadIdx.x;
-    if (*S.err) /* a blob could not be read: nothing below may follow its pointers */
-        return;
+    {
+        /* the LF groups' workgroups run beside this one: it checks the headers it is about to follow itself */
+        uint32_t e = 0;
+        if ((uint32_t)t < plan->num_blobs)
+            e = blob_check(blobs.p[t], blobs.cap[t], plan->blob_slots[t]);
+        if (__syncthreads_or((int)e))
+            return; /* the workgroup of one of that blob's LF groups reports why */
+    }
     const uint32_t per = plan->clusters_per_preset, C = plan->num_presets * per;
     if (t == 0)
         s_max = 0;
@@ -279,9 +315,9 @@ __global__ __launch_bounds__(256) void k_asm_hfglobal(const uint8_t *__restrict_
     }
 }
 
-/* ---- k_asm_layout: one workgroup of 256 ---- */
-__global__ __launch_bounds__(256) void k_asm_layout(const uint8_t *__restrict__ planb, BlobArgs blobs, Scratch S, uint64_t out_cap,
-                                                    uint64_t *h_result /* pinned host [2] */) {
+/* ---- TOC and layout (the workgroup of k_asm_prepare that finishes last, 256 threads) ---- */
+__device__ void asm_layout(const uint8_t *__restrict__ planb, const BlobArgs &blobs, const Scratch &S, uint64_t out_cap,
+                           uint64_t *h_result /* pinned host [2] */) {
     const HydkAsmPlan *plan = plan_of(planb);
     __shared__ uint64_t s_wave[4];
     const int t = threadIdx.x;
@@ -391,26 +427,23 @@ __global__ __launch_bounds__(256) void k_asm_layout(const uint8_t *__restrict__ 
     if ((uint32_t)t < nslots) {
         const HydkAsmSlot sl = ((const HydkAsmSlot *)(planb + plan->slots_off))[t];
         const uint8_t *blob = blobs.p[sl.blob];
-        const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)blob;
         const HydAmdBlobSlot *rec = (const HydAmdBlobSlot *)(blob + sizeof(HydAmdBlobHeader)) + sl.index;
-        const uint64_t lf_bytes_off = sizeof(HydAmdBlobHeader) + (uint64_t)h->num_slots * sizeof(HydAmdBlobSlot);
         Piece p = none;
         p.dst = lf_base + lf_off;
         p.nbytes = lf_mine;
         p.src[0] = S.head + (size_t)t * kHeadWords;
         p.nbits[0] = S.head_bits[t];
-        p.src[1] = (const uint32_t *)(blob + lf_bytes_off + rec->lf.offset);
+        p.src[1] = (const uint32_t *)(blob_lf_bytes(blob) + rec->lf.offset);
         p.nbits[1] = rec->lf.bit_count;
         p.src[2] = (const uint32_t *)(planb + plan->tail_off[sl.tail]);
         p.nbits[2] = plan->tail_bits[sl.tail];
         P[3 + t] = p;
     }
     if ((uint32_t)t < plan->num_blobs) {
-        const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)blobs.p[t];
         Piece p = none;
         p.dst = hf_base + hf_off;
         p.nbytes = hf_mine;
-        p.src[0] = (const uint32_t *)(blobs.p[t] + (h->total_bytes - h->hf_bytes));
+        p.src[0] = (const uint32_t *)blob_hf_bytes(blobs.p[t]);
         p.nbits[0] = hf_mine * 8u;
         P[4 + nslots + t] = p;
     }
@@ -425,6 +458,35 @@ __global__ __launch_bounds__(256) void k_asm_layout(const uint8_t *__restrict__ 
         S.result[1] = e;
         h_result[0] = S.result[0];
         h_result[1] = e;
+    }
+}
+
+/* ---- k_asm_prepare: grid = LF groups + 1, block = 256.  Workgroup s < LF groups: that LF group (asm_slot); the one
+ * behind them: HFGlobal; whichever finishes last: TOC and layout — one launch where three kernels and a memset used
+ * to sit in the stream (in a pipelined loop every launch of a frame costs latency in a GPU full of other frames'
+ * workgroups: export + five launches took 13 % of the frame rate for 1 % of its instructions) ---- */
+__global__ __launch_bounds__(256) void k_asm_prepare(const uint8_t *__restrict__ planb, BlobArgs blobs, Scratch S, uint64_t out_cap,
+                                                     uint64_t *h_result) {
+    __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else */
+    __shared__ int s_last;
+    const uint32_t nslots = plan_of(planb)->num_slots;
+    if (blockIdx.x < nslots)
+        asm_slot(planb, blobs, S, (int)blockIdx.x);
+    else
+        asm_hfglobal(planb, blobs, S);
+    __threadfence(); /* this workgroup's results before its tick */
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = atomicAdd(S.done, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last)
+        return;
+    __threadfence(); /* everyone else's results after the last tick */
+    asm_layout(planb, blobs, S, out_cap, h_result);
+    __syncthreads();
+    if (threadIdx.x == 0) { /* ready for the next frame */
+        *S.done = 0;
+        *S.err = 0;
     }
 }
 
@@ -550,7 +612,7 @@ void hydk_asm_destroy(HydkAsm *a) {
         return;
     (void)hipSetDevice(a->device);
     void *dev[] = {a->own_out, a->plan, a->S.head, a->S.head_bits, a->S.sizes, a->S.slot_hf, a->S.hfg, a->S.toc, a->S.pieces, a->S.npieces,
-                   a->S.err, a->S.result};
+                   a->S.err, a->S.done, a->S.result};
     for (void *p : dev)
         if (p)
             (void)hipFree(p);
@@ -572,6 +634,9 @@ static int asm_alloc(HydkAsm *a) {
     ASM_TRY(a, hipMalloc(&a->S.pieces, (size_t)kMaxPieces * sizeof(Piece)));
     ASM_TRY(a, hipMalloc(&a->S.npieces, sizeof(uint32_t)));
     ASM_TRY(a, hipMalloc(&a->S.err, sizeof(uint32_t)));
+    ASM_TRY(a, hipMalloc(&a->S.done, sizeof(uint32_t)));
+    ASM_TRY(a, hipMemset(a->S.err, 0, sizeof(uint32_t)));
+    ASM_TRY(a, hipMemset(a->S.done, 0, sizeof(uint32_t)));
     ASM_TRY(a, hipMalloc(&a->S.result, 2 * sizeof(uint64_t)));
     ASM_TRY(a, hipHostMalloc((void **)&a->h_result, 2 * sizeof(uint64_t), hipHostMallocDefault));
     a->h_result[0] = a->h_result[1] = 0;
@@ -629,10 +694,14 @@ int hydk_asm_run(HydkAsm *a, const void *const *blobs, const uint64_t *blob_caps
         return afail(a, ST_API_ERROR, "assembler not ready");
     ASM_TRY(a, hipSetDevice(a->device));
     hipStream_t st = (hipStream_t)stream;
-    if (!out) { /* the assembler's own device buffer: no frame is larger than its blobs plus its headers */
-        size_t need = (size_t)1 << 20;
-        for (uint32_t b = 0; b < a->hplan.num_blobs; b++)
-            need += (size_t)blob_caps[b];
+    if (!out) { /* the assembler's own device buffer: `out_cap` bytes if the caller names a size, else what the blobs could hold
+                 * (no frame is larger than its self-contained blobs plus its headers; views need a size from the caller) */
+        size_t need = (size_t)out_cap;
+        if (!need) {
+            need = (size_t)1 << 20;
+            for (uint32_t b = 0; b < a->hplan.num_blobs; b++)
+                need += (size_t)blob_caps[b];
+        }
         if (need > a->own_cap) {
             ASM_TRY(a, hipStreamSynchronize(st));
             if (a->own_out)
@@ -654,10 +723,8 @@ int hydk_asm_run(HydkAsm *a, const void *const *blobs, const uint64_t *blob_caps
         args.p[b] = (const uint8_t *)blobs[b];
         args.cap[b] = blob_caps[b];
     }
-    ASM_TRY(a, hipMemsetAsync(a->S.err, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_asm_slots, dim3(a->hplan.num_slots), dim3(64), 0, st, (const uint8_t *)a->plan, args, a->S);
-    hipLaunchKernelGGL(k_asm_hfglobal, dim3(1), dim3(256), 0, st, (const uint8_t *)a->plan, args, a->S);
-    hipLaunchKernelGGL(k_asm_layout, dim3(1), dim3(256), 0, st, (const uint8_t *)a->plan, args, a->S, out_cap, a->h_result);
+    hipLaunchKernelGGL(k_asm_prepare, dim3(a->hplan.num_slots + 1), dim3(256), 0, st, (const uint8_t *)a->plan, args, a->S, out_cap,
+                       a->h_result);
     hipLaunchKernelGGL(k_asm_copy, dim3(kCopyBlocks), dim3(256), 0, st, a->S, (uint8_t *)out);
     ASM_TRY(a, hipGetLastError());
     return ST_OK;

@@ -45,7 +45,7 @@ hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t 
 hipError_t launch_export(const HydkLfJob *d_jobs, const HydkTables *tabs, const uint32_t *group_bits, const HydkLfStream *lf_streams,
                          const uint8_t *payload, const uint64_t *hf_total, const uint8_t *lf_packed,
                          const unsigned long long *lf_total, const uint32_t *status, int num_slots, int lf_coded, uint8_t *dst,
-                         uint64_t capacity, hipStream_t stream);
+                         uint64_t capacity, int view, hipStream_t stream);
 hipError_t launch_rans(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint32_t *bitbuf,
                        uint32_t bit_pitch_words, uint32_t *group_bits, int preset_bits, int num_slots, const uint32_t *status,
                        hipStream_t stream);
@@ -1189,7 +1189,7 @@ size_t hydamd_blob_bound(HydAmdContext *ctx, int num_slots) {
     return sizeof(HydAmdBlobHeader) + (size_t)num_slots * sizeof(HydAmdBlobSlot) + lf + 16 + ctx->payload_cap + 16;
 }
 
-int hydamd_export_frame(HydAmdContext *ctx, int num_slots, void *device_dst, size_t capacity) {
+static int export_frame(HydAmdContext *ctx, int num_slots, void *device_dst, size_t capacity, int view) {
     if (!ctx || !device_dst)
         return ST_API_ERROR;
     if (num_slots < 1 || num_slots > ctx->coded || num_slots != ctx->slots_finished)
@@ -1201,16 +1201,24 @@ int hydamd_export_frame(HydAmdContext *ctx, int num_slots, void *device_dst, siz
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hydk::launch_export(ctx->d_jobs, ctx->tables, ctx->group_bits, ctx->lf_streams, ctx->payload, ctx->total,
                                      (const uint8_t *)ctx->lf_packed, ctx->lf_total, ctx->status, num_slots,
-                                     ctx->lf_on_device ? 1 : 0, (uint8_t *)device_dst, capacity, ctx->stream));
+                                     ctx->lf_on_device ? 1 : 0, (uint8_t *)device_dst, capacity, view, ctx->stream));
     return ST_OK;
+}
+
+int hydamd_export_frame(HydAmdContext *ctx, int num_slots, void *device_dst, size_t capacity) {
+    return export_frame(ctx, num_slots, device_dst, capacity, 0);
 }
 
 int hydamd_export_frame_owned(HydAmdContext *ctx, int num_slots, const void **blob_dev, size_t *capacity) {
     if (!ctx || !blob_dev || !capacity)
         return ST_API_ERROR;
-    const size_t need = hydamd_blob_bound(ctx, num_slots);
-    if (!need)
+    if (num_slots < 1 || num_slots > ctx->max_slots)
         return fail(ctx, ST_API_ERROR, "slot count out of range");
+    if (!ctx->lf_on_device)
+        return fail(ctx, ST_API_ERROR, "the owned blob needs the LF coder on");
+    /* a VIEW: header and slot records; the packed LF streams and HF sections stay in the context's own buffers and
+     * the header names their addresses — nothing of the frame's bulk is copied */
+    const size_t need = sizeof(HydAmdBlobHeader) + (size_t)num_slots * sizeof(HydAmdBlobSlot);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (need > ctx->own_blob_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* an assembly of the previous frame may still be reading the old one */
@@ -1221,7 +1229,7 @@ int hydamd_export_frame_owned(HydAmdContext *ctx, int num_slots, const void **bl
         HIP_TRY(ctx, hipMalloc(&ctx->own_blob, need));
         ctx->own_blob_cap = need;
     }
-    const int st = hydamd_export_frame(ctx, num_slots, ctx->own_blob, ctx->own_blob_cap);
+    const int st = export_frame(ctx, num_slots, ctx->own_blob, ctx->own_blob_cap, 1);
     if (st != ST_OK)
         return st;
     *blob_dev = ctx->own_blob;

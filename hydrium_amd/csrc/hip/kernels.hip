@@ -1673,13 +1673,15 @@ __global__ __launch_bounds__(kThreads) void k_export_frame(const HydkLfJob *__re
                                                            const uint8_t *payload, const uint64_t *hf_total,
                                                            const uint8_t *lf_packed, const unsigned long long *lf_total,
                                                            const uint32_t *status, int num_slots, int lf_coded,
-                                                           uint8_t *dst, uint64_t capacity) {
+                                                           uint8_t *dst, uint64_t capacity, int view) {
+    /* view: header and slot records only — the two byte strings stay where they are and the header carries their
+     * addresses (for an assembler on the same device, behind this kernel in the same stream: hydamd_export_frame_owned) */
     const int t = threadIdx.x, b = blockIdx.x;
     const uint64_t hf_bytes = *hf_total, lf_bytes = lf_coded ? (uint64_t)*lf_total : 0;
     const uint64_t lf_off = (uint64_t)kBlobHeaderBytes + (uint64_t)num_slots * kBlobSlotBytes;
-    const uint64_t hf_off = (lf_off + lf_bytes + 15ull) & ~15ull;
-    const uint64_t total = hf_off + hf_bytes;
-    const bool fits = total + 16 <= capacity; /* the copies below move whole 16-byte pieces */
+    const uint64_t hf_off = view ? lf_off : (lf_off + lf_bytes + 15ull) & ~15ull;
+    const uint64_t total = view ? lf_off : hf_off + hf_bytes;
+    const bool fits = view ? total <= capacity : total + 16 <= capacity; /* the copies below move whole 16-byte pieces */
     if (b < num_slots) {
         if (capacity < lf_off)
             return;
@@ -1715,13 +1717,19 @@ __global__ __launch_bounds__(kThreads) void k_export_frame(const HydkLfJob *__re
             h64[2] = hf_bytes;
             h64[3] = lf_bytes;
             h64[4] = total;
-            h32[10] = (uint32_t)lf_coded;
+            h32[10] = view ? 0x101u : (uint32_t)lf_coded;
             for (int i = 11; i < 16; i++)
                 h32[i] = 0;
+            if (view) {
+                h32[12] = (uint32_t)(uintptr_t)lf_packed;
+                h32[13] = (uint32_t)((uintptr_t)lf_packed >> 32);
+                h32[14] = (uint32_t)(uintptr_t)payload;
+                h32[15] = (uint32_t)((uintptr_t)payload >> 32);
+            }
         }
         return;
     }
-    if (!fits)
+    if (!fits || view)
         return;
     /* the two byte strings, 16 bytes per thread and step (both sources and both targets are 16-byte aligned) */
     const int cb = b - num_slots - 1;
@@ -1889,9 +1897,9 @@ hipError_t launch_pack(const uint32_t *bitbuf, uint32_t bit_pitch_words, const u
 hipError_t launch_export(const HydkLfJob *d_jobs, const HydkTables *tabs, const uint32_t *group_bits, const HydkLfStream *lf_streams,
                          const uint8_t *payload, const uint64_t *hf_total, const uint8_t *lf_packed,
                          const unsigned long long *lf_total, const uint32_t *status, int num_slots, int lf_coded, uint8_t *dst,
-                         uint64_t capacity, hipStream_t stream) {
-    hipLaunchKernelGGL(k_export_frame, dim3(num_slots + 1 + kExportCopyBlocks), dim3(kThreads), 0, stream, d_jobs, tabs,
-                       group_bits, lf_streams, payload, hf_total, lf_packed, lf_total, status, num_slots, lf_coded, dst, capacity);
+                         uint64_t capacity, int view, hipStream_t stream) {
+    hipLaunchKernelGGL(k_export_frame, dim3(num_slots + 1 + (view ? 0 : kExportCopyBlocks)), dim3(kThreads), 0, stream, d_jobs, tabs,
+                       group_bits, lf_streams, payload, hf_total, lf_packed, lf_total, status, num_slots, lf_coded, dst, capacity, view);
     return hipGetLastError();
 }
 

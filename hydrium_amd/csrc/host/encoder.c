@@ -788,8 +788,8 @@ static int finish_frame_on_device(HYDEncoder *e, const HydFrameShape *shape) {
         const void *blob = NULL;
         size_t cap = 0, size = 0;
         ret = hydamd_export_frame_owned(e->dev, (int)n, &blob, &cap);
-        if (!ret)
-            ret = hydamd_assembler_run(as, &blob, &cap, hydamd_get_stream(e->dev), NULL, 0);
+        if (!ret) /* the blob is a view: the output's size comes from the context's capacities (no frame exceeds them) */
+            ret = hydamd_assembler_run(as, &blob, &cap, hydamd_get_stream(e->dev), NULL, hydamd_blob_bound(e->dev, (int)n));
         if (ret)
             return device_fail(e, ret);
         ret = hydamd_sync(e->dev); /* a frame that outgrew the context's buffers is rerun in here: its blob is then stale */
@@ -1266,7 +1266,7 @@ HYDRIUM_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write
     for (size_t b = 0; b < nblobs; b++) {
         const HydAmdBlobHeader *h = blobs[b];
         if (!h || blob_sizes[b] < sizeof(*h) || h->magic != 0x42445948u || h->version != 1 || h->total_bytes > blob_sizes[b] ||
-            (h->status & HYDAMD_BLOB_RETRY) || !h->lf_coded) {
+            (h->status & HYDAMD_BLOB_RETRY) || h->lf_coded != 1) { /* 0: LF ints not coded; 0x101: a view, for device assemblers only */
             if (err)
                 *err = h && blob_sizes[b] >= sizeof(*h) && (h->status & HYDAMD_BLOB_RETRY)
                            ? "a blob is incomplete (its frame outgrew a buffer): rerun that shard"

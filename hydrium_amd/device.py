@@ -76,6 +76,7 @@ def dll(path: Optional[str] = None):
         d.hydamd_blob_bound.restype = sz
         d.hydamd_blob_bound.argtypes = [vp, i]
         d.hydamd_export_frame.argtypes = [vp, i, vp, sz]
+        d.hydamd_export_frame_owned.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz)]
         d.hydamd_frame_from_blobs.restype = i
         d.hydamd_frame_from_blobs.argtypes = [C.POINTER(api.HYDImageMetadata), i, i, sz, C.POINTER(vp), C.POINTER(sz),
                                               C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_char_p)]
@@ -230,6 +231,13 @@ class DeviceContext:
     def export_frame(self, num_slots: int, out_tensor):
         """Enqueue the blob of slots [0, num_slots) into a uint8 CUDA tensor (behind the entropy stage, no sync)."""
         self._ck(self.d.hydamd_export_frame(self.h, num_slots, out_tensor.data_ptr(), out_tensor.numel()))
+
+    def export_frame_owned(self, num_slots: int):
+        """Enqueue the blob of slots [0, num_slots) as a VIEW in the context's own small buffer (nothing of the frame's bulk
+        is copied; for an assembler on the same device and stream).  Returns (device pointer, readable bytes)."""
+        p, n = C.c_void_p(0), C.c_size_t(0)
+        self._ck(self.d.hydamd_export_frame_owned(self.h, num_slots, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
 
     def sync(self):
         self._ck(self.d.hydamd_sync(self.h))

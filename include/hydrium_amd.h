@@ -282,12 +282,17 @@ HYDAMD_EXPORT int hydamd_assembler_plan(HydAmdAssembler *a, const HYDImageMetada
 HYDAMD_EXPORT int hydamd_assembler_run(HydAmdAssembler *a, const void *const *blobs_dev, const size_t *blob_caps, void *hip_stream,
                                        void *out, size_t out_cap);
 HYDAMD_EXPORT int hydamd_assembler_result(HydAmdAssembler *a, size_t *size);
-/* `out` == NULL in hydamd_assembler_run: the frame goes to a device buffer the assembler owns (sized from the
- * blob capacities), and this copies it to host memory once hydamd_assembler_result has said how large it is. */
+/* `out` == NULL in hydamd_assembler_run: the frame goes to a device buffer the assembler owns — of `out_cap` bytes, or,
+ * with out_cap == 0, sized from the blob capacities (self-contained blobs only: a view's capacity says nothing about
+ * its frame; hydamd_blob_bound() of the exporting context is an upper bound for it) — and this copies it to host
+ * memory once hydamd_assembler_result has said how large it is. */
 HYDAMD_EXPORT int hydamd_assembler_read(HydAmdAssembler *a, uint8_t *dst, size_t capacity);
-/* A context's own way to both: the blob of slots [0, num_slots) exported into a device buffer the context
- * keeps (and grows) for the purpose, and an assembler that lives and is parked with the context.
- * hyd_send_tile builds its frames with these. */
+/* A context's own way to both: the blob of slots [0, num_slots) as a VIEW — header and slot records in a small device
+ * buffer the context keeps, the packed LF streams and HF sections left where the context has them, their addresses in
+ * the header (lf_coded = 0x101) — for an assembler on the same device and stream, valid until the context's next frame:
+ * nothing of the frame's bulk is copied.  hydamd_frame_from_blobs does not take views.  *capacity receives the readable
+ * bytes at *blob_dev.  And an assembler that lives and is parked with the context.  hyd_send_tile builds its frames
+ * with these. */
 HYDAMD_EXPORT int hydamd_export_frame_owned(HydAmdContext *ctx, int num_slots, const void **blob_dev, size_t *capacity);
 HYDAMD_EXPORT HydAmdAssembler *hydamd_context_assembler(HydAmdContext *ctx);
 

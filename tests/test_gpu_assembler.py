@@ -214,3 +214,32 @@ def test_c4_16384_photo_assembled_on_the_device_equals_the_reference():
     if refprobe.available():
         ref = api.encode_image(refprobe.reference_library(optimised=True), np.ascontiguousarray(t.cpu().numpy()))
         assert (len(got), hashlib.md5(got).hexdigest()) == (len(ref), hashlib.md5(ref).hexdigest())
+
+
+def test_a_context_s_own_view_blob(image):
+    """hydamd_export_frame_owned: header and slot records only, the sections stay in the context's buffers and the header
+    names their addresses — what hyd_send_tile assembles from.  Same file as from the self-contained blob; the host
+    assembler refuses a view."""
+    import torch
+    from hydrium_amd import device
+
+    w, h = 2048 + 333, 2048 + 90
+    img = image("photo", w, h, 16)
+    t = _cuda(img)
+    md = api.HYDImageMetadata(w, h, 0, -1, -1)
+    with device.DeviceContext(0, 4, 0) as ctx, device.Assembler(0) as asm:
+        ctx.encode_image_tensor(t)
+        full = torch.zeros(ctx.blob_bound(4), dtype=torch.uint8, device="cuda")
+        ctx.export_frame(4, full)
+        ptr, cap = ctx.export_frame_owned(4)
+        assert cap < 64 * 1024  # records only
+        out = torch.full((ctx.blob_bound(4),), 0x5A, dtype=torch.uint8, device="cuda")
+        asm.plan(md, [[0, 1, 2, 3]])
+        asm.run([ptr], [cap], out.data_ptr(), out.numel(), ctx.get_stream())
+        ctx.sync()
+        n = asm.result()
+        got = bytes(out[:n].cpu().numpy())
+        head = device.blob_header(full[:64].cpu().numpy().tobytes())
+        blob = full[: int(head["total_bytes"])].cpu().numpy().tobytes()
+    assert got == device.frame_from_blobs(md, [blob])
+    assert got == api.encode_image(api.Library(), img)

@@ -127,6 +127,7 @@ struct LfTokenScratch {
     int wtot[kLfWaves];       /* per wave: last run head inside it (absolute index) or -1 */
     uint32_t lastv[kLfWaves]; /* per wave: its last value (the next wave's lane 0 compares against it) */
     int head[kLfWaves];       /* backward scan: nearest run head each wave found, or -1 */
+    uint32_t first;           /* the window's first value */
 };
 
 /* value of the stream at plane c, block (y, x): pack_signed(lf - clamped_gradient(w, n, nw)),
@@ -236,12 +237,17 @@ __device__ __forceinline__ uint32_t lf_tokens_window(const HydkLfJob &job, const
         s_hist[i] = 0;
     uint32_t v[4];
     lf_fetch(dc, sh, tb + q0, v);
-    /* what lies in front of the window: the value at tb - 1 and the start of the run it belongs to */
+    /* what lies in front of the window: the value at tb - 1 and — only if the window's first value continues its run,
+     * which photographic content hardly ever does — the start of that run (a backward scan by the whole workgroup:
+     * until round 3 every window paid for it, a third of this kernel's instructions) */
     const uint32_t tailv = tb > 0 ? lf_value_at(dc, sh, tb - 1) : 0u;
-    const int carry = tb > 0 ? lf_run_start(dc, sh, tb - 1, S) : 0;
     if (lane == 63)
         S.lastv[wave] = v[3];
+    if (tid == 0)
+        S.first = v[0];
     __syncthreads();
+    const bool continues = tb > 0 && tb < sh.n && S.first == tailv; /* the same for every thread */
+    const int carry = continues ? lf_run_start(dc, sh, tb - 1, S) : 0;
 
     /* start of the run each position belongs to (absolute index): max-scan of run heads */
     uint32_t prev = LF_DPP_KEEP(v[3], 0x138, 0xF); /* wave_shr:1 — the previous lane's last value */

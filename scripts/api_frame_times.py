@@ -1,5 +1,7 @@
-import time, sys, ctypes, hashlib
-sys.path.insert(0, '.')
+"""Eight 8192x8192 RGB16 frames through the drop-in API, one at a time: per-frame wall time through the ctypes caller
+(the command rocprofv3 wraps for the API path's kernel trace)."""
+import time, sys, ctypes, hashlib, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from hydrium_amd import api, synth
 img = synth.make_image("photo", 8192, 8192, 16, device="cuda").cpu().numpy().view(np.uint16)

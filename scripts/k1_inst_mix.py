@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Instruction classes of the transform kernel's hot path, weighted by how often each part runs (task 2:
+"separate instruction mix from stalls").  Compiles kernels.hip to assembly here (hipcc cross-compiles), takes
+k_transform_tokenize<u16, register LUTs>, finds the straight-line regions of the strip loop by their landmarks, counts
+their VALU instructions per issue class (profiles/r02_valu_rate.txt) and prices them at the measured issue rates.
+
+  full rate  (1.12-1.28 ns per wave64 instruction and SIMD):  f32 add/sub/mul/fma, 32-bit add/sub, two-operand logic,
+                                                              right shifts, moves
+  half rate  (1.78-2.19 ns):   everything else on the VALU — conversions, multiply-high / 24-bit multiply-add, left
+                               shifts, three-operand integer ops, compares, selects, bit-field ops, DPP / SDWA forms
+  quarter    (3.5-3.8 ns):     v_rcp_f32
+
+usage: python scripts/k1_inst_mix.py > profiles/r03_k1_inst_mix.txt
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FULL = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_add_u32", "v_sub_u32", "v_subrev_u32",
+        "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_mov_b32", "v_not_b32"}
+QUARTER = {"v_rcp_f32"}
+NS = {"full": 1.20, "half": 1.98, "quarter": 3.65}  # mid-points of the measured ranges
+
+
+def classify(op, line):
+    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+    if base in QUARTER:
+        return "quarter"
+    if "dpp" in op or "sdwa" in op or " row_" in line or "quad_perm" in line:
+        return "half"
+    if base in FULL and not re.search(r"\bs\d+\b|\bs\[\d+:\d+\]", line.split(",", 1)[-1] if base.endswith("f32") else ""):
+        return "full"  # an f32 op with an SGPR operand issues at half rate
+    return "half"
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+                        f"-I{ROOT}/include", "-S", "--cuda-device-only", f"{ROOT}/hydrium_amd/csrc/hip/kernels.hip", "-o", out],
+                       check=True, capture_output=True)
+        text = open(out).read().splitlines()
+    start = next(i for i, l in enumerate(text) if l.startswith("_Z20k_transform_tokenizeILi1ELi0EEvPK9HydkLfJobPj:"))
+    end = next(i for i in range(start, len(text)) if ".end_amdhsa_kernel" in text[i])
+    body = text[start:end]
+    # straight-line regions = maximal runs of instructions without a label or a branch
+    regions, cur = [], []
+    for l in body:
+        s = l.strip()
+        if not s or s.startswith(";") or s.startswith("."):
+            if s.startswith(".LBB") and cur:
+                regions.append(cur)
+                cur = []
+            continue
+        op = s.split()[0]
+        cur.append((op, s))
+        if op.startswith("s_cbranch") or op == "s_branch" or op == "s_endpgm":
+            regions.append(cur)
+            cur = []
+    if cur:
+        regions.append(cur)
+
+    def count(reg):
+        c = {"full": 0, "half": 0, "quarter": 0, "salu": 0, "lds": 0, "vmem": 0}
+        for op, line in reg:
+            if op.startswith("v_"):
+                c[classify(op, line)] += 1
+            elif op.startswith("s_"):
+                c["salu"] += 1
+            elif op.startswith("ds_"):
+                c["lds"] += 1
+            elif op.startswith(("global_", "flat_", "buffer_", "scratch_")):
+                c["vmem"] += 1
+        return c
+
+    def has(reg, pat):
+        return any(re.search(pat, line) for _, line in reg)
+
+    # landmarks, in program order: the three wavefront-uniform variants of the XYB stage (24 v_rcp_f32 = 8 px x 3 cube roots: all
+    # pixels above the transfer curve's branch point / all below / mixed), the three row DCTs (one region, full rate only), then per
+    # channel a column DCT (107 full-rate ops) followed by its quantiser; what remains is the token walk and bookkeeping
+    counted = [(count(r), r) for r in regions]
+    xyb = [c for c, r in counted if c["quarter"] == 24]
+    rows = [c for c, r in counted if c["full"] >= 300 and c["half"] == 0 and c["quarter"] == 0]
+    cols, quants = [], []
+    for i, (c, r) in enumerate(counted):
+        if c["full"] == 107 and c["quarter"] == 0:
+            cols.append(c)
+            quants.append(next(q for q, _ in counted[i + 1:] if q["half"] >= 20))  # the next sizeable region: conversions, 24-bit multiply-adds
+    print("k_transform_tokenize<u16, register LUTs>: VALU instructions of the hot path by issue class — static counts of the compiled")
+    print("kernel per thread and strip (a thread owns 8 pixels of a strip, then one column of 8 coefficients per channel); issue rates")
+    print("from profiles/r02_valu_rate.txt\n")
+    print(f"{'region':64s} {'full':>6s} {'half':>6s} {'rcp':>5s} {'SALU':>6s} {'LDS':>5s} {'VMEM':>5s}")
+
+    def show(name, c):
+        print(f"{name:64s} {c['full']:6d} {c['half']:6d} {c['quarter']:5d} {c['salu']:6d} {c['lds']:5d} {c['vmem']:5d}")
+
+    for i, c in enumerate(xyb):
+        show(f"8 px -> XYB, transfer-curve variant {i}", c)
+    for c in rows:
+        show("three row DCTs (8 points each)", c)
+    for i, (c, q) in enumerate(zip(cols, quants)):
+        show(f"column DCT, channel {i}", c)
+        show(f"quantise + LF integer, channel {i}", q)
+    if len(xyb) == 3 and rows and len(cols) == 3:
+        a = sorted(xyb, key=lambda c: c["full"] + c["half"])[1]  # the cubic-only variant (bright 16-bit content): the middle one
+        tot = {k: a[k] + rows[0][k] + sum(c[k] for c in cols) + sum(c[k] for c in quants) for k in a}
+        per_px = {k: tot[k] / 8.0 for k in tot}
+        ns = sum(per_px[k] * NS[k] for k in NS)
+        n = sum(per_px[k] for k in NS)
+        print(f"\ntransform + quantise per pixel: {per_px['full']:.1f} full-rate + {per_px['half']:.1f} half-rate + {per_px['quarter']:.1f} v_rcp_f32 = {n:.1f} VALU")
+        print(f"  instructions; at the measured issue rates {ns:.0f} ns of SIMD time per pixel-lane = {ns / n:.2f} ns per instruction.")
+        total_px, total_ns = 265.5, 1.76
+        whole = total_px * total_ns
+        rest = total_px - n
+        share = 0.403 + 0.068 + 0.263  # profiles/r03_k1_phases.txt: XYB + row DCT + column DCT/quantise, s_memtime per phase
+        print(f"the kernel as a whole (PMC SQ_INSTS_VALU / pixels, rocprofv3 duration): {total_px:.0f} instructions per pixel at {total_ns:.2f} ns each")
+        print(f"  = {whole:.0f} ns.  The phase timers (profiles/r03_k1_phases.txt) give these stages {share * 100:.0f} % of it = {whole * share:.0f} ns, i.e.")
+        print(f"  {whole * share / n:.2f} ns per instruction against {ns / n:.2f} priced: {100 * (whole * share - ns) / (whole * share):.0f} % of the transform's time is not instruction issue (the pixel")
+        print("  loads at the head of a strip, LDS stores of the transpose, barrier skew); the other 4/5 is the mix itself.")
+        print(f"  The token walk, histogram and bookkeeping: {rest:.0f} instructions per pixel in the remaining {whole * (1 - share):.0f} ns = {whole * (1 - share) / rest:.2f} ns each —")
+        print("  half-rate classes almost throughout (compares, selects, bit-field ops, left shifts, DPP reductions; regions below),")
+        print("  issued by partly-active wavefronts, with the walk's LDS round trips (ds_read_u16, ds_add) on top.")
+        print("So the 1.76 ns average splits into: 1.36 ns that the instruction mix alone costs at the measured issue rates (17 % of the")
+        print("transform's instructions are half or quarter rate), ~0.3 ns of waits inside the transform, and a token walk at ~2 ns.")
+        print("A pure full-rate stream (1.12-1.28 ns) is not reachable for this arithmetic: exactness fixes the f32 operations one by one.")
+    print("\nother regions with >= 30 VALU instructions (token walk, LF/HF record stores, histogram flush, section bookkeeping):")
+    for c, r in counted:
+        if c["full"] + c["half"] >= 30 and c["quarter"] == 0 and c not in rows and c not in cols and c not in quants:
+            show("  " + r[-1][1][:44], c)
+
+
+if __name__ == "__main__":
+    main()

@@ -179,10 +179,11 @@ HYDK_HD int hks_node_before(const HydkSmallNode *a, const HydkSmallNode *b) {
     return d < 0;
 }
 
-/* returns 0, or a non-zero error; n <= HYDK_SMALL_N */
-HYDK_HD int hydk_small_code_lengths(const uint32_t *freq, uint32_t *lengths, uint32_t n, int max_depth) {
-    HydkSmallNode nodes[2 * HYDK_SMALL_N - 1];
-    int32_t stack[2 * HYDK_SMALL_N];
+/* returns 0, or a non-zero error; n <= HYDK_SMALL_N.  `nodes` [2 * HYDK_SMALL_N - 1] and `stack` [2 * HYDK_SMALL_N] are
+ * the caller's workspace: on the device it sits in LDS — as private arrays they are indexed dynamically and so live in
+ * scratch memory, where the ~1500 dependent accesses of an 18-symbol run cost 0.2 ms. */
+HYDK_HD int hydk_small_code_lengths_ws(const uint32_t *freq, uint32_t *lengths, uint32_t n, int max_depth, HydkSmallNode *nodes,
+                                       int32_t *stack) {
     uint32_t live_count = 0;
     for (uint32_t i = 0; i < 2 * n - 1; i++) {
         nodes[i].freq = i < n ? freq[i] : 0;
@@ -256,6 +257,12 @@ HYDK_HD int hydk_small_code_lengths(const uint32_t *freq, uint32_t *lengths, uin
         if (nodes[j].token)
             lengths[nodes[j].token - 1] = (uint32_t)nodes[j].depth;
     return 0;
+}
+
+HYDK_HD int hydk_small_code_lengths(const uint32_t *freq, uint32_t *lengths, uint32_t n, int max_depth) {
+    HydkSmallNode nodes[2 * HYDK_SMALL_N - 1];
+    int32_t stack[2 * HYDK_SMALL_N];
+    return hydk_small_code_lengths_ws(freq, lengths, n, max_depth, nodes, stack);
 }
 
 /* canonical codes, bit-reversed for an LSB-first writer (entropy.c:664-707); returns 0 or an error */
@@ -456,6 +463,8 @@ typedef struct HydkLfHeadScratch {
     uint32_t nonzero[64];  /* per lane: coded entries */
     uint32_t l1_freq[18], l1_len[18], l1_bits[18];
     uint32_t used, p0, err;
+    HydkSmallNode nodes[2 * HYDK_SMALL_N - 1]; /* workspace of the 18-symbol code construction */
+    int32_t stack[2 * HYDK_SMALL_N];
 } HydkLfHeadScratch;
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -571,15 +580,13 @@ HYDK_HD int hydk_lf_prefix_codes_wave(uint32_t *words, uint64_t cap_bits, uint64
                 hks_put(&sink, alphabet[c] - 1u, (uint32_t)n);
             }
             hks_put(&sink, 0, 2); /* hskip = 0 */
-            uint32_t f[18], ln[18], bt[18];
-            for (int i = 0; i < 18; i++) {
-                f[i] = S->l1_freq[i];
-                ln[i] = bt[i] = 0;
-            }
-            int ret = hydk_small_code_lengths(f, ln, 18, 5);
+            for (int i = 0; i < 18; i++)
+                S->l1_bits[i] = 0;
+            /* everything this lane indexes by a computed position stays in the scratch structure (LDS on the device) */
+            int ret = hydk_small_code_lengths_ws(S->l1_freq, S->l1_len, 18, 5, S->nodes, S->stack);
             uint32_t space = 0;
             for (int j = 0; j < 18 && !ret; j++) {
-                const uint32_t len = ln[order[j]];
+                const uint32_t len = S->l1_len[order[j]];
                 hks_put(&sink, lol_bits[len], lol_len[len]);
                 if (len)
                     space += 32u >> len;
@@ -589,11 +596,7 @@ HYDK_HD int hydk_lf_prefix_codes_wave(uint32_t *words, uint64_t cap_bits, uint64
             if (!ret && space && space != 32)
                 ret = 4;
             if (!ret)
-                ret = hydk_small_codes(ln, 18, bt);
-            for (int i = 0; i < 18; i++) {
-                S->l1_len[i] = ln[i];
-                S->l1_bits[i] = bt[i];
-            }
+                ret = hydk_small_codes(S->l1_len, 18, S->l1_bits);
             S->err = ret ? (uint32_t)ret : sink.overflow ? 100u : 0u;
             S->p0 = (uint32_t)sink.pos;
         }

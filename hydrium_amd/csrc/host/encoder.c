@@ -1003,8 +1003,10 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
     if (!ret && eager_on()) { /* work on this LF group while the caller prepares / we stage the next tile */
         ret = hydamd_submit_lf_group(e->dev, (int)slot);
         /* and every fourth tile the LF coder for the four just transformed: a launch of it takes
-         * 0.6 ms whether it codes one LF group or sixteen, four tiles take 2 ms to stage */
-        if (!ret && e->one_frame && (slot & 3) == 3 && hydamd_lf_coder(e->dev))
+         * 0.25 ms whether it codes one LF group or sixteen, four tiles take 2 ms to stage.  Not behind the frame's final
+         * tile: there nothing is left to hide it, and the closing stage runs it on a side stream beside the
+         * (2 ms, latency-bound) entropy stage instead of in front of it */
+        if (!ret && e->one_frame && (slot & 3) == 3 && !e->last_tile && hydamd_lf_coder(e->dev))
             ret = hydamd_run_lf_coder(e->dev, (int)slot + 1, 0);
     }
     if (ret)

@@ -78,6 +78,8 @@ def parse():
                     help="frame mode: leave out the configs[3] / configs[4] legs (shard_16k, batch_4k) and the LF-off leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true")
+    ap.add_argument("--no-bind", action="store_true",
+                    help="leave the process where the scheduler put it instead of binding it to the CPUs of the GPU's NUMA node")
     return ap.parse_args()
 
 
@@ -314,6 +316,10 @@ def run_shard(args):
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
+    if not args.no_bind:
+        from hydrium_amd import placement
+
+        placement.bind_near_gpu(local)
     for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29534"), ("RANK", "0"), ("WORLD_SIZE", "1")):
         os.environ.setdefault(k, v)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -414,6 +420,10 @@ def run_batch(args):
     os.environ["HYDAMD_DEVICE"] = str(local)
     os.environ.setdefault("HYDAMD_CONTEXT_CACHE", str(max(4, args.threads)))
     torch.cuda.set_device(local)
+    if not args.no_bind:
+        from hydrium_amd import placement
+
+        placement.bind_near_gpu(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     out = batch_leg(args, args.frames, args.threads)
@@ -441,6 +451,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP extension has no CPU fallback")
     torch.cuda.set_device(local)
     os.environ["HYDAMD_DEVICE"] = str(local)  # the drop-in API legs of this process encode on this rank's GPU
+    placement = None
+    if not args.no_bind:
+        from hydrium_amd import placement as _pl
+
+        placement = _pl.bind_near_gpu(local)  # as a deployment would (numactl): uploads run 20 % slower from the other socket
     os.environ.setdefault("HYDAMD_CONTEXT_CACHE", str(max(4, args.threads)))
     if use_dist:
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
@@ -796,6 +811,7 @@ def main():
                        "Mpixel/s_wall": round(world * W * H * total_frames / wall / 1e6, 1)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "host_placement": placement or "unbound",
             "config": {"workload": f"{W}x{H} RGB{args.depth} '{args.kind}' frame per GPU (BASELINE configs[2]); "
                                    "hot path device-resident RGB -> packed HF group sections "
                                    "(XYB, DCT, quantise, tokenise, ANS tables, rANS, pack)" +

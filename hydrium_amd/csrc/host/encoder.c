@@ -32,6 +32,9 @@
  *     header documents (libhydrium.h:222-226); the reference's hyd_send_tile drops the status of its
  *     closing hyd_flush and always says HYD_OK (libhydrium.c:193-202), so a caller written to the
  *     documented protocol would truncate its file there;
+ *   - tile-mode frames are pipelined: a tile's bytes (and an error its pixels cause) may surface up to
+ *     seven calls later than the reference's, in send order; the final tile's call completes them all
+ *     (tile_pipeline_depth below; the reference's own CLI loop, src/hydrium.c:463-476, is indifferent);
  *   - a one-frame tile sent twice is rejected with HYD_API_ERROR (the reference codes a corrupt
  *     frame: both copies land in the TOC permutation, encoder.c:241-325);
  *   - ICC profiles with the 'SGI ' or 'SUNW' platform signature: position 41 takes the default
@@ -52,6 +55,8 @@
 #include "prefix.h"
 #include "hydrium_amd.h"
 #include "libhydrium/libhydrium.h"
+
+#define TILE_PIPE_MAX 8
 
 typedef struct LfgResult {
     int32_t *dc; /* [3][vbh][vbw]; NULL when the LF coefficients were coded on the device */
@@ -91,6 +96,18 @@ struct HYDEncoder {
     size_t dev_slots;  /* shape the context was created for */
     int dev_linear;
     int dev_failed;    /* a device call failed: do not park this context for reuse */
+
+    /* tile mode: frames in flight (see tile_pipeline_depth).  A ring entry owns a device context for the life of the
+     * encoder; e->dev is then only the entry being worked on */
+    struct PendingTile {
+        HydAmdContext *dev;
+        int failed;
+        int active;          /* launched, not yet collected */
+        HydFrameLfg lfg;     /* the tile (the frame's only LF group) */
+        HydFrameShape shape; /* shape.lfg points at lfg above */
+    } pipe[TILE_PIPE_MAX];
+    int pipe_depth; /* 0: tile frames are coded synchronously through e->dev */
+    size_t tile_seq;
 };
 
 #define FAIL(enc, code, msg) ((enc)->error = (msg), (code))
@@ -238,6 +255,7 @@ static int code_lf_groups_parallel(HYDEncoder *e, const HydFrameShape *shape, co
 }
 
 static int device_fail(HYDEncoder *e, int code);
+static void pipe_release(HYDEncoder *e);
 
 /* payload == NULL: the packed HF sections are still on the device (e->dev) and are copied straight
  * into the output stream */
@@ -461,13 +479,13 @@ static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
 static ParkedCtx g_pool[CTX_POOL_MAX];
 static unsigned long g_stamp;
 
-/* HYDAMD_CONTEXT_CACHE: how many idle contexts may stay parked (default 4, 0 = none): one per
- * thread that encodes images back to back is what a batch job wants */
+/* HYDAMD_CONTEXT_CACHE: how many idle contexts may stay parked (default 8, 0 = none): one per
+ * thread that encodes images back to back is what a batch job wants, one per frame in flight a tile-mode encoder */
 static int ctx_pool_size(void) {
     static int n = -1;
     if (n < 0) {
         const char *v = getenv("HYDAMD_CONTEXT_CACHE");
-        n = v && *v ? atoi(v) : 4;
+        n = v && *v ? atoi(v) : CTX_POOL_MAX;
         if (n < 0)
             n = 0;
         if (n > CTX_POOL_MAX)
@@ -484,6 +502,28 @@ static int eager_on(void) {
         on = !(v && *v == '0');
     }
     return on;
+}
+
+/* Tile mode (tile_size_shift >= 0) makes every tile a frame of its own, and the reference hands its bytes over before
+ * hyd_send_tile returns (encoder.c:339-378, 1008).  Done that way on a GPU a tile costs the latency of the whole kernel
+ * sequence — 2-3 ms, most of it the serial rANS chain of its longest group, whether the tile is 256x256 or 2048x2048
+ * (measured: 32 Mpixel/s for 256x256 tiles, no better than one CPU core).  So up to HYDAMD_TILE_PIPELINE (default 8)
+ * tile frames are in flight, each on a device context of its own: a call stages and launches its tile and collects the
+ * frame launched `depth` calls earlier; frames reach the output in send order, and the call that sends the image's final
+ * tile collects everything.  What a caller sees: a tile's bytes arrive up to depth - 1 calls later than the reference's
+ * (the documented protocol — write what hyd_release_output_buffer reports, loop on HYD_NEED_MORE_OUTPUT — copes: in
+ * one-frame mode every call but the last already yields nothing).  HYDAMD_TILE_PIPELINE=1 is the reference's timing. */
+static int tile_pipeline_depth(void) {
+    static int n = -1;
+    if (n < 0) {
+        const char *v = getenv("HYDAMD_TILE_PIPELINE");
+        n = v && *v ? atoi(v) : TILE_PIPE_MAX;
+        if (n < 1)
+            n = 1;
+        if (n > TILE_PIPE_MAX)
+            n = TILE_PIPE_MAX;
+    }
+    return n;
 }
 
 /* HYDAMD_DEVICE: which GPU the drop-in API encodes on (default 0); a process per GPU sets it to its own */
@@ -568,6 +608,13 @@ static void ctx_release(HydAmdContext *c, size_t slots, int linear, int healthy)
  * public API
  * ------------------------------------------------------------------------------------------- */
 
+/* Frames in flight (tile-mode pipelining, encoders on several threads) live on HIP streams of their own, and the runtime
+ * spreads streams over GPU_MAX_HW_QUEUES hardware queues — 4 unless the process says otherwise, which serialises what was
+ * meant to overlap (eight tile frames in flight: 1.47 ms per 256x256 tile with 4 queues, 0.57 with 20; a batch of 4K
+ * frames on 8 threads: 628 frames/s against 1037).  The library asks for 20 when it is loaded, unless the environment
+ * already holds a value; the runtime reads it at its first call, so a process that used HIP before loading us keeps its own. */
+__attribute__((constructor)) static void hyd_ask_for_hardware_queues(void) { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
+
 HYDRIUM_EXPORT HYDEncoder *hyd_encoder_new(void) {
     HYDEncoder *e = calloc(1, sizeof(HYDEncoder));
     if (e)
@@ -648,6 +695,7 @@ static int offer_spare_buffer(void *p, size_t cap) {
 HYDRIUM_EXPORT HYDStatusCode hyd_encoder_destroy(HYDEncoder *e) {
     if (!e)
         return HYD_OK;
+    pipe_release(e);
     if (e->dev) {
         const double t0 = now_ms();
         ctx_release(e->dev, e->dev_slots, e->dev_linear, !e->dev_failed);
@@ -695,11 +743,13 @@ HYDRIUM_EXPORT HYDStatusCode hyd_set_metadata(HYDEncoder *e, const HYDImageMetad
     e->sent_mask = calloc(e->lfg_per_frame, 1);
     if (!e->sent || !e->sent_mask)
         return FAIL(e, HYD_NOMEM, "out of memory");
+    pipe_release(e);
     if (e->dev) { /* metadata changed: the device context is rebuilt lazily */
         ctx_release(e->dev, e->dev_slots, e->dev_linear, !e->dev_failed);
         e->dev = NULL;
     }
     e->have_metadata = 1;
+    e->tile_seq = 0;
     e->tiles_sent = 0;
     e->frame_done = 0;
     return HYD_OK;
@@ -818,25 +868,30 @@ static int finish_frame_on_device(HYDEncoder *e, const HydFrameShape *shape) {
     return FAIL(e, HYD_INTERNAL_ERROR, "frame still does not fit after enlarging its buffers");
 }
 
-/* read back everything the frame assembler needs and write the frame */
-static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
+/* The host-assembly path in two halves, both on e->dev: every kernel of the frame is enqueued (nothing waits) ... */
+static int finish_frame_launch(HYDEncoder *e, const HydFrameShape *shape) {
     const size_t n = shape->lfg_count;
     const size_t fg = ((shape->frame_width + 255) >> 8) * ((shape->frame_height + 255) >> 8);
-    const int lf_on_gpu = hydamd_lf_coder(e->dev);
-    if (shape->one_frame && fg > 1 && lf_on_gpu && !host_assembly_forced())
-        return finish_frame_on_device(e, shape);
     /* With more than one group the LF groups are byte-aligned sections of their own: the LF coder is
      * then put in front of the entropy stage, so that its streams can be read back and wrapped
      * into sections on the host while the (2 ms, latency-bound) entropy stage is still running. */
-    const int early_lf = lf_on_gpu && fg > 1;
-    double t0 = now_ms();
+    const int early_lf = hydamd_lf_coder(e->dev) && fg > 1;
     int ret = 0;
     if (early_lf)
         ret = hydamd_run_lf_coder(e->dev, (int)n, 1);
     if (!ret)
         ret = hydamd_finish_frame(e->dev, (int)n);
-    if (ret)
-        return device_fail(e, ret);
+    return ret ? device_fail(e, ret) : 0;
+}
+
+/* ... and everything the frame assembler needs is read back and the frame written */
+static int finish_frame_collect(HYDEncoder *e, const HydFrameShape *shape) {
+    const size_t n = shape->lfg_count;
+    const size_t fg = ((shape->frame_width + 255) >> 8) * ((shape->frame_height + 255) >> 8);
+    const int lf_on_gpu = hydamd_lf_coder(e->dev);
+    const int early_lf = lf_on_gpu && fg > 1;
+    double t0 = now_ms();
+    int ret = 0;
     LfgResult *res = calloc(n, sizeof(LfgResult));
     HydBits *lf_sections = NULL;
     HydAmdLfInfo *lf_info = NULL;
@@ -944,6 +999,41 @@ done:
     return ret;
 }
 
+static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
+    const size_t fg = ((shape->frame_width + 255) >> 8) * ((shape->frame_height + 255) >> 8);
+    if (shape->one_frame && fg > 1 && hydamd_lf_coder(e->dev) && !host_assembly_forced())
+        return finish_frame_on_device(e, shape);
+    const int ret = finish_frame_launch(e, shape);
+    return ret ? ret : finish_frame_collect(e, shape);
+}
+
+/* tile mode: the ring entry's frame, launched some calls ago, into the output stream */
+static int pipe_collect(HYDEncoder *e, struct PendingTile *p) {
+    e->dev = p->dev;
+    e->dev_failed = 0;
+    const int ret = finish_frame_collect(e, &p->shape);
+    p->failed |= e->dev_failed;
+    p->active = 0;
+    return ret;
+}
+
+static void pipe_release(HYDEncoder *e) {
+    for (int i = 0; i < TILE_PIPE_MAX; i++) {
+        struct PendingTile *p = &e->pipe[i];
+        if (!p->dev)
+            continue;
+        if (p->active && hydamd_sync(p->dev)) /* an abandoned image: its frames in flight are dropped */
+            p->failed = 1;
+        if (p->dev == e->dev && e->dev_failed)
+            p->failed = 1;
+        ctx_release(p->dev, e->dev_slots, e->dev_linear, !p->failed);
+        memset(p, 0, sizeof(*p));
+    }
+    if (e->pipe_depth)
+        e->dev = NULL; /* it was one of the ring's */
+    e->pipe_depth = 0;
+}
+
 HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buffer[3], uint32_t tile_x, uint32_t tile_y,
                                            ptrdiff_t row_stride, ptrdiff_t pixel_stride, int is_last,
                                            HYDSampleFormat sample_fmt) {
@@ -968,6 +1058,19 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
     if (ret)
         return ret;
 
+    struct PendingTile *pend = NULL;
+    if (!e->one_frame && tile_pipeline_depth() > 1) {
+        /* this tile's ring entry: the frame it still holds is the oldest in flight */
+        e->pipe_depth = tile_pipeline_depth();
+        pend = &e->pipe[e->tile_seq % (size_t)e->pipe_depth];
+        if (pend->active) {
+            ret = pipe_collect(e, pend);
+            if (ret)
+                return ret;
+        }
+        e->dev = pend->dev;
+        e->dev_failed = pend->failed;
+    }
     if (!e->dev) {
         int st = 0;
         const double tc = now_ms();
@@ -985,11 +1088,15 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
                                                    : "GPU initialisation failed");
         }
     }
+    if (pend)
+        pend->dev = e->dev; /* the ring owns it from here on, whatever happens to this tile */
     const size_t slot = e->one_frame ? e->tiles_sent : 0;
     if (slot == 0) {
+        const double tb = now_ms();
         ret = hydamd_begin_frame(e->dev, (unsigned)e->lfg_per_frame);
         if (ret)
             return device_fail(e, ret);
+        TRACE("begin frame", tb);
     }
     HydFrameLfg *l = &e->sent[slot];
     l->raster_id = e->one_frame ? (size_t)tile_y * e->lfg_count_x + tile_x : 0;
@@ -1036,9 +1143,32 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
     shape.lfg_count = e->lfg_per_frame;
     shape.lfg = e->sent;
     shape.is_last = e->last_tile;
-    ret = finish_frame(e, &shape);
-    if (ret)
-        return ret;
+    if (pend) {
+        pend->dev = e->dev;
+        pend->failed = e->dev_failed;
+        pend->lfg = e->sent[0];
+        pend->shape = shape;
+        pend->shape.lfg = &pend->lfg;
+        e->tile_seq++;
+        const double tl = now_ms();
+        ret = finish_frame_launch(e, &pend->shape);
+        TRACE("launch tile frame", tl);
+        pend->failed |= e->dev_failed;
+        if (ret)
+            return ret;
+        pend->active = 1;
+        if (e->last_tile) { /* the image ends here: every frame in flight, oldest first */
+            for (int i = 0; i < e->pipe_depth; i++) {
+                struct PendingTile *q = &e->pipe[(e->tile_seq + (size_t)i) % (size_t)e->pipe_depth];
+                if (q->active && (ret = pipe_collect(e, q)) != 0)
+                    return ret;
+            }
+        }
+    } else {
+        ret = finish_frame(e, &shape);
+        if (ret)
+            return ret;
+    }
     if (e->one_frame)
         e->frame_done = 1;
     /* the reference ends the tile with hyd_flush (encoder.c:1008): its error when no buffer is on loan

@@ -135,6 +135,59 @@ def test_abandoned_frame_leaves_a_reusable_context(lib, image):
     assert api.encode_image(lib, img) == want
 
 
+@pytest.mark.parametrize("shift,w,h,depth", [(0, 1300, 1100, 8), (1, 2300, 1500, 16), (0, 700, 2400, 16)])
+def test_tile_mode_with_more_tiles_than_frames_in_flight(lib, image, shift, w, h, depth):
+    """Tile-mode frames are pipelined (encoder.c tile_pipeline_depth: up to eight in flight, each on a device context of
+    its own, collected in send order): images of 30, 15 and 30 tiles, ragged at the right and bottom edges — the bytes
+    are the reference's, through the CLI's call pattern (flush after every tile) and the documented one."""
+    img = image("photo", w, h, depth)
+    want, _ = _expected(img, shift_x=shift, shift_y=shift)
+    assert api.encode_image(lib, img, shift_x=shift, shift_y=shift) == want
+    assert _encode_documented_protocol(lib, img, 1 << 16, shift) == want
+
+
+def test_tile_mode_image_abandoned_with_frames_in_flight(lib, image):
+    """An encoder destroyed (or given new metadata) while tile frames are in flight drops them and hands clean contexts
+    back; what follows — the same encoder on a new image, then a fresh one — is unaffected."""
+    import ctypes as C
+
+    img = image("photo", 1300, 1100, 8)
+    want, _ = _expected(img, shift_x=0, shift_y=0)
+    enc = api.Encoder(lib)
+    enc.check(enc.set_metadata(1300, 1100, 0, 0, 0))
+    buf = (C.c_uint8 * (1 << 20))()
+    enc.check(enc.provide_output(buf))
+    for t in range(11):                                   # more than one lap of the ring, none of them the last tile
+        enc.check(enc.send_tile(img, t % 6, t // 6, 256, 256))
+    other = image("smooth", 600, 520, 8)                  # new metadata on the same encoder: frames in flight are dropped
+    enc.check(enc.set_metadata(600, 520, 0, 1, 1))
+    enc.release_output()
+    enc.check(enc.provide_output(buf))
+    out = bytearray()
+    for ty in range(2):
+        for tx in range(2):
+            enc.check(enc.send_tile(other, tx, ty, 512, 512))
+            while True:
+                ret = enc.check(enc.flush())
+                code, n = enc.release_output()
+                enc.check(code)
+                out += C.string_at(buf, n)
+                enc.check(enc.provide_output(buf))
+                if ret != api.HYD_NEED_MORE_OUTPUT:
+                    break
+    enc.close()
+    # the reference writes the file header once per encoder, so the second image of a reused encoder has none: compare its tail
+    ref_other, _ = _expected(other, shift_x=1, shift_y=1)
+    assert bytes(out) == ref_other[len(ref_other) - len(out):] and len(out) > 1000
+    enc = api.Encoder(lib)
+    enc.check(enc.set_metadata(1300, 1100, 0, 0, 0))
+    enc.check(enc.provide_output(buf))
+    for t in range(5):
+        enc.check(enc.send_tile(img, t, 0, 256, 256))
+    enc.close()                                           # destroyed with five frames in flight
+    assert api.encode_image(lib, img, shift_x=0, shift_y=0) == want
+
+
 def test_two_encoders_on_two_threads(lib, image):
     """Distinct encoders may run on distinct threads (SURVEY 8b threading contract): the parked
     context, the LF-metadata cache and the staging threads are shared process state."""

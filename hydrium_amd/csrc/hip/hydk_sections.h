@@ -199,58 +199,69 @@ HYDK_HD int hydk_small_code_lengths_ws(const uint32_t *freq, uint32_t *lengths, 
         return 1;
     for (uint32_t k = 0; k + 1 < n; k++, live_count--) {
         const int32_t limit = max_depth - hks_clog2(live_count) + 1;
+        /* the two best candidates, their sort keys kept in registers: hks_node_before(j, best) spelled out */
         int32_t first = -1, second = -1;
+        uint32_t f1 = 0, f2 = 0;
+        int32_t t1 = 0, t2 = 0;
         for (uint32_t j = 2 * k; j < n + k; j++) {
-            if (!nodes[j].freq || nodes[j].deepest >= limit)
+            const uint32_t fj = nodes[j].freq;
+            if (!fj || nodes[j].deepest >= limit)
                 continue;
-            if (first < 0 || hks_node_before(&nodes[j], &nodes[first])) {
+            const int32_t tj = nodes[j].token;
+            /* candidates all have a weight: smaller weight first; equal weights: a leaf before a merged node, leaves by
+             * symbol, and a later merged node before an earlier one (hks_node_before with b->token == 0) */
+            const int before1 = first < 0 || (fj != f1 ? fj < f1 : !t1 ? 1 : !tj ? 0 : tj < t1);
+            if (before1) {
                 second = first;
+                f2 = f1;
+                t2 = t1;
                 first = (int32_t)j;
-            } else if (second < 0 || hks_node_before(&nodes[j], &nodes[second])) {
+                f1 = fj;
+                t1 = tj;
+            } else if (second < 0 || (fj != f2 ? fj < f2 : !t2 ? 1 : !tj ? 0 : tj < t2)) {
                 second = (int32_t)j;
+                f2 = fj;
+                t2 = tj;
             }
         }
         if (first < 0)
             return 2;
-        HydkSmallNode tmp = nodes[first];
-        nodes[first] = nodes[2 * k];
-        nodes[2 * k] = tmp;
+        if ((uint32_t)first != 2 * k) {
+            const HydkSmallNode tmp = nodes[first];
+            nodes[first] = nodes[2 * k];
+            nodes[2 * k] = tmp;
+        }
         if (second < 0)
             break; /* a single tree is left */
         if ((uint32_t)second == 2 * k)
             second = first;
-        tmp = nodes[second];
-        nodes[second] = nodes[2 * k + 1];
-        nodes[2 * k + 1] = tmp;
+        if ((uint32_t)second != 2 * k + 1) {
+            const HydkSmallNode tmp = nodes[second];
+            nodes[second] = nodes[2 * k + 1];
+            nodes[2 * k + 1] = tmp;
+        }
         HydkSmallNode *parent = &nodes[n + k];
         parent->freq = nodes[2 * k].freq + nodes[2 * k + 1].freq;
         parent->token = 0;
         parent->depth = parent->deepest = 0;
         parent->left = (int32_t)(2 * k);
         parent->right = (int32_t)(2 * k + 1);
-        /* every node of the new subtree moves one level down; a node's `deepest` is the largest depth
-         * below it: children are settled before their parents (lower slots), so one ascending pass over
-         * the subtree's slots after the depths are bumped recomputes them bottom-up */
+        /* every node of the new subtree moves one level down, and with it the largest depth below it (`deepest`);
+         * nothing outside the subtree changes.  The new root's own `deepest` is the larger of its children's. */
         int sp = 0;
         stack[sp++] = (int32_t)(n + k);
         while (sp) {
             const int32_t i = stack[--sp];
             nodes[i].depth++;
+            nodes[i].deepest++;
             if (nodes[i].left >= 0)
                 stack[sp++] = nodes[i].left;
             if (nodes[i].right >= 0)
                 stack[sp++] = nodes[i].right;
         }
-        for (uint32_t j = 0; j <= n + k; j++) {
-            /* settled slots (< 2k + 2) and the new parent: leaves first have deepest = depth */
-            if (j > 2 * k + 1 && j != n + k)
-                continue;
-            int32_t m = nodes[j].depth;
-            if (nodes[j].left >= 0 && nodes[nodes[j].left].deepest > m)
-                m = nodes[nodes[j].left].deepest;
-            if (nodes[j].right >= 0 && nodes[nodes[j].right].deepest > m)
-                m = nodes[nodes[j].right].deepest;
-            nodes[j].deepest = m;
+        {
+            const int32_t dl = nodes[2 * k].deepest, dr = nodes[2 * k + 1].deepest;
+            parent->deepest = dl > dr ? dl : dr; /* both >= 1, the depth the walk left the new root itself at */
         }
     }
     for (uint32_t j = 0; j < 2 * n - 1; j++)
@@ -268,7 +279,12 @@ HYDK_HD int hydk_small_code_lengths(const uint32_t *freq, uint32_t *lengths, uin
 /* canonical codes, bit-reversed for an LSB-first writer (entropy.c:664-707); returns 0 or an error */
 HYDK_HD int hydk_small_codes(const uint32_t *lengths, uint32_t n, uint32_t *bits) {
     uint64_t next = 0;
-    for (uint32_t len = 1; len <= 32; len++) {
+    uint32_t longest = 0;
+    for (uint32_t i = 0; i < n; i++)
+        longest = lengths[i] > longest ? lengths[i] : longest;
+    if (longest > 32)
+        longest = 32;
+    for (uint32_t len = 1; len <= longest; len++) {
         for (uint32_t i = 0; i < n; i++) {
             if (lengths[i] != len)
                 continue;

@@ -121,10 +121,21 @@ def test_lf_stream_header_random(lib):
 
 def test_small_code_lengths(lib):
     rng = np.random.default_rng(3)
-    for trial in range(400):
+    for trial in range(3000):
         f = np.zeros(18, np.uint32)
         k = int(rng.integers(1, 19))
-        f[rng.choice(18, size=k, replace=False)] = rng.integers(1, 400 if trial % 2 else 6, size=k)
+        kind = trial % 5
+        if kind == 0:
+            vals = rng.integers(1, 6, size=k)           # many ties
+        elif kind == 1:
+            vals = rng.integers(1, 400, size=k)
+        elif kind == 2:
+            vals = 1 << rng.permutation(18)[:k]         # geometric: the depth limit (5) has to flatten the tree
+        elif kind == 3:
+            vals = np.full(k, int(rng.integers(1, 50)))  # all equal: merged nodes tie with one another
+        else:
+            vals = (rng.pareto(0.7, size=k) * 3 + 1).astype(np.int64)
+        f[rng.choice(18, size=k, replace=False)] = np.minimum(vals, 1 << 20)
         a, b = np.zeros(18, np.uint32), np.zeros(18, np.uint32)
         ra = lib.hydt_code_lengths(f.ctypes.data, a.ctypes.data, 18, 5)
         rb = lib.hydt_small_code_lengths(f.ctypes.data, b.ctypes.data, 18, 5)

@@ -101,6 +101,20 @@ def test_nan_sample_is_an_api_error(lib):
     assert ei.value.code == api.HYD_API_ERROR and ei.value.message == "Invalid NaN Float"
 
 
+def test_nan_sample_in_a_pipelined_tile_frame_is_an_api_error(lib, image):
+    """Tile mode keeps frames in flight: the error of a tile's pixels surfaces when its frame is collected — a later
+    call, at the latest the final tile's — with the reference's message; the library is usable afterwards."""
+    from hydrium_amd import synth
+
+    f = synth.make_image_f32("photo", 600, 520).copy()
+    f[300, 300, 1] = np.nan                                # tile (1, 1) of 3 x 3
+    with pytest.raises(api.HydriumError) as ei:
+        api.encode_image(lib, f, shift_x=0, shift_y=0)
+    assert ei.value.code == api.HYD_API_ERROR and ei.value.message == "Invalid NaN Float"
+    good = image("photo", 600, 520, 8)
+    assert api.encode_image(lib, good, shift_x=0, shift_y=0) == _expected(good, shift_x=0, shift_y=0)[0]
+
+
 def test_golden_manifest(lib, image):
     """Fixtures generated from the reference by tests/golden/make_golden.py."""
     with open(os.path.join(GOLDEN, "manifest.json")) as f:

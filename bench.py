@@ -520,8 +520,13 @@ def main():
                 for q in range(j * per, j * per + per):
                     xstream.wait_stream(ext[q])
             # one frame per collective: issued under the context's own stream (RCCL's stream waits for it through an event)
+            # the assembling rank rotates with the collective (as in --mode shard): every rank receives world blobs every
+            # world-th time instead of rank 0 receiving all of them — inbound bytes per rank = its outbound bytes, and the
+            # max-over-ranks time is not one rank's
+            root = (i // per) % world
             with torch.cuda.stream(xstream if per > 1 else ext[k]):
-                xstate["work"][j][half] = dist.gather(xstate["big"][j][half].view(-1), gather_list=xstate["rows"][j], dst=0,
+                xstate["work"][j][half] = dist.gather(xstate["big"][j][half].view(-1),
+                                                      gather_list=xstate["rows"][j] if rank == root else None, dst=root,
                                                       async_op=True)
             xt[1] += time.perf_counter() - t_b
         return ctx
@@ -554,8 +559,8 @@ def main():
         del probe
         for j in range(ngroups):
             xstate["big"][j] = [torch.zeros((per, xstate["cap"]), dtype=torch.uint8, device=img.device) for _ in range(2)]
-            if rank == 0:
-                xstate["rows"][j] = [torch.empty(per * xstate["cap"], dtype=torch.uint8, device=img.device) for _ in range(world)]
+            # every rank takes its turn as the root
+            xstate["rows"][j] = [torch.empty(per * xstate["cap"], dtype=torch.uint8, device=img.device) for _ in range(world)]
     for i in range(args.warmup):
         step(i)
     drain()
@@ -819,7 +824,7 @@ def main():
                        "lf_coder": "gpu, in-stream" if args.lf_coder == "on" else "off",
                        "groups": lfg * 64 if W % 2048 == 0 and H % 2048 == 0 else None, "lf_groups": lfg,
                        "streams": len(ctxs), "rans_groups_per_workgroup": args.rans_waves, "parallelism": f"{world} x (one frame per GPU)" +
-                                                            (f", one RCCL gather of result blobs per {per} frames to rank 0" if use_dist else "")},
+                                                            (f", one RCCL gather of result blobs per {per} frames, root rotating over the ranks" if use_dist else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_in, "avg_launch_ms": round(dom_ms, 4),

@@ -84,6 +84,13 @@ class Library:
         d.hyd_error_message_get.argtypes = [C.c_void_p]
         d.hyd_set_suggested_icc_profile.restype = C.c_int
         d.hyd_set_suggested_icc_profile.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        # additive knob of this build (include/hydrium_amd.h); the reference library has no such symbol
+        self.has_tile_pipeline = hasattr(d, "hydamd_set_tile_pipeline")
+        if self.has_tile_pipeline:
+            d.hydamd_set_tile_pipeline.restype = C.c_int
+            d.hydamd_set_tile_pipeline.argtypes = [C.c_void_p, C.c_int]
+            d.hydamd_get_tile_pipeline.restype = C.c_int
+            d.hydamd_get_tile_pipeline.argtypes = [C.c_void_p]
 
 
 _FMT = {np.dtype(np.uint8): HYD_UINT8, np.dtype(np.uint16): HYD_UINT16, np.dtype(np.float32): HYD_FLOAT32}
@@ -122,6 +129,13 @@ class Encoder:
     def set_metadata(self, width, height, linear_light=0, shift_x=-1, shift_y=-1) -> int:
         md = HYDImageMetadata(width, height, linear_light, shift_x, shift_y)
         return self.lib.dll.hyd_set_metadata(self.h, C.byref(md))
+
+    def set_tile_pipeline(self, depth: int) -> int:
+        """Tile-mode frames in flight (hydamd_set_tile_pipeline): 1 = the reference's timing, up to 8; 0 = process default."""
+        return self.lib.dll.hydamd_set_tile_pipeline(self.h, depth)
+
+    def tile_pipeline(self) -> int:
+        return self.lib.dll.hydamd_get_tile_pipeline(self.h)
 
     def set_icc(self, icc: Optional[bytes]) -> int:
         if icc is None:
@@ -189,8 +203,9 @@ def tile_dims(width: int, height: int, shift_x: int, shift_y: int):
 
 def encode_image(lib: Library, img: np.ndarray, *, linear_light: int = 0, shift_x: int = -1, shift_y: int = -1,
                  out_buf_size: int = 1 << 20, layout: str = "packed", order=None, icc: Optional[bytes] = None,
-                 explicit_last: bool = False, out_buf=None) -> bytes:
-    """Encode a whole (H, W, 3) image the way the reference CLI does; returns the codestream."""
+                 explicit_last: bool = False, out_buf=None, tile_pipeline: Optional[int] = None) -> bytes:
+    """Encode a whole (H, W, 3) image the way the reference CLI does; returns the codestream.
+    ``tile_pipeline``: tile-mode frames in flight (this build only; None leaves the default, one frame per call)."""
     h, w, _ = img.shape
     src = img[::-1].copy() if layout == "flipped" else img
     tw, th = tile_dims(w, h, shift_x, shift_y)
@@ -199,6 +214,8 @@ def encode_image(lib: Library, img: np.ndarray, *, linear_light: int = 0, shift_
     chunks = []
     with Encoder(lib) as enc:
         enc.check(enc.set_metadata(w, h, linear_light, shift_x, shift_y))
+        if tile_pipeline is not None:
+            enc.check(enc.set_tile_pipeline(tile_pipeline))
         if icc is not None:
             enc.check(enc.set_icc(icc))
         buf = out_buf if out_buf is not None else (C.c_uint8 * out_buf_size)()  # a caller encoding many images keeps one buffer

@@ -251,8 +251,10 @@ __device__ void asm_hfglobal(const uint8_t *__restrict__ planb, const BlobArgs &
         uint32_t e = 0;
         if ((uint32_t)t < plan->num_blobs)
             e = blob_check(blobs.p[t], blobs.cap[t], plan->blob_slots[t]);
+        if (e)
+            atomicOr(S.err, e);
         if (__syncthreads_or((int)e))
-            return; /* the workgroup of one of that blob's LF groups reports why */
+            return;
     }
     const uint32_t per = plan->clusters_per_preset, C = plan->num_presets * per;
     if (t == 0)
@@ -583,6 +585,8 @@ struct HydkAsm {
     uint8_t *own_out = nullptr;   /* output buffer for callers that bring none (hydk_asm_run with out == NULL) */
     size_t own_cap = 0;
     uint8_t *last_out = nullptr;  /* where the last run wrote */
+    hipStream_t last_stream = nullptr; /* ... and the stream it ran in */
+    bool ran = false;
 };
 
 namespace {
@@ -672,16 +676,17 @@ int hydk_asm_set_plan(HydkAsm *a, const void *plan, size_t bytes) {
         hp->toc_n != 2 + hp->num_slots + hp->frame_groups || hp->ntails > HYDK_ASM_MAX_TAILS)
         return afail(a, ST_API_ERROR, "inconsistent plan");
     ASM_TRY(a, hipSetDevice(a->device));
+    /* an earlier frame may still be reading the old plan: wait for ITS stream only (a device-wide wait would stall every
+     * other encoder thread's frames in a batch of differently shaped images) */
+    if (a->ran)
+        ASM_TRY(a, hipStreamSynchronize(a->last_stream));
     if (bytes > a->plan_cap) {
-        ASM_TRY(a, hipDeviceSynchronize()); /* an earlier frame may still be reading the old plan */
         if (a->plan)
             (void)hipFree(a->plan);
         a->plan = nullptr;
         a->plan_cap = 0;
         ASM_TRY(a, hipMalloc(&a->plan, bytes + 16)); /* + 16: the copy kernel reads whole words */
         a->plan_cap = bytes;
-    } else {
-        ASM_TRY(a, hipDeviceSynchronize());
     }
     ASM_TRY(a, hipMemcpy(a->plan, plan, bytes, hipMemcpyHostToDevice));
     a->hplan = *hp;
@@ -714,12 +719,19 @@ int hydk_asm_run(HydkAsm *a, const void *const *blobs, const uint64_t *blob_caps
         out = a->own_out;
         out_cap = a->own_cap;
     }
+    /* k_asm_copy moves whole 32-bit words of the output and 16-byte-aligned records of the blobs */
+    if ((uintptr_t)out & 3u)
+        return afail(a, ST_API_ERROR, "output buffer must be 4-byte aligned");
     a->last_out = (uint8_t *)out;
+    a->last_stream = st;
+    a->ran = true;
     BlobArgs args;
     memset(&args, 0, sizeof(args));
     for (uint32_t b = 0; b < a->hplan.num_blobs; b++) {
         if (!blobs[b])
             return afail(a, ST_API_ERROR, "null blob");
+        if ((uintptr_t)blobs[b] & 15u)
+            return afail(a, ST_API_ERROR, "blobs must be 16-byte aligned");
         args.p[b] = (const uint8_t *)blobs[b];
         args.cap[b] = blob_caps[b];
     }

@@ -36,6 +36,29 @@ constexpr int kThreads = 256;
 #ifndef HYDK_K1_WAVES
 #define HYDK_K1_WAVES 4 /* waves per SIMD the transform kernel is compiled for (register budget 512 / this) */
 #endif
+/* Build-time variants of the transform kernel, for A/B measurements (scripts/k1_variants.py); the defaults are the
+ * product.  HYDK_K1_GATHER: bit i set = LUT i of a pixel is a gather from the uploaded table instead of a register
+ * evaluation (0-2 transfer curve of R, G, B; 3-5 bias curve of L, M, S); HYDK_K1_WAVELOCAL: a wavefront row-transforms
+ * exactly the eight blocks whose columns it transforms next, so no workgroup barrier separates the two;
+ * HYDK_K1_TOK: form of the token walk; HYDK_K1_SKIP: timing-only builds that leave a stage out (wrong bytes). */
+#ifndef HYDK_K1_GATHER
+#define HYDK_K1_GATHER 0
+#endif
+#ifndef HYDK_K1_GATHER_ODD
+#define HYDK_K1_GATHER_ODD 0 /* the same, for the odd pixels of a row only (needs HYDK_K1_ILP >= 2) */
+#endif
+#ifndef HYDK_K1_WAVELOCAL
+#define HYDK_K1_WAVELOCAL 0
+#endif
+#ifndef HYDK_K1_TOK
+#define HYDK_K1_TOK 0
+#endif
+#ifndef HYDK_K1_SKIP
+#define HYDK_K1_SKIP 0
+#endif
+#ifndef HYDK_K1_ILP
+#define HYDK_K1_ILP 0 /* > 0: pixels of a row whose curves are evaluated in lock step (instruction-level parallelism) */
+#endif
 constexpr int kS0Block = 72;            /* floats per block in the row-pass buffer: 64 + 8 pad -> conflict-free column reads */
 constexpr int kS0Chan = 32 * kS0Block;  /* floats per channel */
 constexpr int kDbgPitch = 2048;
@@ -188,6 +211,121 @@ __device__ __forceinline__ float bias_lut_eval(uint32_t i) {
     return r1 - 0.155954f;
 }
 
+/* Pointers read from a job descriptor in memory are generic to the compiler (flat_* instructions, which also
+ * count against the LDS counter every LDS wait looks at); all of them are device memory. */
+#define HYDK_GLOBAL(T, p) ((__attribute__((address_space(1))) T *)(p))
+/* The same two curves for N values in lock step: every statement is N independent operations, so a wavefront always
+ * has N instructions to issue while the previous N are in the pipeline (a dependent VALU instruction issues ~9 cycles
+ * after its producer, an independent one after ~2: the one-value forms above are chains of up to 21 dependent steps).
+ * Operation order per value is exactly that of input_lut16_eval_as / bias_lut_eval. */
+template <int CURVE, int N>
+__device__ __forceinline__ void input_lut16_eval_n(const uint32_t (&i)[N], uint32_t (&o)[N]) {
+    float f[N], y[N];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        f[k] = (float)i[k] * kUnit16;
+    if (CURVE == kCurveNone) {
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            y[k] = f[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            y[k] = 0.2852804880f * f[k];
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            y[k] = 0.72007737769f + y[k];
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            y[k] = f[k] * y[k];
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            y[k] = -0.009982599f + y[k];
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            y[k] = f[k] * y[k];
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            y[k] = 0.003094300919832f + y[k];
+        if (CURVE == kCurveBoth) {
+#pragma unroll
+            for (int k = 0; k < N; k++)
+                y[k] = f[k] <= 0.0404482362771082f ? 0.07739938080495357f * f[k] : y[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        y[k] = y[k] * 65535.f;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        y[k] = y[k] + 0.5f;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        o[k] = (uint32_t)(int)y[k];
+}
+
+template <int XMODE, int N>
+__device__ __forceinline__ void bias_lut_eval_n(const uint32_t (&i)[N], float (&o)[N]) {
+    if (XMODE == kXybIeeeDiv) {
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            o[k] = bias_curve((float)i[k] * kUnit16);
+        return;
+    }
+    float x[N], z[N], t[N];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        x[k] = (float)i[k] * kUnit16;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        x[k] = x[k] + 0.0037930732552754493f;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        z[k] = __uint_as_float(0x548c39cbu - div3(__float_as_uint(x[k])));
+    /* z *= 1.5015480449f - 0.534850249f * x * z * z * z */
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        t[k] = 0.534850249f * x[k];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            t[k] = t[k] * z[k];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        t[k] = 1.5015480449f - t[k];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        z[k] = z[k] * t[k];
+    /* z *= 1.333333985f - 0.33333333f * x * z * z * z */
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        t[k] = 0.33333333f * x[k];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            t[k] = t[k] * z[k];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        t[k] = 1.333333985f - t[k];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        z[k] = z[k] * t[k];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        t[k] = __builtin_amdgcn_rcpf(z[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        x[k] = __builtin_fmaf(-z[k], t[k], 1.0f);
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        t[k] = __builtin_fmaf(t[k], x[k], t[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        o[k] = t[k] - 0.155954f;
+}
+
 /* c * x + acc for c, x below 2^24, as the one instruction it is (the compiler keeps multiply and add apart) */
 __device__ __forceinline__ uint32_t umad24(uint32_t c, uint32_t x, uint32_t acc) {
     uint32_t d;
@@ -212,9 +350,10 @@ __device__ __forceinline__ void lms_mix_u16(uint32_t r, uint32_t g, uint32_t b, 
         m = bias_lut[im];
         s = bias_lut[is];
     } else {
-        l = bias_lut_eval<XMODE>(il);
-        m = bias_lut_eval<XMODE>(im);
-        s = bias_lut_eval<XMODE>(is);
+        const auto *gl = HYDK_GLOBAL(const float, bias_lut);
+        l = (HYDK_K1_GATHER & 8) ? gl[il] : bias_lut_eval<XMODE>(il);
+        m = (HYDK_K1_GATHER & 16) ? gl[im] : bias_lut_eval<XMODE>(im);
+        s = (HYDK_K1_GATHER & 32) ? gl[is] : bias_lut_eval<XMODE>(is);
     }
     Y = (l + m) * 0.5f;
     X = Y - m;
@@ -380,11 +519,14 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
  * bias LUT's range and the scaled DCT has unit gain), so token < 64, residue < 2^13 and one record fits
  * 32 bits: token | cluster << 7 | residue bit count << 11 | residue << 16.  Float input has no such
  * bound and keeps the 8-byte record: lo = token | cluster << 8 | bit count << 16, hi = residue. */
+constexpr bool kK1GlobalMem = (HYDK_K1_TOK & 4) != 0;
 template <int FMT>
 __device__ __forceinline__ void store_record(void *tok, uint32_t at, uint32_t token, uint32_t cluster, uint32_t rbits,
                                              uint32_t residue) {
     if (FMT == HYDK_FMT_F32)
         ((uint64_t *)tok)[at] = ((uint64_t)residue << 32) | HYDK_REC_LO(token, cluster, rbits);
+    else if (kK1GlobalMem)
+        HYDK_GLOBAL(uint32_t, tok)[at] = HYDK_REC32(token, cluster, rbits, residue);
     else
         ((uint32_t *)tok)[at] = HYDK_REC32(token, cluster, rbits, residue);
 }
@@ -431,6 +573,11 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
     __shared__ uint32_t s_blen[32];                   /* symbols of the block's Y | X << 8 | B << 16 runs */
     __shared__ __attribute__((aligned(16))) float s_wq[3 * 64]; /* quantisation weight [channel][kh][kv]: a thread's eight in two 16-byte reads */
 
+#ifdef HYDK_K1_PADLDS /* occupancy experiments: extra LDS per workgroup, so that fewer of them fit a compute unit */
+    __shared__ uint32_t s_pad[HYDK_K1_PADLDS / 4];
+    if (threadIdx.x == 0 && jobs == nullptr)
+        s_pad[blockIdx.x & 255] = 1;
+#endif
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
@@ -457,6 +604,16 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
 
     /* column / token phases: thread (block cb, horizontal frequency kh) */
     const int cb = t >> 3, kh = t & 7;
+#if HYDK_K1_TOK & 8
+    /* the quantised coefficients go back into the block's 64 words in ZIG-ZAG order (this thread's eight land at
+     * kZigzag[kv][kh]): the token walk then reads position j at word j, no index table on its address path.  In place
+     * is safe: a block's eight threads are neighbours in one wavefront, whose LDS operations execute in order — every
+     * lane's column reads of a channel are done before any lane's stores of that channel. */
+    uint32_t zz[8];
+#pragma unroll
+    for (int kv = 0; kv < 8; kv++)
+        zz[kv] = kZigzag[kv][kh];
+#endif
     const uint32_t nib_row = (uint32_t)kh * (uint32_t)sizeof(kNibbleMasks.m[0]); /* 256 bytes per kh */
     /* first cluster holding coefficient contexts, by scheme (encoder.c:862-901) */
     const int coef_cl_lo = job.scheme == 0 ? 3 : job.scheme == 3 ? 0 : 1;
@@ -468,7 +625,13 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                         FMT != HYDK_FMT_F32;
 
     /* phase-A role of this thread: row ar of block ab */
+#if HYDK_K1_WAVELOCAL
+    /* wavefront w row-transforms all eight rows of blocks 8w .. 8w+7: exactly the blocks whose columns it takes in
+     * phase B (cb = t >> 3), so the transposition through LDS stays inside the wavefront */
+    const int ar = lane >> 3, ab = (wave << 3) | (lane & 7);
+#else
     const int ar = t >> 5, ab = t & 31;
+#endif
     const bool fast = packed && ab < gbw && ab * 8 + 8 <= gw; /* whole block row comes as aligned dwords */
     uint32_t nxt[kWords];
 #pragma unroll
@@ -481,7 +644,7 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                                                     (long long)(px0 + ab * 8) * 3) * (long long)sizeof(sample_t));
 #pragma unroll
             for (int k = 0; k < kWords; k++)
-                nxt[k] = p[k];
+                nxt[k] = kK1GlobalMem ? HYDK_GLOBAL(const uint32_t, p)[k] : p[k];
         }
     };
     prefetch(0);
@@ -524,6 +687,67 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                 }
                 auto row_to_xyb = [&](auto curve_tag) {
                     constexpr int CURVE = decltype(curve_tag)::value;
+#if HYDK_K1_ILP
+                    if (FMT == HYDK_FMT_U16 && !LUTS) {
+                        constexpr int P = HYDK_K1_ILP; /* pixels evaluated in lock step */
+#pragma unroll
+                        for (int i0 = 0; i0 < 8; i0 += P) {
+                            uint32_t smp[3 * P], lin[3 * P], idx[3 * P];
+                            float bia[3 * P];
+#pragma unroll
+                            for (int k = 0; k < 3 * P; k++) {
+                                const int si = i0 * 3 + k;
+                                smp[k] = (w[si >> 1] >> (16 * (si & 1))) & 0xFFFF;
+                            }
+                            input_lut16_eval_n<CURVE, 3 * P>(smp, lin);
+#pragma unroll
+                            for (int q = 0; q < P; q++) { /* format.c:48-56 */
+                                const uint32_t r = lin[3 * q], g = lin[3 * q + 1], b = lin[3 * q + 2];
+                                const uint32_t bb = __umul24(5112u, b);
+                                idx[3 * q] = umad24(19661u, r, umad24(40761u, g, bb)) >> 16;
+                                idx[3 * q + 1] = umad24(15073u, r, umad24(45350u, g, bb)) >> 16;
+                                idx[3 * q + 2] = umad24(15953u, r, umad24(13419u, g, __umul24(36163u, b))) >> 16;
+                            }
+                            /* which of the 3 * P bias values come from the uploaded table through the (otherwise idle)
+                             * texture path: HYDK_K1_GATHER bits 3-5 for every pixel, HYDK_K1_GATHER_ODD for odd ones on top */
+                            constexpr auto gathered = [](int k) constexpr {
+                                return (((HYDK_K1_GATHER >> 3) | (((k / 3) & 1) ? (HYDK_K1_GATHER_ODD >> 3) : 0)) >> (k % 3) & 1) != 0;
+                            };
+                            constexpr int NG = [&]() constexpr { int n = 0; for (int k = 0; k < 3 * P; k++) n += gathered(k); return n; }();
+                            if (NG == 0)
+                                bias_lut_eval_n<XMODE, 3 * P>(idx, bia);
+                            else {
+                                const auto *gl = HYDK_GLOBAL(const float, job.bias_lut);
+                                constexpr int NE = 3 * P - NG > 0 ? 3 * P - NG : 1;
+                                uint32_t eidx[NE];
+                                float eb[NE];
+                                int n = 0;
+#pragma unroll
+                                for (int k = 0; k < 3 * P; k++) {
+                                    if (gathered(k))
+                                        bia[k] = gl[idx[k]]; /* issued first: they travel while the others are evaluated */
+                                    else
+                                        eidx[n++] = idx[k];
+                                }
+                                if (NG < 3 * P)
+                                    bias_lut_eval_n<XMODE, NE>(eidx, eb);
+                                n = 0;
+#pragma unroll
+                                for (int k = 0; k < 3 * P; k++)
+                                    if (!gathered(k))
+                                        bia[k] = eb[n++];
+                            }
+#pragma unroll
+                            for (int q = 0; q < P; q++) {
+                                const float Y = (bia[3 * q] + bia[3 * q + 1]) * 0.5f;
+                                yv[i0 + q] = Y;
+                                xv[i0 + q] = Y - bia[3 * q + 1];
+                                bv[i0 + q] = bia[3 * q + 2] - Y;
+                            }
+                        }
+                        return;
+                    }
+#endif
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         uint32_t rgb[3];
@@ -534,8 +758,14 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                                 rgb[ch] = s_lut8[(w[si >> 2] >> (8 * (si & 3))) & 0xFF];
                             else {
                                 const uint32_t v = (w[si >> 1] >> (16 * (si & 1))) & 0xFFFF;
-                                rgb[ch] = LUTS ? job.in_lut16[v] : input_lut16_eval_as<CURVE>(v);
+                                rgb[ch] = LUTS ? (uint32_t)job.in_lut16[v] : (HYDK_K1_GATHER >> ch & 1) ? (uint32_t)HYDK_GLOBAL(const uint16_t, job.in_lut16)[v] : input_lut16_eval_as<CURVE>(v);
                             }
+                        }
+                        if (HYDK_K1_SKIP & 2) { /* timing only: no transfer or bias curves */
+                            xv[i] = __uint_as_float(0x3f000000u | w[(i * 3) >> 1]);
+                            yv[i] = __uint_as_float(0x3f000000u | w[(i * 3 + 1) >> 1]);
+                            bv[i] = __uint_as_float(0x3f000000u | w[(i * 3 + 2) >> 1]);
+                            continue;
                         }
                         lms_mix_u16<XMODE>(rgb[0], rgb[1], rgb[2], job.bias_lut, xv[i], yv[i], bv[i]);
                     }
@@ -608,13 +838,20 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                 dst[2 * kS0Chan + k] = o[k];
         }
         HYDK_PHASE_MARK(1);
+#if HYDK_K1_WAVELOCAL
+        /* LDS operations of one wavefront execute in order: its own stores are visible to its loads */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
         __syncthreads();
+#endif
         HYDK_PHASE_MARK(2);
 
         /* ---------------- phase B: column DCT, quantise (in place in LDS), LF ints, non-zero bitmaps ---------------- */
         unsigned long long msk[3] = {0, 0, 0}; /* per channel X, Y, B: non-zero coefficients by zig-zag position */
         int32_t lf_int[3] = {0, 0, 0};
-        if (cb < gbw) {
+        if (!(HYDK_K1_SKIP & 8) && cb < gbw) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 float col[8], v[8];
@@ -649,8 +886,12 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                         nlo |= nz ? 8u << kv : 0u;
                     else
                         nhi |= nz ? 8u << (kv - 4) : 0u;
+#if HYDK_K1_TOK & 8
+                    ((int *)(s_rowpass + c * kS0Chan + cb * kS0Block))[zz[kv]] = qq;
+#else
                     /* the thread's own column: nobody else reads or writes these eight words */
                     ((int *)src)[kv * 8] = qq;
+#endif
                 }
                 if (job.dbg_quant) {
                     int32_t *d = job.dbg_quant + (size_t)c * kDbgPitch * kDbgPitch +
@@ -662,16 +903,20 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                 /* 32-bit offsets from one uniform base: the loads take an SGPR base and a VGPR offset, no 64-bit address arithmetic */
                 const char *const nib = (const char *)&kNibbleMasks.m[0][0][0];
                 /* the loaded masks are first used after the loop: the next channel's transform runs while they travel */
+                if (!(HYDK_K1_SKIP & 4))
                 msk[c] = *(const unsigned long long *)(nib + (nib_row | nlo)) | *(const unsigned long long *)(nib + (nib_row | 128u | nhi));
                 lf_int[c] = (int32_t)(v[0] * kLfShift[c]); /* LF int: trunc(dc * shift[c]) (encoder.c:573,582) */
             }
             if (kh == 0) {
 #pragma unroll
                 for (int c = 0; c < 3; c++)
+                    if (kK1GlobalMem)
+                        HYDK_GLOBAL(int32_t, job.dc)[(size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH + (size_t)((py0 >> 3) + s) * HYDK_DC_PITCH + (px0 >> 3) + cb] = lf_int[c];
+                    else
                     job.dc[(size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH + (size_t)((py0 >> 3) + s) * HYDK_DC_PITCH + (px0 >> 3) + cb] = lf_int[c];
             }
 #pragma unroll
-            for (int c = 0; c < 3; c++) { /* the block's bitmap = OR over its eight threads */
+            for (int c = 0; c < 3 && !(HYDK_K1_SKIP & 4); c++) { /* the block's bitmap = OR over its eight threads */
                 const uint32_t lo = or_reduce8((uint32_t)msk[c]), hi = or_reduce8((uint32_t)(msk[c] >> 32));
                 msk[c] = ((unsigned long long)hi << 32) | lo;
             }
@@ -720,7 +965,104 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
             const uint32_t per = strip_total >> 8, extra = strip_total & 255u;
             uint32_t p = (uint32_t)t * per + min((uint32_t)t, extra);
             const uint32_t pend = overflowed ? 0u : p + per + ((uint32_t)t < extra ? 1u : 0u);
-            if (p < pend) {
+#if HYDK_K1_TOK & 8
+            if (!(HYDK_K1_SKIP & 1) && p < pend) {
+                /* ---- the pipelined walk: every LDS value a symbol needs is requested while the symbol before it is
+                 * being coded (its coefficient, the frequency context of its position, the count context of the
+                 * non-zeros still to come, and — a segment ahead — the next segment's descriptor), so an iteration's
+                 * critical path is arithmetic only; stepping to the next segment is a handful of selects, no branch ---- */
+                uint32_t b = 0;
+#pragma unroll
+                for (uint32_t step = 16; step; step >>= 1)
+                    b += s_boff[b + step] <= p ? step : 0u;
+                uint32_t j = p - s_boff[b];
+                const uint32_t len = s_blen[b];
+                uint32_t visit = 0;
+                if (j >= (len & 0xffu)) {
+                    j -= len & 0xffu;
+                    visit = 1;
+                    if (j >= ((len >> 8) & 0xffu)) {
+                        j -= (len >> 8) & 0xffu;
+                        visit = 2;
+                    }
+                }
+                uint32_t seg_at = b * 3u + visit;
+                const uint4 seg = s_seg[seg_at];
+                uint2 nseg = *(const uint2 *)&s_seg[seg_at + 1].z; /* {symbols | non-zeros << 8, word offset} of the segment after */
+                uint32_t n = seg.z & 0xffu, nz_total = seg.z >> 8;
+                const unsigned long long m = ((unsigned long long)seg.y << 32) | seg.x;
+                uint32_t remaining = nz_total - (uint32_t)__popcll(m & ((1ull << j) - 1ull));
+                uint32_t prev = j <= 1u ? (uint32_t)(nz_total <= 4u) : (uint32_t)(m >> (j - 1u)) & 1u;
+                const uint32_t coef_base = (uint32_t)coef_cl_lo;
+                const uint32_t prev_mask = job.scheme <= 1 ? 1u : 0u, ctx_mask = job.scheme == 0 ? 6u : 0u;
+                const uint32_t count_mask = job.scheme == 0 ? 3u : 0u;
+                const char *const lds_q = (const char *)s_rowpass;
+                const uint8_t *const lds_f3 = (const uint8_t *)s_jinfo + 1; /* byte 2 j: frequency context of position j, mod 3 */
+                uint32_t qa = (seg.w + j) << 2;  /* byte address of this symbol's coefficient */
+                int coef = *(const int *)(lds_q + qa);
+                uint32_t f3 = lds_f3[2u * j];
+                uint32_t z3 = s_nnz3[remaining & 63u];
+                uint32_t at = (goff + p) << 2;   /* byte offset of the record */
+                char *const tokb = (char *)tok;
+                for (; p < pend; p++) {
+                    /* ---- where the next symbol sits, and its loads ---- */
+                    const uint32_t here = coef != 0 ? 1u : 0u;
+                    const bool is_count = j == 0u;
+                    const bool step = j + 1u == n;
+                    const uint32_t jn = step ? 0u : j + 1u;
+                    const uint32_t qn = step ? nseg.y << 2 : qa + 4u;
+                    const uint32_t rem_n = step ? nseg.x >> 8 : remaining - here;
+                    const int coef_n = *(const int *)(lds_q + qn);
+                    const uint32_t f3_n = lds_f3[2u * jn];
+                    const uint32_t z3_n = s_nnz3[rem_n & 63u];
+                    /* ---- this symbol ---- */
+                    const uint32_t value = is_count ? nz_total : pack_signed(coef);
+                    const uint32_t u = visit + z3 + f3;
+                    const uint32_t cluster = is_count ? (visit & count_mask)
+                                                      : coef_base + (prev & prev_mask) + ((0x1248u >> (u + u)) & ctx_mask);
+                    uint32_t token, rbits, residue;
+                    if (FMT != HYDK_FMT_F32) {
+                        const uint32_t fb = __float_as_uint((float)value) >> 22;
+                        const bool big = value >= 16u;
+                        token = big ? fb - 246u : value;
+                        rbits = big ? (fb >> 1) - 128u : 0u;
+                        residue = __builtin_amdgcn_ubfe(value, 0u, rbits);
+                        *HYDK_GLOBAL(uint32_t, tokb + at) = HYDK_REC32(token, cluster, rbits, residue);
+                    } else {
+                        if (value < 16) {
+                            token = value;
+                            rbits = 0;
+                            residue = 0;
+                        } else {
+                            const int nb = 30 - __clz((int)value);
+                            rbits = (uint32_t)nb;
+                            residue = value & ((1u << nb) - 1u);
+                            token = 16u + (((uint32_t)(nb - 3) << 1) | ((value >> nb) & 1u));
+                        }
+                        *HYDK_GLOBAL(uint64_t, tokb + 2u * at) = ((uint64_t)residue << 32) | HYDK_REC_LO(token, cluster, rbits);
+                    }
+                    rb_sum += rbits;
+                    atomicAdd(&s_hist[cluster * kHistW + (FMT == HYDK_FMT_F32 ? (int)min(token, (uint32_t)kHistW - 1u) : (int)token)], 1u);
+                    /* ---- walk on ---- */
+                    prev = is_count ? (uint32_t)(nz_total <= 4u) : here;
+                    if (step) { /* selects: the next segment's descriptor is already in registers */
+                        seg_at++;
+                        visit = visit == 2u ? 0u : visit + 1u;
+                        n = nseg.x & 0xffu;
+                        nz_total = nseg.x >> 8;
+                        nseg = *(const uint2 *)&s_seg[seg_at + 1].z;
+                    }
+                    j = jn;
+                    qa = qn;
+                    remaining = rem_n;
+                    coef = coef_n;
+                    f3 = f3_n;
+                    z3 = z3_n;
+                    at += 4u;
+                }
+            }
+#else
+            if (!(HYDK_K1_SKIP & 1) && p < pend) {
                 uint32_t b = 0;
 #pragma unroll
                 for (uint32_t step = 16; step; step >>= 1)
@@ -761,7 +1103,15 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                                                       : coef_base + (prev & prev_mask) + ((0x1248u >> (u + u)) & ctx_mask);
                     /* hybrid-uint split, config (4,1,0) (entropy.c:427-444) */
                     uint32_t token, rbits, residue;
-                    if (value < 16) {
+                    if ((HYDK_K1_TOK & 1) && FMT != HYDK_FMT_F32) {
+                        /* value < 2^14 converts exactly: its float's exponent and top mantissa bit are floor(log2) and
+                         * the bit below the leading one, i.e. the token's two variable parts (entropy.c:427-444) */
+                        const uint32_t fb = __float_as_uint((float)value) >> 22; /* 2 * (127 + floor(log2)) + next bit */
+                        const bool big = value >= 16u;
+                        token = big ? fb - 246u : value;
+                        rbits = big ? (fb >> 1) - 128u : 0u;
+                        residue = __builtin_amdgcn_ubfe(value, 0u, rbits);
+                    } else if (value < 16) {
                         token = value;
                         rbits = 0;
                         residue = 0;
@@ -773,7 +1123,9 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                     }
                     store_record<FMT>(tok, goff + p, token, cluster, rbits, residue);
                     rb_sum += rbits;
-                    if (token == 0 && !is_count)
+                    if (HYDK_K1_TOK & 2)
+                        atomicAdd(&s_hist[cluster * kHistW + (FMT == HYDK_FMT_F32 ? (int)min(token, (uint32_t)kHistW - 1u) : (int)token)], 1u);
+                    else if (token == 0 && !is_count)
                         zero_tokens += 1ull << (10 * (cluster - coef_base)); /* at most 24 x 32 per thread and group */
                     else
                         atomicAdd(&s_hist[cluster * kHistW + (int)min(token, (uint32_t)kHistW - 1u)], 1u);
@@ -791,6 +1143,7 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                     }
                 }
             }
+#endif
         }
         goff += strip_total;
         HYDK_PHASE_MARK(6);
@@ -825,7 +1178,7 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
         atomicAdd(&s_rbits, rb_sum);
     __syncthreads();
     if (t == 0) {
-        job.sym_count[g] = overflowed ? 0u : goff;
+        job.sym_count[g] = overflowed || HYDK_K1_SKIP ? 0u : goff; /* timing-only builds leave no symbols for the later stages */
         job.rbits_total[g] = s_rbits;
         if (overflowed)
             atomicOr(status, HYDK_STATUS_TOKENS);

@@ -118,8 +118,11 @@ HYDRIUM_EXPORT int hydamd_assembler_plan(HydAmdAssembler *a, const HYDImageMetad
     const size_t lfx = (W + 2047) >> 11, lfy = (H + 2047) >> 11, nlf = lfx * lfy;
     const size_t fgx = (W + 255) >> 8, fgy = (H + 255) >> 8, fg = fgx * fgy;
     size_t nslots = 0;
-    for (size_t b = 0; b < nblobs; b++)
+    for (size_t b = 0; b < nblobs; b++) {
+        if (!blob_slots[b]) /* no LF group's workgroup would check (and report on) such a blob */
+            return AFAIL(a, HYD_API_ERROR, "a blob without LF groups");
         nslots += blob_slots[b];
+    }
     if (nslots != nlf || nlf > HYDAMD_MAX_LF_GROUPS || nlf == 128)
         return AFAIL(a, HYD_API_ERROR, "a frame needs every one of its LF groups (at most 255, not 128)");
     if (fg < 2)
@@ -318,8 +321,10 @@ HYDRIUM_EXPORT int hydamd_assembler_plan(HydAmdAssembler *a, const HYDImageMetad
     plan.total_bytes = (uint32_t)buf.len;
     memcpy(buf.p, &plan, sizeof(plan));
     ret = hydk_asm_set_plan(a->dev, buf.p, buf.len);
+    free(a->key); /* on failure the device's plan may be half-written: whatever comes next is planned afresh */
+    a->key = NULL;
+    a->key_len = 0;
     if (!ret) {
-        free(a->key);
         a->key = key;
         a->key_len = key_len;
         key = NULL;

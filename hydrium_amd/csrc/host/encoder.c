@@ -107,6 +107,8 @@ struct HYDEncoder {
         HydFrameShape shape; /* shape.lfg points at lfg above */
     } pipe[TILE_PIPE_MAX];
     int pipe_depth; /* 0: tile frames are coded synchronously through e->dev */
+    int pipe_request; /* hydamd_set_tile_pipeline: frames in flight this encoder asks for; 0 = HYDAMD_TILE_PIPELINE, else 1 */
+    struct PendingTile *cur_pend; /* the ring entry the running call works for (device errors are recorded there) */
     size_t tile_seq;
 };
 
@@ -505,25 +507,29 @@ static int eager_on(void) {
 }
 
 /* Tile mode (tile_size_shift >= 0) makes every tile a frame of its own, and the reference hands its bytes over before
- * hyd_send_tile returns (encoder.c:339-378, 1008).  Done that way on a GPU a tile costs the latency of the whole kernel
- * sequence — 2-3 ms, most of it the serial rANS chain of its longest group, whether the tile is 256x256 or 2048x2048
- * (measured: 32 Mpixel/s for 256x256 tiles, no better than one CPU core).  So up to HYDAMD_TILE_PIPELINE (default 8)
- * tile frames are in flight, each on a device context of its own: a call stages and launches its tile and collects the
- * frame launched `depth` calls earlier; frames reach the output in send order, and the call that sends the image's final
- * tile collects everything.  What a caller sees: a tile's bytes arrive up to depth - 1 calls later than the reference's
- * (the documented protocol — write what hyd_release_output_buffer reports, loop on HYD_NEED_MORE_OUTPUT — copes: in
- * one-frame mode every call but the last already yields nothing).  HYDAMD_TILE_PIPELINE=1 is the reference's timing. */
-static int tile_pipeline_depth(void) {
-    static int n = -1;
-    if (n < 0) {
+ * hyd_send_tile returns (encoder.c:339-378, 1008).  That is the DEFAULT here too (depth 1): a call's frame is complete
+ * when the call returns, a device or NaN error is reported by the call that sent the offending tile, and an encoder
+ * abandoned mid-image has emitted every frame the reference would have.  Done that way on a GPU a tile costs the latency
+ * of the whole kernel sequence — 2-3 ms, most of it the serial rANS chain of its longest group, whether the tile is
+ * 256x256 or 2048x2048 (measured: 32 Mpixel/s for 256x256 tiles, no better than one CPU core).  A caller that wants the
+ * throughput instead asks for it: hydamd_set_tile_pipeline(encoder, depth) (include/hydrium_amd.h) or the environment's
+ * HYDAMD_TILE_PIPELINE=depth (2..8) keeps up to `depth` tile frames in flight, each on a device context of its own: a
+ * call stages and launches its tile and collects the frame launched `depth` calls earlier; frames reach the output in
+ * send order, and the call that sends the image's final tile collects everything.  What such a caller sees: a tile's bytes
+ * (and a NaN or device error) arrive up to depth - 1 calls later than the reference's; the documented protocol — write
+ * what hyd_release_output_buffer reports, loop on HYD_NEED_MORE_OUTPUT — copes (in one-frame mode every call but the
+ * last already yields nothing); an encoder destroyed before its final tile drops the frames still in flight. */
+static int tile_pipeline_depth(const HYDEncoder *e) {
+    static int env = -1;
+    if (env < 0) {
         const char *v = getenv("HYDAMD_TILE_PIPELINE");
-        n = v && *v ? atoi(v) : TILE_PIPE_MAX;
-        if (n < 1)
-            n = 1;
-        if (n > TILE_PIPE_MAX)
-            n = TILE_PIPE_MAX;
+        env = v && *v ? atoi(v) : 1;
+        if (env < 1)
+            env = 1;
+        if (env > TILE_PIPE_MAX)
+            env = TILE_PIPE_MAX;
     }
-    return n;
+    return e->pipe_request ? e->pipe_request : env;
 }
 
 /* HYDAMD_DEVICE: which GPU the drop-in API encodes on (default 0); a process per GPU sets it to its own */
@@ -611,9 +617,9 @@ static void ctx_release(HydAmdContext *c, size_t slots, int linear, int healthy)
 /* Frames in flight (tile-mode pipelining, encoders on several threads) live on HIP streams of their own, and the runtime
  * spreads streams over GPU_MAX_HW_QUEUES hardware queues — 4 unless the process says otherwise, which serialises what was
  * meant to overlap (eight tile frames in flight: 1.47 ms per 256x256 tile with 4 queues, 0.57 with 20; a batch of 4K
- * frames on 8 threads: 628 frames/s against 1037).  The library asks for 20 when it is loaded, unless the environment
- * already holds a value; the runtime reads it at its first call, so a process that used HIP before loading us keeps its own. */
-__attribute__((constructor)) static void hyd_ask_for_hardware_queues(void) { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
+ * frames on 8 threads: 628 frames/s against 1037).  That is the DEPLOYMENT's setting to make (export GPU_MAX_HW_QUEUES=20
+ * before the process starts): a drop-in library does not edit its host's environment (until
+ * round 3 a load-time constructor did — it changed HIP for every other user of the process and raced getenv in threads). */
 
 HYDRIUM_EXPORT HYDEncoder *hyd_encoder_new(void) {
     HYDEncoder *e = calloc(1, sizeof(HYDEncoder));
@@ -785,8 +791,16 @@ HYDRIUM_EXPORT HYDStatusCode hyd_flush(HYDEncoder *e) {
     return e->stream_pos < e->stream.len ? HYD_NEED_MORE_OUTPUT : HYD_OK;
 }
 
-static int device_fail(HYDEncoder *e, int code) {
+/* the context e->dev is not to be parked for reuse; in tile mode that is recorded in the ring entry that owns it,
+ * whatever the call does next (e->dev_failed alone is overwritten when the next call switches to another entry) */
+static void mark_device_failed(HYDEncoder *e) {
     e->dev_failed = 1;
+    if (e->cur_pend)
+        e->cur_pend->failed = 1;
+}
+
+static int device_fail(HYDEncoder *e, int code) {
+    mark_device_failed(e);
     /* hydamd status codes are HYDStatusCode values; keep a static string for the message */
     static const char *const generic = "GPU encode failed (see hydamd_error)";
     const char *m = hydamd_error(e->dev);
@@ -834,12 +848,16 @@ static int finish_frame_on_device(HYDEncoder *e, const HydFrameShape *shape) {
     ret = hydamd_assembler_plan(as, &e->metadata, 0, 1, 1, &slots, lf_ids, NULL, 0);
     if (ret)
         return FAIL(e, ret, "frame description rejected by the assembler");
-    for (int attempt = 0; attempt < 3; attempt++) {
+    /* the blob is a view: the output's size comes from the context's capacities plus what the assembler itself adds per
+     * LF group (head bits, TOC entries) and per frame (prefix, HFGlobal); should a frame still exceed it, the assembler
+     * says how many bytes it needs and the frame is assembled again into a buffer of that size */
+    size_t out_cap = hydamd_blob_bound(e->dev, (int)n) + 4096 * n + (256u << 10);
+    for (int attempt = 0; attempt < 4; attempt++) {
         const void *blob = NULL;
         size_t cap = 0, size = 0;
         ret = hydamd_export_frame_owned(e->dev, (int)n, &blob, &cap);
-        if (!ret) /* the blob is a view: the output's size comes from the context's capacities (no frame exceeds them) */
-            ret = hydamd_assembler_run(as, &blob, &cap, hydamd_get_stream(e->dev), NULL, hydamd_blob_bound(e->dev, (int)n));
+        if (!ret)
+            ret = hydamd_assembler_run(as, &blob, &cap, hydamd_get_stream(e->dev), NULL, out_cap);
         if (ret)
             return device_fail(e, ret);
         ret = hydamd_sync(e->dev); /* a frame that outgrew the context's buffers is rerun in here: its blob is then stale */
@@ -852,9 +870,13 @@ static int finish_frame_on_device(HYDEncoder *e, const HydFrameShape *shape) {
             const char *m = hydamd_assembler_error(as);
             if (m && strstr(m, "incomplete"))
                 continue; /* export the rerun frame's results and assemble again */
+            if (ret == HYD_NEED_MORE_OUTPUT && size > out_cap) {
+                out_cap = size;
+                continue;
+            }
             if (m && strstr(m, "NaN"))
                 return FAIL(e, HYD_API_ERROR, "Invalid NaN Float");
-            e->dev_failed = 1;
+            mark_device_failed(e);
             return FAIL(e, ret < HYD_ERROR_START ? ret : HYD_INTERNAL_ERROR, "GPU frame assembly failed");
         }
         uint8_t *dst = hb_extend(&e->stream, size);
@@ -864,7 +886,7 @@ static int finish_frame_on_device(HYDEncoder *e, const HydFrameShape *shape) {
         TRACE("frame to the host", t0);
         return ret ? device_fail(e, ret) : 0;
     }
-    e->dev_failed = 1;
+    mark_device_failed(e);
     return FAIL(e, HYD_INTERNAL_ERROR, "frame still does not fit after enlarging its buffers");
 }
 
@@ -1009,11 +1031,14 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
 
 /* tile mode: the ring entry's frame, launched some calls ago, into the output stream */
 static int pipe_collect(HYDEncoder *e, struct PendingTile *p) {
+    struct PendingTile *const before = e->cur_pend;
     e->dev = p->dev;
     e->dev_failed = 0;
+    e->cur_pend = p; /* a device error in here is this entry's */
     const int ret = finish_frame_collect(e, &p->shape);
     p->failed |= e->dev_failed;
     p->active = 0;
+    e->cur_pend = before;
     return ret;
 }
 
@@ -1032,7 +1057,34 @@ static void pipe_release(HYDEncoder *e) {
     if (e->pipe_depth)
         e->dev = NULL; /* it was one of the ring's */
     e->pipe_depth = 0;
+    e->cur_pend = NULL;
+    e->tile_seq = 0;
 }
+
+/* additive API (include/hydrium_amd.h): tile frames in flight for this encoder, 1 (the reference's timing) .. 8;
+ * 0 returns to the process default (HYDAMD_TILE_PIPELINE, else 1).  Not while frames are in flight. */
+HYDRIUM_EXPORT int hydamd_set_tile_pipeline(HYDEncoder *e, int depth) {
+    if (!e)
+        return HYD_API_ERROR;
+    if (depth < 0 || depth > TILE_PIPE_MAX)
+        return FAIL(e, HYD_API_ERROR, "tile pipeline depth out of range");
+    for (int i = 0; i < TILE_PIPE_MAX; i++)
+        if (e->pipe[i].active)
+            return FAIL(e, HYD_API_ERROR, "tile frames are in flight");
+    if (depth != e->pipe_request) {
+        /* the ring is indexed by the depth: hand its contexts back, the next tile builds the new one */
+        pipe_release(e);
+        if (e->dev) { /* the encoder's own context (depth 1): the ring's entries bring theirs */
+            ctx_release(e->dev, e->dev_slots, e->dev_linear, !e->dev_failed);
+            e->dev = NULL;
+        }
+        e->dev_failed = 0;
+    }
+    e->pipe_request = depth;
+    return HYD_OK;
+}
+
+HYDRIUM_EXPORT int hydamd_get_tile_pipeline(const HYDEncoder *e) { return e ? tile_pipeline_depth(e) : 0; }
 
 HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buffer[3], uint32_t tile_x, uint32_t tile_y,
                                            ptrdiff_t row_stride, ptrdiff_t pixel_stride, int is_last,
@@ -1059,9 +1111,10 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
         return ret;
 
     struct PendingTile *pend = NULL;
-    if (!e->one_frame && tile_pipeline_depth() > 1) {
+    e->cur_pend = NULL;
+    if (!e->one_frame && tile_pipeline_depth(e) > 1) {
         /* this tile's ring entry: the frame it still holds is the oldest in flight */
-        e->pipe_depth = tile_pipeline_depth();
+        e->pipe_depth = tile_pipeline_depth(e);
         pend = &e->pipe[e->tile_seq % (size_t)e->pipe_depth];
         if (pend->active) {
             ret = pipe_collect(e, pend);
@@ -1070,6 +1123,7 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
         }
         e->dev = pend->dev;
         e->dev_failed = pend->failed;
+        e->cur_pend = pend;
     }
     if (!e->dev) {
         int st = 0;

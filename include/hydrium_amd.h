@@ -266,6 +266,8 @@ HYDAMD_EXPORT int hydamd_frame_from_blobs(const HYDImageMetadata *md, int write_
  *                            `blobs_dev[b]` is a device pointer to blob b (`blob_caps[b]` readable bytes),
  *                            `out` any device-accessible buffer of `out_cap` bytes (device memory, or
  *                            pinned host memory for frames that should land on the host directly).
+ *                            Alignment: `out` 4 bytes, every blob 16 bytes (the copy kernel moves whole
+ *                            words and 16-byte records); anything else is HYD_API_ERROR.
  *   hydamd_assembler_result  after the stream has been synchronised: the frame's size; HYD_NEED_MORE_OUTPUT
  *                            (with *size = bytes needed) if `out_cap` was too small; HYD_API_ERROR for a
  *                            blob that is malformed, incomplete (rerun the shard) or carries NaN input.
@@ -338,6 +340,18 @@ HYDAMD_EXPORT void hydamd_free(void *p);
  * HYDAMD_CONTEXT_CACHE_MB megabytes (default 8192) per process.  This releases whatever is parked, and the spare
  * frame buffers hydamd_free may have kept. */
 HYDAMD_EXPORT void hydamd_trim_cache(void);
+
+/* ---- knobs of the drop-in encoder (HYDEncoder of libhydrium.h) that the reference has no counterpart for ----
+ * Tile mode (tile_size_shift >= 0): every tile is a frame, and by default — as in the reference
+ * (src/libhydrium/libhydrium.c:147-203, encoder.c:339-378) — hyd_send_tile returns with that frame complete.
+ * hydamd_set_tile_pipeline(e, depth) lets up to `depth` (2..8) tile frames be in flight instead: a call launches
+ * its tile and collects the frame launched `depth` calls earlier, the final tile's call collects the rest; the
+ * bytes are the same, in the same order, up to depth - 1 calls later (4-5x the tile rate: a tile costs 2-3 ms of
+ * latency however small it is), a NaN or device error is reported by the call that collects the frame, and an
+ * encoder destroyed before its final tile drops what is still in flight.  depth 1 = the reference's timing;
+ * 0 = the process default (environment HYDAMD_TILE_PIPELINE, else 1).  HYD_API_ERROR while frames are in flight. */
+HYDAMD_EXPORT int hydamd_set_tile_pipeline(HYDEncoder *encoder, int depth);
+HYDAMD_EXPORT int hydamd_get_tile_pipeline(const HYDEncoder *encoder);
 
 /* ---- optional per-kernel timing with HIP events on the context's stream ---- */
 HYDAMD_EXPORT int hydamd_profile(HydAmdContext *ctx, int enable);

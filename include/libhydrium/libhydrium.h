@@ -109,10 +109,11 @@ HYDRIUM_EXPORT HYDStatusCode hyd_provide_output_buffer(HYDEncoder *encoder, uint
  * image size given in the metadata, so row_stride must describe the caller's real row pitch.
  * After each tile call hyd_flush until it stops returning HYD_NEED_MORE_OUTPUT, swapping output
  * buffers in between.  In one-frame mode nothing but the file header is produced before the
- * final tile.  In tile mode (tile_size_shift >= 0) every tile is a frame of its own; this build keeps
- * up to eight of them in flight on the GPU, so a tile's bytes may appear up to seven calls after the
- * call that sent it (always in send order; the call that sends the final tile delivers everything
- * still outstanding; HYDAMD_TILE_PIPELINE=1 in the environment restores one frame per call).
+ * final tile.  In tile mode (tile_size_shift >= 0) every tile is a frame of its own, complete when
+ * the call returns — unless the caller opted into pipelined tile frames (hydamd_set_tile_pipeline in
+ * hydrium_amd.h, or HYDAMD_TILE_PIPELINE=2..8 in the environment): then a tile's bytes may appear up
+ * to depth - 1 calls after the call that sent it (always in send order; the call that sends the
+ * final tile delivers everything still outstanding).
  * Returns HYD_OK or an error code.
  */
 HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *encoder, const void *const buffer[3],

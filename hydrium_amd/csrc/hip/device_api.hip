@@ -207,6 +207,10 @@ struct HydAmdContext {
     uint64_t *h_total_pinned = nullptr;
     uint32_t *h_status_pinned = nullptr;
 
+    /* several contexts (devices) working on one frame: hydamd_wait_for, hydamd_alphabet_floor_from_peers */
+    hipEvent_t peer_event = nullptr; /* "everything enqueued so far on this context's stream" */
+    uint32_t *peer_floor = nullptr;  /* [1] the floor k_floor_from_peers leaves for the table kernel */
+
     /* the drop-in API's frame assembly on the device (hydamd_export_frame_owned, hydamd_context_assembler) */
     void *own_blob = nullptr;
     size_t own_blob_cap = 0;
@@ -617,6 +621,10 @@ void hydamd_destroy(HydAmdContext *ctx) {
         (void)hipEventDestroy(ctx->lf_join);
     if (ctx->lf_ready)
         (void)hipEventDestroy(ctx->lf_ready);
+    if (ctx->peer_event)
+        (void)hipEventDestroy(ctx->peer_event);
+    if (ctx->peer_floor)
+        (void)hipFree(ctx->peer_floor);
     if (ctx->h_lf_total_pinned)
         (void)hipHostFree(ctx->h_lf_total_pinned);
     void *lfdev[] = {ctx->lf_recs, ctx->lf_codes, ctx->lf_work, ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total};
@@ -624,8 +632,8 @@ void hydamd_destroy(HydAmdContext *ctx) {
         if (p)
             (void)hipFree(p);
     void *dev[] = {ctx->rans_aux, ctx->rans_flags, ctx->rans_final, ctx->rbits_total, ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->accum, ctx->sym_count, ctx->group_bits,
-                   ctx->offsets, ctx->total, ctx->d_jobs, ctx->in_lut8, ctx->in_lut16,
-                   ctx->bias_lut, ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant, ctx->d_arena};
+                   ctx->offsets, ctx->total, ctx->d_jobs, /* the LUTs are the device's, shared by its contexts */
+                   ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant, ctx->d_arena};
     for (void *p : dev)
         if (p)
             (void)hipFree(p);
@@ -689,6 +697,62 @@ static int ensure_bitbuf(HydAmdContext *ctx) {
     const size_t groups = (size_t)ctx->max_slots * HYDK_GROUPS_PER_LFG;
     ctx->bit_pitch_words = HYDK_BITWORDS_FOR(ctx->tok_cap);
     HIP_TRY(ctx, hipMalloc(&ctx->bitbuf, groups * ctx->bit_pitch_words * sizeof(uint32_t)));
+    return ST_OK;
+}
+
+/* ---- per-device lookup tables (format.c:58-83), shared by all contexts ---- */
+namespace {
+struct SharedLuts {
+    int device, linear_light;
+    uint16_t *in_lut8, *in_lut16;
+    float *bias_lut;
+    int best_register_mode;
+};
+std::mutex g_luts_mutex;
+std::vector<SharedLuts> g_luts; /* never freed: 385 KB per (device, transfer curve) for the life of the process */
+} /* namespace */
+
+static int acquire_shared_luts(HydAmdContext *ctx) {
+    std::lock_guard<std::mutex> lock(g_luts_mutex);
+    for (const SharedLuts &l : g_luts)
+        if (l.device == ctx->device && l.linear_light == ctx->linear_light) {
+            ctx->in_lut8 = l.in_lut8;
+            ctx->in_lut16 = l.in_lut16;
+            ctx->bias_lut = l.bias_lut;
+            ctx->best_register_mode = l.best_register_mode;
+            return ST_OK;
+        }
+    SharedLuts l = {ctx->device, ctx->linear_light, nullptr, nullptr, nullptr, 2};
+    HIP_TRY(ctx, hipMalloc(&l.in_lut8, 256 * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMalloc(&l.in_lut16, 65536 * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMalloc(&l.bias_lut, 65536 * sizeof(float)));
+    std::vector<uint16_t> l8(256), l16(65536);
+    std::vector<float> bias(65536);
+    host_input_lut(l8.data(), 256, ctx->linear_light);
+    host_input_lut(l16.data(), 65536, ctx->linear_light);
+    const float unit = 1.0f / (65536 - 1.0f);
+    for (size_t i = 0; i < 65536; i++)
+        bias[i] = host_bias(i * unit);
+    HIP_TRY(ctx, hipMemcpy(l.in_lut8, l8.data(), 256 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(l.in_lut16, l16.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(l.bias_lut, bias.data(), 65536 * sizeof(float), hipMemcpyHostToDevice));
+    uint32_t *mism = nullptr;
+    HIP_TRY(ctx, hipMalloc(&mism, sizeof(uint32_t)));
+    for (int mode = 0; mode < 2 && l.best_register_mode == 2; mode++) {
+        uint32_t h_mism = 1;
+        HIP_TRY(ctx, hipMemsetAsync(mism, 0, sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hydk::launch_lut_selftest(l.in_lut16, l.bias_lut, ctx->linear_light, mode, mism, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&h_mism, mism, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (h_mism == 0)
+            l.best_register_mode = mode;
+    }
+    (void)hipFree(mism);
+    g_luts.push_back(l);
+    ctx->in_lut8 = l.in_lut8;
+    ctx->in_lut16 = l.in_lut16;
+    ctx->bias_lut = l.bias_lut;
+    ctx->best_register_mode = l.best_register_mode;
     return ST_OK;
 }
 
@@ -757,9 +821,6 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->jobs_uploaded[i], hipEventDisableTiming));
     }
     ctx->h_jobs = ctx->h_jobs_ring[0];
-    HIP_TRY(ctx, hipMalloc(&ctx->in_lut8, 256 * sizeof(uint16_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->in_lut16, 65536 * sizeof(uint16_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->bias_lut, 65536 * sizeof(float)));
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_total_pinned, sizeof(uint64_t), hipHostMallocDefault));
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_status_pinned, sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(ctx, hipMemset(ctx->group_bits, 0, slots * G * sizeof(uint32_t)));
@@ -770,31 +831,14 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
         HIP_TRY(ctx, hipMalloc(&ctx->dbg_quant, 3 * kDbgPlane * sizeof(int32_t)));
     }
 
-    /* LUTs: built on the host, uploaded, then the register evaluation is checked against them */
-    std::vector<uint16_t> l8(256), l16(65536);
-    std::vector<float> bias(65536);
-    host_input_lut(l8.data(), 256, ctx->linear_light);
-    host_input_lut(l16.data(), 65536, ctx->linear_light);
-    const float unit = 1.0f / (65536 - 1.0f);
-    for (size_t i = 0; i < 65536; i++)
-        bias[i] = host_bias(i * unit);
-    HIP_TRY(ctx, hipMemcpy(ctx->in_lut8, l8.data(), 256 * sizeof(uint16_t), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->in_lut16, l16.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->bias_lut, bias.data(), 65536 * sizeof(float), hipMemcpyHostToDevice));
-
-    uint32_t *mism = nullptr;
-    HIP_TRY(ctx, hipMalloc(&mism, sizeof(uint32_t)));
-    ctx->best_register_mode = 2;
-    for (int mode = 0; mode < 2 && ctx->best_register_mode == 2; mode++) {
-        uint32_t h_mism = 1;
-        HIP_TRY(ctx, hipMemsetAsync(mism, 0, sizeof(uint32_t), ctx->stream));
-        HIP_TRY(ctx, hydk::launch_lut_selftest(ctx->in_lut16, ctx->bias_lut, ctx->linear_light, mode, mism, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(&h_mism, mism, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (h_mism == 0)
-            ctx->best_register_mode = mode;
+    /* LUTs: built on the host, uploaded ONCE per device and transfer curve and shared by every context of the process
+     * (sixteen contexts' private copies were 6 MB of tables competing for each 4 MB L2 — the gathers of the transform
+     * kernel then miss); the register evaluation is checked against them, also once */
+    {
+        const int st = acquire_shared_luts(ctx);
+        if (st != ST_OK)
+            return st;
     }
-    (void)hipFree(mism);
     ctx->register_luts_ok = ctx->best_register_mode < 2;
     ctx->use_luts = ctx->best_register_mode;
     if (const char *env = getenv("HYDAMD_RANS_WAVES")) {
@@ -986,6 +1030,39 @@ int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, const void *const 
     st = record_lf_group(ctx, slot, dsrc, (ptrdiff_t)(3 * width), 3, sample_fmt, width, height, preset);
     if (st == ST_OK && slot + 1 > ctx->host_staged)
         ctx->host_staged = slot + 1;
+    return st;
+}
+
+/* One call for a whole device-resident frame: begin, every LF group in raster order (slot = raster index = preset,
+ * the one-frame layout of reference libhydrium.c:172-203 for tiles sent in raster order), the closing stage.  What a
+ * caller with frames in HBM wants, and what keeps a host loop out of the frame rate: eighteen calls through a binding
+ * (Python: 0.44 ms of host time per 8K frame — as much as the GPU needs for the frame) become one. */
+int hydamd_encode_image(HydAmdContext *ctx, const void *const src[3], ptrdiff_t row_stride, ptrdiff_t pixel_stride,
+                        int sample_fmt, size_t width, size_t height) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (!src || !src[0] || !src[1] || !src[2])
+        return fail(ctx, ST_API_ERROR, "null pixel pointer");
+    if (width == 0 || height == 0)
+        return fail(ctx, ST_API_ERROR, "empty image");
+    const size_t lfx = (width + 2047) >> 11, lfy = (height + 2047) >> 11;
+    if (lfx * lfy > (size_t)ctx->max_slots)
+        return fail(ctx, ST_API_ERROR, "context has too few LF-group slots for this image");
+    if (sample_fmt != HYDK_FMT_U8 && sample_fmt != HYDK_FMT_U16 && sample_fmt != HYDK_FMT_F32)
+        return fail(ctx, ST_API_ERROR, "Invalid Sample Format");
+    int st = hydamd_begin_frame(ctx, (unsigned)(lfx * lfy));
+    const ptrdiff_t ss = (ptrdiff_t)sample_size(sample_fmt);
+    for (size_t ty = 0; ty < lfy && st == ST_OK; ty++)
+        for (size_t tx = 0; tx < lfx && st == ST_OK; tx++) {
+            const ptrdiff_t off = ((ptrdiff_t)(ty * 2048) * row_stride + (ptrdiff_t)(tx * 2048) * pixel_stride) * ss;
+            const void *p[3] = {(const char *)src[0] + off, (const char *)src[1] + off, (const char *)src[2] + off};
+            const size_t w = width - tx * 2048 < 2048 ? width - tx * 2048 : 2048;
+            const size_t h = height - ty * 2048 < 2048 ? height - ty * 2048 : 2048;
+            st = hydamd_encode_lf_group(ctx, (int)(ty * lfx + tx), p, row_stride, pixel_stride, sample_fmt, w, h,
+                                        (unsigned)(ty * lfx + tx));
+        }
+    if (st == ST_OK)
+        st = hydamd_finish_frame(ctx, (int)(lfx * lfy));
     return st;
 }
 
@@ -1205,6 +1282,99 @@ int hydamd_set_alphabet_floor_device(HydAmdContext *ctx, const uint32_t *floor_o
     if (!ctx)
         return ST_API_ERROR;
     ctx->alpha_floor_dev = floor_on_device;
+    return ST_OK;
+}
+
+/* ---- one frame on several devices, inside one process: no collective library, peer reads over xGMI ----
+ * The reference codes a frame's LF groups one after another on one core (encoder.c:928-957); here every device owns a
+ * run of consecutive LF groups (in send order) on a context of its own.  Two things cross devices: the running alphabet
+ * maximum (one word per LF group, read from the earlier devices' contexts by a single-wave kernel) and, at the end, the
+ * blobs, which the assembling device's kernels read in place through peer access. */
+int hydamd_context_device(HydAmdContext *ctx) { return ctx ? ctx->device : -1; }
+
+static int enable_peer_reads(HydAmdContext *ctx, int peer_device) {
+    if (peer_device == ctx->device)
+        return ST_OK; /* several contexts of one device (also how the tests alias a device list) */
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int can = 0;
+    HIP_TRY(ctx, hipDeviceCanAccessPeer(&can, ctx->device, peer_device));
+    if (!can)
+        return fail(ctx, ST_INTERNAL_ERROR, "no peer access between two devices of HYDAMD_DEVICES");
+    const hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+        return fail(ctx, ST_INTERNAL_ERROR, "hipDeviceEnablePeerAccess", e);
+    (void)hipGetLastError();
+    return ST_OK;
+}
+
+/* ctx's stream waits (on the device) for everything enqueued so far on peer's stream, and may read peer's memory */
+int hydamd_wait_for(HydAmdContext *ctx, HydAmdContext *peer) {
+    if (!ctx || !peer)
+        return ST_API_ERROR;
+    if (ctx == peer)
+        return ST_OK;
+    HIP_TRY(peer, hipSetDevice(peer->device));
+    if (!peer->peer_event)
+        HIP_TRY(peer, hipEventCreateWithFlags(&peer->peer_event, hipEventDisableTiming));
+    HIP_TRY(peer, hipEventRecord(peer->peer_event, peer->stream));
+    const int st = enable_peer_reads(ctx, peer->device);
+    if (st != ST_OK)
+        return st;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, peer->peer_event, 0));
+    return ST_OK;
+}
+
+namespace {
+struct PeerMaxima {
+    const uint32_t *max[HYDAMD_MAX_PEERS];
+    int slots[HYDAMD_MAX_PEERS];
+    int count;
+};
+__global__ __launch_bounds__(64) void k_floor_from_peers(PeerMaxima a, uint32_t *floor) {
+    uint32_t m = 0;
+    for (int p = 0; p < a.count; p++)
+        for (int i = threadIdx.x; i < a.slots[p]; i += 64)
+            m = max(m, a.max[p][i]);
+#pragma unroll
+    for (int d = 32; d; d >>= 1)
+        m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    if (threadIdx.x == 0)
+        *floor = m;
+}
+} /* namespace */
+
+/* The floor of ctx's LF groups = the largest token + 1 over the LF groups sent before them, which the `npeers` contexts in
+ * `peers` transformed (their transform stages must be enqueued: hydamd_run_transform or hydamd_submit_lf_group for every
+ * slot): read from their memory by a kernel in ctx's stream, behind their transform kernels, and left where ctx's table
+ * kernel looks for it.  No host synchronisation. */
+int hydamd_alphabet_floor_from_peers(HydAmdContext *ctx, int npeers, HydAmdContext *const *peers) {
+    if (!ctx || npeers < 0 || npeers > HYDAMD_MAX_PEERS || (npeers && !peers))
+        return ctx ? fail(ctx, ST_API_ERROR, "bad peer list") : ST_API_ERROR;
+    if (npeers == 0) {
+        ctx->alpha_floor_dev = nullptr;
+        return ST_OK;
+    }
+    PeerMaxima a;
+    memset(&a, 0, sizeof(a));
+    for (int p = 0; p < npeers; p++) {
+        if (!peers[p] || peers[p] == ctx)
+            return fail(ctx, ST_API_ERROR, "bad peer");
+        if (peers[p]->transformed < 1)
+            return fail(ctx, ST_API_ERROR, "a peer's transform stage is not enqueued yet");
+        const int st = hydamd_wait_for(ctx, peers[p]);
+        if (st != ST_OK)
+            return st;
+        a.max[p] = peers[p]->alpha_max;
+        a.slots[p] = peers[p]->transformed;
+    }
+    a.count = npeers;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->peer_floor)
+        HIP_TRY(ctx, hipMalloc(&ctx->peer_floor, sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_floor_from_peers, dim3(1), dim3(64), 0, ctx->stream, a, ctx->peer_floor);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->alpha_floor_dev = ctx->peer_floor;
     return ST_OK;
 }
 

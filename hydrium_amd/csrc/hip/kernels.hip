@@ -48,16 +48,16 @@ constexpr int kThreads = 256;
 #define HYDK_K1_GATHER_ODD 0 /* the same, for the odd pixels of a row only (needs HYDK_K1_ILP >= 2) */
 #endif
 #ifndef HYDK_K1_WAVELOCAL
-#define HYDK_K1_WAVELOCAL 0
+#define HYDK_K1_WAVELOCAL 1
 #endif
 #ifndef HYDK_K1_TOK
-#define HYDK_K1_TOK 0
+#define HYDK_K1_TOK 7 /* 1: hybrid-uint split through the float conversion; 2: every token straight into the LDS histogram; 4: global_* instead of flat_* memory instructions; 8: the pipelined walk over zig-zag-ordered coefficients */
 #endif
 #ifndef HYDK_K1_SKIP
 #define HYDK_K1_SKIP 0
 #endif
 #ifndef HYDK_K1_ILP
-#define HYDK_K1_ILP 0 /* > 0: pixels of a row whose curves are evaluated in lock step (instruction-level parallelism) */
+#define HYDK_K1_ILP 2 /* > 0: pixels of a row whose curves are evaluated in lock step (instruction-level parallelism) */
 #endif
 constexpr int kS0Block = 72;            /* floats per block in the row-pass buffer: 64 + 8 pad -> conflict-free column reads */
 constexpr int kS0Chan = 32 * kS0Block;  /* floats per channel */

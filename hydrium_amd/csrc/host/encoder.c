@@ -57,6 +57,7 @@
 #include "libhydrium/libhydrium.h"
 
 #define TILE_PIPE_MAX 8
+#define HYD_MAX_DEVICES HYDAMD_MAX_PEERS /* devices one encoder can deal a frame to */
 
 typedef struct LfgResult {
     int32_t *dc; /* [3][vbh][vbw]; NULL when the LF coefficients were coded on the device */
@@ -106,6 +107,16 @@ struct HYDEncoder {
         HydFrameLfg lfg;     /* the tile (the frame's only LF group) */
         HydFrameShape shape; /* shape.lfg points at lfg above */
     } pipe[TILE_PIPE_MAX];
+    /* which device this encoder's single-device work runs on (taken in turn from the device list at the first tile), and,
+     * for a one-frame image dealt to several devices: shard d owns the tiles sent first_slot[d] .. first_slot[d + 1] - 1 */
+    int home_device;
+    int have_home;
+    int shards; /* 0: not decided yet; 1: everything on e->dev; > 1: multi[] */
+    struct Shard {
+        HydAmdContext *dev;
+        size_t first_slot, slots;
+        int failed;
+    } multi[HYD_MAX_DEVICES];
     int pipe_depth; /* 0: tile frames are coded synchronously through e->dev */
     int pipe_request; /* hydamd_set_tile_pipeline: frames in flight this encoder asks for; 0 = HYDAMD_TILE_PIPELINE, else 1 */
     struct PendingTile *cur_pend; /* the ring entry the running call works for (device errors are recorded there) */
@@ -258,6 +269,7 @@ static int code_lf_groups_parallel(HYDEncoder *e, const HydFrameShape *shape, co
 
 static int device_fail(HYDEncoder *e, int code);
 static void pipe_release(HYDEncoder *e);
+static void multi_release(HYDEncoder *e);
 
 /* payload == NULL: the packed HF sections are still on the device (e->dev) and are copied straight
  * into the output stream */
@@ -532,23 +544,57 @@ static int tile_pipeline_depth(const HYDEncoder *e) {
     return e->pipe_request ? e->pipe_request : env;
 }
 
-/* HYDAMD_DEVICE: which GPU the drop-in API encodes on (default 0); a process per GPU sets it to its own */
-static int api_device(void) {
-    static int dev = -1;
-    if (dev < 0) {
-        const char *v = getenv("HYDAMD_DEVICE");
-        dev = v && *v ? atoi(v) : 0;
-        if (dev < 0)
-            dev = 0;
+/* The devices the drop-in API encodes on (the host tile scheduler's view of the node):
+ *   HYDAMD_DEVICES=a,b,c   this list, in this order (an index may repeat: several contexts of one GPU — how the tests
+ *                          run the multi-device path on a box with one);
+ *   HYDAMD_DEVICE=n        one device (a process per GPU sets its own; what bench.py's ranks do);
+ *   neither                every device the runtime shows, at most HYD_MAX_DEVICES.
+ * A one-frame image of at least HYDAMD_SHARD_MIN_LF_GROUPS (default 8) LF groups is dealt to the devices in runs of
+ * consecutive tiles, two or more per device (multi_* below); anything smaller — and every tile-mode encoder — runs on ONE
+ * device, encoders taking the devices in turn (a batch of frames on several threads spreads over the node). */
+static int g_devices[HYD_MAX_DEVICES], g_device_count = -1;
+static unsigned long g_encoder_seq; /* under g_ctx_lock */
+static int g_shard_min = 8;
+
+static void device_list_init(void) {
+    pthread_mutex_lock(&g_ctx_lock);
+    if (g_device_count < 0) {
+        int n = 0;
+        const char *v = getenv("HYDAMD_DEVICES");
+        if (v && *v) {
+            while (*v && n < HYD_MAX_DEVICES) {
+                char *end = NULL;
+                const long d = strtol(v, &end, 10);
+                if (end == v)
+                    break;
+                g_devices[n++] = d < 0 ? 0 : (int)d;
+                v = *end == ',' ? end + 1 : end;
+            }
+        } else if ((v = getenv("HYDAMD_DEVICE")) != NULL && *v) {
+            g_devices[n++] = atoi(v) < 0 ? 0 : atoi(v);
+        } else {
+            n = hydamd_device_count();
+            if (n > HYD_MAX_DEVICES)
+                n = HYD_MAX_DEVICES;
+            for (int i = 0; i < n; i++)
+                g_devices[i] = i;
+        }
+        if (n < 1) { /* no device: hydamd_create says so when a tile arrives */
+            g_devices[0] = 0;
+            n = 1;
+        }
+        if ((v = getenv("HYDAMD_SHARD_MIN_LF_GROUPS")) != NULL && *v)
+            g_shard_min = atoi(v) < 2 ? 2 : atoi(v);
+        g_device_count = n;
     }
-    return dev;
+    pthread_mutex_unlock(&g_ctx_lock);
 }
 
-static HydAmdContext *ctx_acquire(size_t slots, int linear, int *status) {
+static HydAmdContext *ctx_acquire(int device, size_t slots, int linear, int *status) {
     HydAmdContext *c = NULL;
     pthread_mutex_lock(&g_ctx_lock);
     for (int i = 0; i < CTX_POOL_MAX && !c; i++)
-        if (g_pool[i].ctx && g_pool[i].slots == slots && g_pool[i].linear == linear) {
+        if (g_pool[i].ctx && g_pool[i].slots == slots && g_pool[i].linear == linear && hydamd_context_device(g_pool[i].ctx) == device) {
             c = g_pool[i].ctx;
             g_pool[i].ctx = NULL;
         }
@@ -557,7 +603,7 @@ static HydAmdContext *ctx_acquire(size_t slots, int linear, int *status) {
         *status = HYD_OK;
         return c;
     }
-    return hydamd_create(api_device(), (int)slots, linear, 0, status);
+    return hydamd_create(device, (int)slots, linear, 0, status);
 }
 
 /* what a parked context of `slots` LF-group slots holds, in MB: its frame arrays at their default sizes,
@@ -701,6 +747,7 @@ static int offer_spare_buffer(void *p, size_t cap) {
 HYDRIUM_EXPORT HYDStatusCode hyd_encoder_destroy(HYDEncoder *e) {
     if (!e)
         return HYD_OK;
+    multi_release(e);
     pipe_release(e);
     if (e->dev) {
         const double t0 = now_ms();
@@ -749,6 +796,7 @@ HYDRIUM_EXPORT HYDStatusCode hyd_set_metadata(HYDEncoder *e, const HYDImageMetad
     e->sent_mask = calloc(e->lfg_per_frame, 1);
     if (!e->sent || !e->sent_mask)
         return FAIL(e, HYD_NOMEM, "out of memory");
+    multi_release(e);
     pipe_release(e);
     if (e->dev) { /* metadata changed: the device context is rebuilt lazily */
         ctx_release(e->dev, e->dev_slots, e->dev_linear, !e->dev_failed);
@@ -797,6 +845,9 @@ static void mark_device_failed(HYDEncoder *e) {
     e->dev_failed = 1;
     if (e->cur_pend)
         e->cur_pend->failed = 1;
+    for (int d = 0; d < e->shards && e->shards > 1; d++)
+        if (e->multi[d].dev == e->dev)
+            e->multi[d].failed = 1;
 }
 
 static int device_fail(HYDEncoder *e, int code) {
@@ -1029,6 +1080,114 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
     return ret ? ret : finish_frame_collect(e, shape);
 }
 
+/* ---- one frame on several devices (SURVEY 8(e) behind the C boundary) ----
+ * hands the shards' contexts back; e->dev was only an alias of one of them */
+static void multi_release(HYDEncoder *e) {
+    if (e->shards > 1) {
+        for (int d = 0; d < e->shards; d++) {
+            struct Shard *sh = &e->multi[d];
+            if (sh->dev)
+                ctx_release(sh->dev, sh->slots, e->dev_linear, !sh->failed);
+        }
+        e->dev = NULL;
+    }
+    memset(e->multi, 0, sizeof(e->multi));
+    e->shards = 0;
+}
+
+/* The closing stage of a frame whose LF groups sit on several devices' contexts (shard d: tiles first_slot[d] ... in send
+ * order).  Per device what the reference does per LF group (encoder.c:928-957), with two crossings, both device-side: the
+ * running alphabet maximum (hydamd_alphabet_floor_from_peers: a peer read behind the earlier shards' transform kernels)
+ * and the frame itself, which the first shard's GPU assembles from every shard's blob — read in place over xGMI
+ * (hydamd_wait_for + peer access); nothing of the frame passes through host memory before the finished file. */
+static int finish_frame_multi(HYDEncoder *e, const HydFrameShape *shape) {
+    const int N = e->shards;
+    const size_t n = shape->lfg_count;
+    HydAmdContext *ctxs[HYD_MAX_DEVICES];
+    double t0 = now_ms();
+    int ret = 0;
+    for (int d = 0; d < N; d++) {
+        ctxs[d] = e->multi[d].dev;
+        if (!ctxs[d])
+            return FAIL(e, HYD_INTERNAL_ERROR, "a shard of this frame never received a tile");
+    }
+    for (int d = 0; d < N; d++) { /* whatever of the transform stage the tiles' own calls did not enqueue */
+        e->dev = ctxs[d];
+        if ((ret = hydamd_run_transform(ctxs[d], (int)e->multi[d].slots)) != 0)
+            return device_fail(e, ret);
+    }
+    for (int d = 1; d < N; d++) { /* shard d's entropy tables start from the maximum over shards 0 .. d-1 */
+        e->dev = ctxs[d];
+        if ((ret = hydamd_alphabet_floor_from_peers(ctxs[d], d, ctxs)) != 0)
+            return device_fail(e, ret);
+    }
+    for (int d = 0; d < N; d++) {
+        e->dev = ctxs[d];
+        if ((ret = hydamd_finish_frame(ctxs[d], (int)e->multi[d].slots)) != 0)
+            return device_fail(e, ret);
+    }
+    e->dev = ctxs[0];
+    HydAmdAssembler *as = hydamd_context_assembler(ctxs[0]);
+    if (!as)
+        return device_fail(e, HYD_INTERNAL_ERROR);
+    uint32_t lf_ids[HYDAMD_MAX_LF_GROUPS], blob_slots[HYD_MAX_DEVICES];
+    for (size_t s = 0; s < n; s++)
+        lf_ids[s] = (uint32_t)shape->lfg[s].raster_id;
+    for (int d = 0; d < N; d++)
+        blob_slots[d] = (uint32_t)e->multi[d].slots;
+    ret = hydamd_assembler_plan(as, &e->metadata, 0, 1, (size_t)N, blob_slots, lf_ids, NULL, 0);
+    if (ret)
+        return FAIL(e, ret, "frame description rejected by the assembler");
+    size_t out_cap = 4096 * n + (256u << 10);
+    for (int d = 0; d < N; d++)
+        out_cap += hydamd_blob_bound(ctxs[d], (int)e->multi[d].slots);
+    for (int attempt = 0; attempt < 4; attempt++) {
+        const void *blob[HYD_MAX_DEVICES];
+        size_t cap[HYD_MAX_DEVICES], size = 0;
+        for (int d = 0; d < N; d++) {
+            e->dev = ctxs[d];
+            if ((ret = hydamd_export_frame_owned(ctxs[d], (int)e->multi[d].slots, &blob[d], &cap[d])) != 0)
+                return device_fail(e, ret);
+        }
+        e->dev = ctxs[0];
+        for (int d = 1; d < N; d++) /* the assembling GPU's stream waits for the other shards' exports and may read their memory */
+            if ((ret = hydamd_wait_for(ctxs[0], ctxs[d])) != 0)
+                return device_fail(e, ret);
+        ret = hydamd_assembler_run(as, blob, cap, hydamd_get_stream(ctxs[0]), NULL, out_cap);
+        if (ret)
+            return device_fail(e, ret);
+        for (int d = N - 1; d >= 0; d--) { /* a shard whose frame outgrew its buffers reruns it in here: its blob is then stale */
+            e->dev = ctxs[d];
+            if ((ret = hydamd_sync(ctxs[d])) != 0)
+                return device_fail(e, ret);
+        }
+        TRACE("GPU hot path on every device + assembly", t0);
+        t0 = now_ms();
+        ret = hydamd_assembler_result(as, &size);
+        if (ret) {
+            const char *m = hydamd_assembler_error(as);
+            if (m && strstr(m, "incomplete"))
+                continue;
+            if (ret == HYD_NEED_MORE_OUTPUT && size > out_cap) {
+                out_cap = size;
+                continue;
+            }
+            if (m && strstr(m, "NaN"))
+                return FAIL(e, HYD_API_ERROR, "Invalid NaN Float");
+            mark_device_failed(e);
+            return FAIL(e, ret < HYD_ERROR_START ? ret : HYD_INTERNAL_ERROR, "GPU frame assembly failed");
+        }
+        uint8_t *dst = hb_extend(&e->stream, size);
+        if (!dst)
+            return FAIL(e, HYD_NOMEM, "out of memory");
+        ret = hydamd_assembler_read(as, dst, size);
+        TRACE("frame to the host", t0);
+        return ret ? device_fail(e, ret) : 0;
+    }
+    mark_device_failed(e);
+    return FAIL(e, HYD_INTERNAL_ERROR, "frame still does not fit after enlarging its buffers");
+}
+
 /* tile mode: the ring entry's frame, launched some calls ago, into the output stream */
 static int pipe_collect(HYDEncoder *e, struct PendingTile *p) {
     struct PendingTile *const before = e->cur_pend;
@@ -1110,6 +1269,93 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
     if (ret)
         return ret;
 
+    device_list_init();
+    if (!e->have_home) { /* encoders take the devices in turn */
+        pthread_mutex_lock(&g_ctx_lock);
+        e->home_device = g_devices[g_encoder_seq++ % (unsigned long)g_device_count];
+        pthread_mutex_unlock(&g_ctx_lock);
+        e->have_home = 1;
+    }
+    if (!e->shards) {
+        const size_t n = e->lfg_per_frame;
+        const int by_device = g_device_count, by_size = (int)(n / 2 < HYD_MAX_DEVICES ? n / 2 : HYD_MAX_DEVICES);
+        e->shards = e->one_frame && by_device > 1 && n >= (size_t)g_shard_min && !host_assembly_forced() ? (by_device < by_size ? by_device : by_size) : 1;
+        memset(e->multi, 0, sizeof(e->multi));
+        for (int d = 0; d < e->shards && e->shards > 1; d++) {
+            e->multi[d].first_slot = (size_t)d * n / (size_t)e->shards;
+            e->multi[d].slots = (size_t)(d + 1) * n / (size_t)e->shards - e->multi[d].first_slot;
+        }
+    }
+    if (e->shards > 1) { /* one frame dealt to several devices: this tile goes to the shard that owns its place in send order */
+        const size_t slot = e->tiles_sent;
+        int d = e->shards - 1;
+        while (d > 0 && slot < e->multi[d].first_slot)
+            d--;
+        struct Shard *sh = &e->multi[d];
+        e->cur_pend = NULL;
+        e->dev_linear = e->metadata.linear_light != 0;
+        if (!sh->dev) {
+            int st = 0;
+            const double tc = now_ms();
+            sh->dev = ctx_acquire(g_devices[d], sh->slots, e->dev_linear, &st);
+            TRACE("acquire device context (shard)", tc);
+            if (!sh->dev) {
+                const char *m = hydamd_error(NULL);
+                if (st == HYD_NOMEM)
+                    return FAIL(e, HYD_NOMEM, "out of device memory");
+                return FAIL(e, HYD_INTERNAL_ERROR, m && strstr(m, "no usable HIP device")
+                                                       ? "no usable HIP device (this build has no CPU fallback)"
+                                                       : "GPU initialisation failed");
+            }
+            e->dev = sh->dev;
+            if ((ret = hydamd_begin_frame(sh->dev, (unsigned)e->lfg_per_frame)) != 0)
+                return device_fail(e, ret);
+        }
+        e->dev = sh->dev;
+        const int local = (int)(slot - sh->first_slot);
+        HydFrameLfg *l = &e->sent[slot];
+        l->raster_id = (size_t)tile_y * e->lfg_count_x + tile_x;
+        l->x = tile_x;
+        l->y = tile_y;
+        l->width = tw;
+        l->height = th;
+        const double tu = now_ms();
+        ret = hydamd_encode_lf_group_host(sh->dev, local, buffer, row_stride, pixel_stride, (int)sample_fmt, tw, th, (unsigned)l->raster_id);
+        if (!ret && eager_on()) {
+            ret = hydamd_submit_lf_group(sh->dev, local);
+            if (!ret && (local & 3) == 3 && !e->last_tile && hydamd_lf_coder(sh->dev))
+                ret = hydamd_run_lf_coder(sh->dev, local + 1, 0);
+        }
+        if (ret)
+            return device_fail(e, ret);
+        TRACE("stage + upload tile (shard)", tu);
+        e->sent_mask[l->raster_id] = 1;
+        e->tiles_sent++;
+        if (!e->last_tile) {
+            drain(e);
+            return HYD_OK;
+        }
+        if (e->tiles_sent != e->lfg_per_frame)
+            return FAIL(e, HYD_API_ERROR, "one-frame mode needs every tile before the final one");
+        HydFrameShape shape;
+        memset(&shape, 0, sizeof(shape));
+        shape.one_frame = 1;
+        shape.image_width = shape.frame_width = W;
+        shape.image_height = shape.frame_height = H;
+        shape.tile_count_x = e->tile_w >> 8;
+        shape.tile_count_y = e->tile_h >> 8;
+        shape.lfg_count = e->lfg_per_frame;
+        shape.lfg = e->sent;
+        shape.is_last = e->last_tile;
+        if ((ret = finish_frame_multi(e, &shape)) != 0)
+            return ret;
+        e->frame_done = 1;
+        if (!e->out)
+            return FAIL(e, HYD_API_ERROR, "buffer was never provided");
+        drain(e);
+        return e->stream_pos < e->stream.len ? HYD_NEED_MORE_OUTPUT : HYD_OK;
+    }
+
     struct PendingTile *pend = NULL;
     e->cur_pend = NULL;
     if (!e->one_frame && tile_pipeline_depth(e) > 1) {
@@ -1131,7 +1377,7 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
         e->dev_slots = e->lfg_per_frame;
         e->dev_linear = e->metadata.linear_light != 0;
         e->dev_failed = 0;
-        e->dev = ctx_acquire(e->dev_slots, e->dev_linear, &st);
+        e->dev = ctx_acquire(e->home_device, e->dev_slots, e->dev_linear, &st);
         TRACE("acquire device context", tc);
         if (!e->dev) {
             const char *m = hydamd_error(NULL);

@@ -65,6 +65,7 @@ def dll(path: Optional[str] = None):
         lf_args = [vp, i, C.POINTER(vp), C.c_ssize_t, C.c_ssize_t, i, sz, sz, u]
         d.hydamd_encode_lf_group.argtypes = lf_args
         d.hydamd_encode_lf_group_host.argtypes = lf_args
+        d.hydamd_encode_image.argtypes = [vp, C.POINTER(vp), C.c_ssize_t, C.c_ssize_t, i, sz, sz]
         d.hydamd_finish_frame.argtypes = [vp, i]
         d.hydamd_run_transform.argtypes = [vp, i]
         d.hydamd_run_entropy.argtypes = [vp, i]
@@ -255,6 +256,12 @@ class DeviceContext:
         n = lfx * lfy
         if num_slots_check and n > self.max_lf_groups:
             raise ValueError("context has too few LF-group slots for this image")
+        if not getattr(self, "per_lf_group_calls", False):
+            # one C call per frame (hydamd_encode_image): eighteen ctypes calls cost the host as much as the GPU needs
+            base = img.data_ptr()
+            arr = (C.c_void_p * 3)(base, base + isz, base + 2 * isz)
+            self._ck(self.d.hydamd_encode_image(self.h, arr, 3 * w, 3, fmt, w, h))
+            return n
         self.begin_frame(n)
         base = img.data_ptr()
         for ty in range(lfy):

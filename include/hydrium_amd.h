@@ -105,6 +105,12 @@ HYDAMD_EXPORT int hydamd_encode_lf_group(HydAmdContext *ctx, int slot, const voi
                                          ptrdiff_t pixel_stride, int sample_fmt, size_t width, size_t height,
                                          unsigned preset);
 
+/* A whole device-resident image in ONE call: hydamd_begin_frame, hydamd_encode_lf_group for every LF group in raster
+ * order (slot = raster index = preset: the one-frame layout of the reference for tiles sent in raster order,
+ * libhydrium.c:172-203) and hydamd_finish_frame.  src/strides/fmt as above, for the image's first pixel.  Asynchronous. */
+HYDAMD_EXPORT int hydamd_encode_image(HydAmdContext *ctx, const void *const src[3], ptrdiff_t row_stride,
+                                      ptrdiff_t pixel_stride, int sample_fmt, size_t width, size_t height);
+
 /* Same, from HOST pointers: the samples are gathered into pinned staging (the caller's buffers may
  * be reused as soon as this returns, as after hyd_send_tile) and copied to the GPU on the stream. */
 HYDAMD_EXPORT int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, const void *const src[3],
@@ -213,6 +219,21 @@ HYDAMD_EXPORT int hydamd_run_entropy(HydAmdContext *ctx, int num_slots);
  * hydamd_begin_frame).  A job that all-gathers the maxima with RCCL writes its floor there. */
 HYDAMD_EXPORT const uint32_t *hydamd_alphabet_max_device(HydAmdContext *ctx);
 HYDAMD_EXPORT int hydamd_set_alphabet_floor_device(HydAmdContext *ctx, const uint32_t *floor_on_device);
+
+/* One frame on several devices of ONE process (what hyd_send_tile does when HYDAMD_DEVICES names more than one; no
+ * collective library involved): every device's context owns a run of consecutive LF groups in send order.
+ *   hydamd_wait_for                   ctx's stream waits, on the device, for everything enqueued so far on peer's
+ *                                     stream; peer access from ctx's device to peer's is enabled (xGMI reads).
+ *   hydamd_alphabet_floor_from_peers  the floor of ctx's LF groups = the largest token + 1 over the LF groups of the
+ *                                     `npeers` contexts that hold the LF groups sent BEFORE ctx's (their transform
+ *                                     stages enqueued): a single-wave kernel in ctx's stream reads the peers' maxima
+ *                                     in place, behind their transform kernels, and leaves the floor where ctx's
+ *                                     table kernel reads it.  Then hydamd_run_entropy / hydamd_finish_frame.
+ * The assembler (below) reads blobs of other devices in place: hydamd_wait_for(assembling ctx, peer) first. */
+#define HYDAMD_MAX_PEERS 8
+HYDAMD_EXPORT int hydamd_context_device(HydAmdContext *ctx);
+HYDAMD_EXPORT int hydamd_wait_for(HydAmdContext *ctx, HydAmdContext *peer);
+HYDAMD_EXPORT int hydamd_alphabet_floor_from_peers(HydAmdContext *ctx, int npeers, HydAmdContext *const *peers);
 
 /*
  * One self-describing byte string with everything a frame assembler needs from this context's LF

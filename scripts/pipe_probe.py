@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""What bounds the pipelined loop (bench.py --mode frame)?  The same loop, stripped to its core, with knobs:
+
+    python scripts/pipe_probe.py [--streams 16] [--frames 192] [--profile 0|1] [--lf 0|2] [--rans 5] [--reps 3]
+
+Prints, per repetition: frames/ms by HIP events (last priming frame -> last timed frame), the host's time per frame
+spent enqueuing (time inside encode_image_tensor), and how far ahead of the GPU the host ran.  HYDAMD_LIB selects a
+library variant (scripts/k1_variants.py)."""
+import argparse
+import os
+import sys
+import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from hydrium_amd import device, placement, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--streams", type=int, default=16)
+ap.add_argument("--frames", type=int, default=192)
+ap.add_argument("--profile", type=int, default=0)
+ap.add_argument("--lf", type=int, default=2)
+ap.add_argument("--rans", type=int, default=5)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--size", type=int, default=8192)
+ap.add_argument("--no-bind", action="store_true")
+a = ap.parse_args()
+if not a.no_bind:
+    placement.bind_near_gpu(0)
+img = synth.make_image("photo", a.size, a.size, 16, device=torch.device("cuda", 0))
+lfg = (-(-a.size // 2048)) ** 2
+ctxs = [device.DeviceContext(0, lfg, 0) for _ in range(a.streams)]
+ext = [torch.cuda.ExternalStream(c.get_stream()) for c in ctxs]
+for c in ctxs:
+    c.set_rans_waves(a.rans)
+    c.set_lf_coder(a.lf)
+    c.encode_image_tensor(img)
+for c in ctxs:
+    c.sync()
+    c.profile(bool(a.profile))
+S = a.streams
+for rep in range(a.reps):
+    torch.cuda.synchronize()
+    host = 0.0
+    evs = []
+    t0 = time.perf_counter()
+    n = 4 * S + a.frames + S
+    first = 0.0
+    for i in range(n):
+        th = time.perf_counter()
+        ctxs[i % S].encode_image_tensor(img)
+        host += time.perf_counter() - th
+        if i == 3 * S - 1:
+            first = host / (3 * S)  # no context has more than three frames queued yet: nothing can have blocked
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(ext[i % S])
+        evs.append(e)
+    t_issue = time.perf_counter() - t0
+    for c in ctxs:
+        c.sync()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    w = min(S, a.frames)
+    base = evs[0]
+    t_start = sum(base.elapsed_time(e) for e in evs[4 * S - w:4 * S]) / w
+    t_end = sum(base.elapsed_time(e) for e in evs[4 * S + a.frames - w:4 * S + a.frames]) / w
+    ms = (t_end - t_start) / a.frames
+    print(f"streams {S} profile {a.profile} lf {a.lf} rans {a.rans}: {ms:.4f} ms/frame = {a.size * a.size / ms / 1e6:.1f} Gpixel/s; "
+          f"host enqueue {host / n * 1e3:.3f} ms/frame (first 3 per stream, unblocked: {first * 1e3:.3f}), issue loop {t_issue / n * 1e3:.3f} ms/frame, wall {wall / n * 1e3:.3f} ms/frame",
+          flush=True)

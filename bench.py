@@ -26,11 +26,13 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# frames in flight live on separate HIP streams; let them map to separate hardware queues
-# 16 contexts + RCCL's stream + the default stream, each on a hardware queue of its own.  Measured in a world of one: an
-# auxiliary stream that lands on a context's queue costs a third of the rate (18 queues: 83 instead of 122 Gpixel/s), and
-# so did the extra stream the per-frame gather used to be issued under with 14 contexts or 22-32 queues; 24 queues: 115.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
+# Frames in flight live on HIP streams of their own, which the runtime deals to GPU_MAX_HW_QUEUES hardware queues.  The loop
+# sits at the knee between two bounds: the transform kernels' instruction issue (capacity) and frames in flight
+# over a frame's time in its stream (latency: 2.5 ms of it is the serial rANS chain).  Round 4 scan on one box
+# (profiles/r04_queue_stream_scan.txt): 16 contexts on 20 queues 133-134 Gpixel/s; 32 contexts on 22 queues 141-143 (on a
+# faster box of the pool 155); 24-48 contexts on 20-28 queues 130-139; 64 queues and more 31-64 (the firmware time-slices
+# hardware queues beyond its slots).  More frames in flight than queues keep every queue's next frame already queued.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "22")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -52,7 +54,7 @@ def parse():
     ap.add_argument("--size", type=int, default=8192, help="frame edge in pixels (per GPU)")
     ap.add_argument("--depth", type=int, default=16, choices=(8, 16))
     ap.add_argument("--kind", default="photo")
-    ap.add_argument("--streams", type=int, default=16, help="frames in flight (one context + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=32, help="frames in flight (one context + HIP stream each)")
     ap.add_argument("--rans-waves", type=int, default=5, choices=(4, 5),
                     help="entropy-stage form, see hydamd_set_rans_waves: 5 = one lane per group, a wavefront per LF group "
                          "(throughput); 4 = one wave per group (lowest single-frame latency)")
@@ -331,6 +333,77 @@ def run_shard(args):
         emit(out)
 
 
+def batch_device_leg(args, frames, contexts=16, rounds=4):
+    """BASELINE configs[4] WITHOUT PCIe: the batch of independent 3840x2160 RGB8 frames already resident in HBM
+    ("synthetic RGB tiles"), frame i on GPU i mod N, each rank's frames round-robined over `contexts` device contexts
+    (hydamd_encode_image: one call per frame), every frame's finished sections left in HBM.  After the clock stops the
+    sections of every frame are hashed and compared with a one-context, one-frame-at-a-time run of the same pictures."""
+    import torch
+    import torch.distributed as dist
+
+    from hydrium_amd import device, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1 and dist.is_initialized()
+    w, h = 3840, 2160
+    distinct = 8
+    imgs = [synth.make_image("photo", w, h, 8, seed=1234 + k, device=torch.device("cuda", local)) for k in range(distinct)]
+    mine = list(range(rank, frames, world))
+    S = max(1, min(contexts, len(mine) or 1))
+    ctxs = [device.DeviceContext(local, 4, 0) for _ in range(S)]
+    for c in ctxs:
+        c.set_rans_waves(5)
+        c.set_lf_coder(2)
+    want = {}
+    for k in range(distinct):  # reference digests: one context, one frame at a time
+        ctxs[0].encode_image_tensor(imgs[k])
+        ctxs[0].sync()
+        want[k] = hashlib.md5(ctxs[0].read_payload()).hexdigest()
+    for c in ctxs:  # every context's buffers touched once
+        c.encode_image_tensor(imgs[0])
+    for c in ctxs:
+        c.sync()
+    dts = []
+    last = {}
+    for _ in range(rounds):
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i, f in enumerate(mine):
+            ctxs[i % S].encode_image_tensor(imgs[f % distinct])
+            last[i % S] = f
+        for c in ctxs:
+            c.sync()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        dts.append(time.perf_counter() - t0)
+    ok = all(hashlib.md5(ctxs[k].read_payload()).hexdigest() == want[f % distinct] for k, f in last.items())
+    for c in ctxs:
+        c.close()
+    if use_dist:
+        tt = torch.tensor(dts, dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dts = [float(x) for x in tt.tolist()]
+    timed = sorted(dts[1:])
+    dt = timed[len(timed) // 2]
+    if rank != 0:
+        return None
+    return {"value": round(frames * w * h / dt / 1e6, 1), "unit": "Mpixel/s", "frames_per_s": round(frames / dt, 1),
+            "ms_per_step": round(dt / frames * 1e3, 4), "n_gpus": world, "steps": frames, "scaling": "strong",
+            "frames_per_s_each_round": [round(frames / x, 1) for x in dts[1:]],
+            "frac_of_hbm_read_roofline": round(frames * w * h * 3 / dt / (HBM_PEAK_GBS * 1e9), 5),
+            "config": {"workload": f"{frames} independent {w}x{h} RGB8 'photo' frames (BASELINE configs[4]) resident in HBM, "
+                                   f"round-robined over {S} device contexts per GPU, frame i on GPU i mod {world}; sections + coded LF streams "
+                                   "of every frame left in HBM (no PCIe in the timed region: the host-pointer form is batch_4k); wall clock "
+                                   "around the whole batch, fill and drain included",
+                       "contexts_per_gpu": S},
+            "sections_identical_to_single_context_run": ok}
+
+
 def batch_leg(args, frames, threads, rounds=4):
     """BASELINE configs[4]: a batch of independent 3840x2160 RGB8 frames through the drop-in API
     (hyd_encoder_new .. hyd_send_tile .. hyd_flush from host memory), frame i on GPU i mod N, several
@@ -580,7 +653,12 @@ def main():
     # moves by several per cent with where it happens to start (round 2: 136-146 at --steps 20, 128-133 at 120 on the
     # same box): at least 2 S frames are timed whatever --steps says, and the rate is reported per frame.
     S = len(ctxs)
-    K = max(args.steps, 2 * S)
+    # at least eight periods of every stream per window (128 frames, ~65 ms), three windows: the contract line is the MEDIAN
+    # window, the spread is reported.  The event timers of hydamd_profile stay OFF in these windows (two event records per
+    # kernel lengthen every frame's stay in its stream: -4 % measured); the co-residency durations under `kernels` come from
+    # a fourth, short, profiled window that is not part of the rate.
+    K = max(args.steps, 8 * S)
+    WINDOWS = 3
 
     def timed_run(K, step=step):
         nprime = 4 * S  # several frame latencies: started together, the contexts take a while to fall into their steady interleaving
@@ -630,14 +708,18 @@ def main():
                 periods.append((mine[-1] - mine[0]) / (len(mine) - 1) / S)
         return dict(dt=(t_end - t_start) * 1e-3, wall=wall, frames=seq, periods=periods)
 
+    windows = [timed_run(K) for _ in range(WINDOWS)]
+    if use_dist:  # every window's time is the slowest rank's
+        t = torch.tensor([[w["dt"], w["wall"]] for w in windows], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        for w, row in zip(windows, t.tolist()):
+            w["dt"], w["wall"] = row
+    run = sorted(windows, key=lambda w: w["dt"])[WINDOWS // 2]
+    dt, wall, total_frames = run["dt"], run["wall"], run["frames"]
+    window_rates = [round(world * W * H * K / w["dt"] / 1e6, 1) for w in windows]
     for c in ctxs:
         c.profile(True)
-    run = timed_run(K)
-    dt, wall, total_frames = run["dt"], run["wall"], run["frames"]
-    if use_dist:
-        t = torch.tensor([dt, wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, wall = float(t[0].item()), float(t[1].item())
+    timed_run(2 * S)
 
     # per-kernel durations from HIP events recorded on the kernels' own streams during the timed region
     kern = {}
@@ -716,8 +798,8 @@ def main():
     if world == 1 and args.lf_coder == "on" and not args.no_legs:
         for c in ctxs:
             c.set_lf_coder(False)
-        r2 = timed_run(2 * S)
-        hf_only = {"Mpixel/s": round(W * H * 2 * S / r2["dt"] / 1e6, 1), "frames": 2 * S,
+        r2 = timed_run(4 * S)
+        hf_only = {"Mpixel/s": round(W * H * 4 * S / r2["dt"] / 1e6, 1), "frames": 4 * S,
                    "note": "same loop and same event-window timing, LF coder off: HF group sections only, LF ints left for a host coder"}
         for c in ctxs:
             c.set_lf_coder(2)
@@ -740,11 +822,11 @@ def main():
                 ptr, n = ctxs[k].export_frame_owned(lfg)  # a view: records only, the sections stay in the context's buffers
                 asms[k].run([ptr], [n], outs_w[k].data_ptr(), outs_w[k].numel(), ext[k].cuda_stream)
 
-        r3 = timed_run(2 * S, step_file)
+        r3 = timed_run(4 * S, step_file)
         sizes = {a.result() for a in asms}
         digest = hashlib.md5(outs_w[0][:asms[0].result()].cpu().numpy()).hexdigest()
-        whole_file = {"Mpixel/s": round(W * H * 2 * S / r3["dt"] / 1e6, 1), "ms_per_step": round(r3["dt"] / (2 * S) * 1e3, 4),
-                      "frames": 2 * S, "file_bytes": sorted(sizes), "md5": digest,
+        whole_file = {"Mpixel/s": round(W * H * 4 * S / r3["dt"] / 1e6, 1), "ms_per_step": round(r3["dt"] / (4 * S) * 1e3, 4),
+                      "frames": 4 * S, "file_bytes": sorted(sizes), "md5": digest,
                       "note": "same loop and timing; each step also runs hydamd_export_frame_owned and the device-side assembler: "
                               "the finished codestream (file header, frame header, TOC, every section) is in HBM when the step ends"}
         for a in asms:
@@ -807,8 +889,11 @@ def main():
             "ms_per_step": round(dt / K * 1e3, 4),
             "timing": {"method": "HIP events at the end of each frame's stream: completion of the last priming frames -> "
                                  "completion of the last timed frames, pipeline primed before and kept full behind; "
-                                 "at least two frames per stream are timed (timed_frames), the rate is per frame",
-                       "timed_frames": K,
+                                 "at least eight frames per stream are timed per window (timed_frames), three windows, the rate is per frame "
+                                 "of the median window; no event timers inside the windows",
+                       "timed_frames": K, "windows": WINDOWS, "Mpixel/s_each_window": window_rates,
+                       "spread_pct": round(100.0 * (max(window_rates) - min(window_rates)) / (sum(window_rates) / len(window_rates)), 2),
+                       "value_is": "the median window",
                        "per_stream_ms_per_step": ({"min": round(min(per_stream), 4), "mean": round(sum(per_stream) / len(per_stream), 4),
                                                    "max": round(max(per_stream), 4)} if per_stream else None),
                        "transform_kernel_alone_ms_over_ms_per_step": round(k1_ms / (dt / K * 1e3), 3) if k1_ms else None,
@@ -836,7 +921,7 @@ def main():
             "valu_roofline": valu,
             "hbm_ceiling_under_exact_arithmetic": ceiling,
             "kernels": kernels,
-            "kernels_note": "per-launch durations in the timed region, where the streams' kernels overlap each other",
+            "kernels_note": "per-launch durations in a separate short profiled window of the same loop, where the streams' kernels overlap each other",
             "exchange": ({"blob_capacity_bytes": xstate["cap"], "host_ms_per_step_issuing_export_and_gather":
                           round(xt[1] / max(total_frames + args.warmup, 1) * 1e3, 4),
                           "frames_per_collective": per,
@@ -882,7 +967,8 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             return shard_leg(args, 40, 4, 16384, assemble=args.assemble)
 
-        for name, fn in (("batch_4k", lambda: batch_leg(args, args.frames, args.threads)), ("shard_16k", shard_16k)):
+        for name, fn in (("batch_4k_device", lambda: batch_device_leg(args, args.frames)),
+                         ("batch_4k", lambda: batch_leg(args, args.frames, args.threads)), ("shard_16k", shard_16k)):
             try:
                 t_leg = time.perf_counter()
                 r = fn()
@@ -897,7 +983,8 @@ def main():
                 continue
             keep = ("value", "unit", "ms_per_step", "frames_per_s", "n_gpus", "steps", "scaling", "config", "frame_bytes", "frame_md5",
                     "frames_checked", "assembled_frames_identical_to_host_assembly", "host_ms_per_frame", "frac_of_hbm_read_roofline",
-                    "frame0_identical_to_reference", "threads_agree_with_single_thread_run", "frames_per_s_each_round", "leg_wall_s", "error")
+                    "frame0_identical_to_reference", "threads_agree_with_single_thread_run", "frames_per_s_each_round", "leg_wall_s", "error",
+                    "sections_identical_to_single_context_run")
             out[name] = {k: r[k] for k in keep if k in r}
         if world == 1 and not args.no_api:
             # API end-to-end through the drop-in hyd_send_tile (host pixels: includes PCIe, read-back, assembly)

@@ -42,7 +42,8 @@ namespace hydk {
 hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, int xmode, uint32_t *status,
                             hipStream_t stream);
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int first_slot,
-                         int num_slots, uint32_t alpha_floor, const uint32_t *alpha_floor_dev, hipStream_t stream);
+                         int num_slots, uint32_t alpha_floor, const uint32_t *alpha_floor_dev, const uint32_t *lf_hist,
+                         HydkLfStream *lf_streams, void *lf_work, hipStream_t stream);
 hipError_t launch_export(const HydkLfJob *d_jobs, const HydkTables *tabs, const uint32_t *group_bits, const HydkLfStream *lf_streams,
                          const uint8_t *payload, const uint64_t *hf_total, const uint8_t *lf_packed,
                          const unsigned long long *lf_total, const uint32_t *status, int num_slots, int lf_coded, uint8_t *dst,
@@ -897,6 +898,7 @@ int hydamd_set_stream(HydAmdContext *ctx, void *hip_stream) {
 
 void *hydamd_get_stream(HydAmdContext *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+
 int hydamd_uses_register_luts(HydAmdContext *ctx) { return ctx && ctx->use_luts < 2; }
 
 int hydamd_xyb_mode(HydAmdContext *ctx) { return ctx ? ctx->use_luts : -1; }
@@ -1445,14 +1447,31 @@ HydAmdAssembler *hydamd_context_assembler(HydAmdContext *ctx) {
     return ctx->assembler;
 }
 
+/* HYDAMD_DEBUG_SKIP (bit mask, measurements only — the frame's bytes are then stale or wrong): leave a stage of the closing
+ * sequence out of the stream: 1 table kernel, 2 rANS chains, 4 section scan + emit, 8 the LF coder's kernels.
+ * scripts/pipe_probe.py uses it to price each stage's share of the pipelined frame rate. */
+static int debug_skip() {
+    static const int v = getenv("HYDAMD_DEBUG_SKIP") ? atoi(getenv("HYDAMD_DEBUG_SKIP")) : 0;
+    return v;
+}
+
 /* K2 + the rANS chains for slots [first, first + count); with_lf_codes: the lane-form launch also builds the
  * LF coder's prefix codes of the same slots (their token kernel must be enqueued already) */
 static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_codes) {
     const size_t G = HYDK_GROUPS_PER_LFG, g0 = (size_t)first * G;
     {
         ScopedTimer timer(ctx, HYDAMD_K_TABLES);
+        /* HYDAMD_LF_CODES_RIDE=rans: the passengers in the chain kernel's launch, as until round 4 (A/B measurements) */
+        if (!(debug_skip() & 1)) {
+        static const bool ride_with_tables = !(getenv("HYDAMD_LF_CODES_RIDE") && !strcmp(getenv("HYDAMD_LF_CODES_RIDE"), "rans"));
+        const bool here = with_lf_codes && ride_with_tables;
         HIP_TRY(ctx, hydk::launch_tables(ctx->hist, ctx->tables, ctx->alpha_max, ctx->nclusters, first, count,
-                                         ctx->alpha_floor, ctx->alpha_floor_dev, ctx->stream));
+                                         ctx->alpha_floor, ctx->alpha_floor_dev,
+                                         here ? ctx->lf_hist + (size_t)first * HYDK_LF_CODES : nullptr, ctx->lf_streams + first,
+                                         ctx->lf_work + (size_t)first * hydk::lf_work_bytes(), ctx->stream));
+        if (here)
+            with_lf_codes = false;
+        }
     }
     {
         ScopedTimer timer(ctx, HYDAMD_K_RANS);
@@ -1463,7 +1482,9 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
         const bool lanes = ctx->rans_lanes && !any_float;
         if (with_lf_codes && !lanes)
             return fail(ctx, ST_INTERNAL_ERROR, "LF code construction can only ride with the lane-form entropy stage");
-        if (lanes) {
+        (void)lanes;
+        if (debug_skip() & 2) {
+        } else if (lanes) {
             HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, ctx->sym_count + g0, ctx->tables + first,
                                                  ctx->rans_aux + g0 * ctx->tok_cap, ctx->rans_flags + g0 * (ctx->tok_cap / 16),
                                                  ctx->tok_cap, ctx->rans_final + g0, ctx->group_bits + g0, ctx->preset_bits,
@@ -1500,7 +1521,8 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
      * group rides in the chain kernel's launch instead of sitting in the stream on its own — tokens before
      * the entropy stage, offsets + pack behind it. */
     int lf_first = -1, lf_count = 0;
-    if (num_slots > ctx->coded && ctx->lf_on_device == 2 && ctx->rans_lanes && ctx->lf_coded == ctx->coded && !ctx->lf_pending) {
+    if (num_slots > ctx->coded && ctx->lf_on_device == 2 && ctx->rans_lanes && ctx->lf_coded == ctx->coded && !ctx->lf_pending &&
+        !(debug_skip() & 8)) {
         bool any_float = false;
         for (int i = ctx->coded; i < num_slots; i++)
             any_float = any_float || ctx->h_jobs[i].fmt == HYDK_FMT_F32;
@@ -1519,7 +1541,7 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
             return st;
         ctx->coded = num_slots;
     }
-    {
+    if (!(debug_skip() & 4)) {
         /* section sizes -> byte offsets, then the sections themselves: lane-form slots write their bits
          * straight into place, wave-form slots copy theirs out of the reversed bit buffers */
         ScopedTimer timer(ctx, HYDAMD_K_PACK);

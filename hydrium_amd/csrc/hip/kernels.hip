@@ -47,6 +47,9 @@ constexpr int kThreads = 256;
 #ifndef HYDK_K1_GATHER_ODD
 #define HYDK_K1_GATHER_ODD 0 /* the same, for the odd pixels of a row only (needs HYDK_K1_ILP >= 2) */
 #endif
+#ifndef HYDK_K1_GATHER_EARLY
+#define HYDK_K1_GATHER_EARLY 0 /* 1: L of every pixel is a gather, all eight issued before M and S are evaluated */
+#endif
 #ifndef HYDK_K1_WAVELOCAL
 #define HYDK_K1_WAVELOCAL 1
 #endif
@@ -531,8 +534,13 @@ __device__ __forceinline__ void store_record(void *tok, uint32_t at, uint32_t to
         ((uint32_t *)tok)[at] = HYDK_REC32(token, cluster, rbits, residue);
 }
 
+#ifdef HYDK_K1_WAVES_EXACT /* register allocation padded so that exactly this many wavefronts fit a SIMD (occupancy experiments) */
+#define HYDK_K1_OCCUPANCY __attribute__((amdgpu_waves_per_eu(HYDK_K1_WAVES_EXACT, HYDK_K1_WAVES_EXACT))) __launch_bounds__(kThreads)
+#else
+#define HYDK_K1_OCCUPANCY __launch_bounds__(kThreads, HYDK_K1_WAVES)
+#endif
 template <int FMT, int XMODE>
-__global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
+__global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
     typedef typename SampleOf<FMT>::type sample_t;
     constexpr bool LUTS = XMODE == kXybGather;
     constexpr int kWords = FMT == HYDK_FMT_U8 ? 6 : 12; /* dwords holding 8 packed RGB pixels */
@@ -687,7 +695,55 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
                 }
                 auto row_to_xyb = [&](auto curve_tag) {
                     constexpr int CURVE = decltype(curve_tag)::value;
-#if HYDK_K1_ILP
+#if HYDK_K1_GATHER_EARLY
+                    if (FMT == HYDK_FMT_U16 && !LUTS) {
+                        /* all eight pixels' table indices first, the gathers of the L values right behind them, then the
+                         * register evaluation of M and S — some 1500 cycles of this wavefront's own work in which the
+                         * gathered values arrive, whatever else loads the memory system */
+                        constexpr int P = 2;
+                        uint32_t idx[24];
+                        float lg[8];
+                        const auto *gl = HYDK_GLOBAL(const float, job.bias_lut);
+#pragma unroll
+                        for (int i0 = 0; i0 < 8; i0 += P) {
+                            uint32_t smp[3 * P], lin[3 * P];
+#pragma unroll
+                            for (int k = 0; k < 3 * P; k++) {
+                                const int si = i0 * 3 + k;
+                                smp[k] = (w[si >> 1] >> (16 * (si & 1))) & 0xFFFF;
+                            }
+                            input_lut16_eval_n<CURVE, 3 * P>(smp, lin);
+#pragma unroll
+                            for (int q = 0; q < P; q++) {
+                                const uint32_t r = lin[3 * q], g = lin[3 * q + 1], b = lin[3 * q + 2];
+                                const uint32_t bb = __umul24(5112u, b);
+                                idx[3 * (i0 + q)] = umad24(19661u, r, umad24(40761u, g, bb)) >> 16;
+                                idx[3 * (i0 + q) + 1] = umad24(15073u, r, umad24(45350u, g, bb)) >> 16;
+                                idx[3 * (i0 + q) + 2] = umad24(15953u, r, umad24(13419u, g, __umul24(36163u, b))) >> 16;
+                                lg[i0 + q] = gl[idx[3 * (i0 + q)]];
+                            }
+                        }
+#pragma unroll
+                        for (int i0 = 0; i0 < 8; i0 += P) {
+                            uint32_t eidx[2 * P];
+                            float eb[2 * P];
+#pragma unroll
+                            for (int q = 0; q < P; q++) {
+                                eidx[2 * q] = idx[3 * (i0 + q) + 1];
+                                eidx[2 * q + 1] = idx[3 * (i0 + q) + 2];
+                            }
+                            bias_lut_eval_n<XMODE, 2 * P>(eidx, eb);
+#pragma unroll
+                            for (int q = 0; q < P; q++) {
+                                const float Y = (lg[i0 + q] + eb[2 * q]) * 0.5f;
+                                yv[i0 + q] = Y;
+                                xv[i0 + q] = Y - eb[2 * q];
+                                bv[i0 + q] = eb[2 * q + 1] - Y;
+                            }
+                        }
+                        return;
+                    }
+#elif HYDK_K1_ILP
                     if (FMT == HYDK_FMT_U16 && !LUTS) {
                         constexpr int P = HYDK_K1_ILP; /* pixels evaluated in lock step */
 #pragma unroll
@@ -1189,14 +1245,28 @@ __global__ __launch_bounds__(kThreads, HYDK_K1_WAVES) void k_transform_tokenize(
     HYDK_PHASE_FLUSH();
 }
 
+#include "lf_huffman.h" /* the LF coder's code construction rides in the table kernel's (or the chain kernel's) launch, see below */
+
 /* ==========================================================================================
  * K2: per-LF-group ANS tables.  grid = LF groups of the frame (send order), block = 256.
+ * With lf_hist != NULL the launch carries num_slots PASSENGER workgroups: workgroup num_slots + s builds the prefix code of
+ * LF group s's coefficient stream (lf_huffman.h: 200 us of one wavefront, which depends only on the LF token histograms
+ * and not on this kernel's tables).  Until round 4 the passengers rode in the chain kernel's launch — where each of them
+ * asked the dispatcher for that kernel's 92 KB of LDS, i.e. for a compute unit with two transform workgroups gone.
  * ======================================================================================== */
 __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_all, HydkTables *tabs,
                                                            const uint32_t *alpha_max_all, int nclusters,
                                                            uint32_t alpha_floor, const uint32_t *alpha_floor_dev,
-                                                           int first_slot) {
+                                                           int first_slot, int num_slots, const uint32_t *lf_hist,
+                                                           HydkLfStream *lf_streams, void *lf_work) {
     HYDK_URGENT();
+    if ((int)blockIdx.x >= num_slots) {
+        __shared__ LfHuffScratch s_huff;
+        const int s = (int)blockIdx.x - num_slots;
+        if (threadIdx.x < 64)
+            lf_huffman_wave(lf_hist + (size_t)s * HYDK_LF_CODES, ((LfWork *)lf_work)[s].codes, lf_streams + s, s_huff, (int)threadIdx.x);
+        return;
+    }
     const unsigned slot = (unsigned)first_slot + blockIdx.x; /* all arrays are indexed by the frame's slot */
     const uint32_t *hist = hist_all + (size_t)slot * HYDK_MAX_CLUSTERS * HYDK_ALPHABET;
     HydkTables *tab = tabs + slot;
@@ -1622,7 +1692,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
  * Integer sample formats only (4-byte records); float frames use k_rans_encode.
  * grid = LF groups, block = 64.
  * ======================================================================================== */
-#include "lf_huffman.h" /* the LF coder's code construction rides in this kernel's launch, see below */
 
 struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs besides the state */
     uint32_t thr;   /* (f << 20) - 1: renormalise when state > thr (entropy.c:1092) */
@@ -2183,10 +2252,13 @@ hipError_t transform_footprint(int fmt, int xmode, int *lds_bytes, int *register
     return e;
 }
 
+/* lf_hist != NULL: the launch also builds the LF coder's prefix codes of the same LF groups (num_slots more workgroups);
+ * lf_hist / lf_streams / lf_work already point at the first of them */
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int first_slot,
-                         int num_slots, uint32_t alpha_floor, const uint32_t *alpha_floor_dev, hipStream_t stream) {
-    hipLaunchKernelGGL(k_build_tables, dim3(num_slots), dim3(kThreads), 0, stream, hist, tabs, alpha_max, nclusters,
-                       alpha_floor, alpha_floor_dev, first_slot);
+                         int num_slots, uint32_t alpha_floor, const uint32_t *alpha_floor_dev, const uint32_t *lf_hist,
+                         HydkLfStream *lf_streams, void *lf_work, hipStream_t stream) {
+    hipLaunchKernelGGL(k_build_tables, dim3(lf_hist ? 2 * num_slots : num_slots), dim3(kThreads), 0, stream, hist, tabs, alpha_max,
+                       nclusters, alpha_floor, alpha_floor_dev, first_slot, num_slots, lf_hist, lf_streams, lf_work);
     return hipGetLastError();
 }
 

@@ -26,12 +26,18 @@ ap.add_argument("--rans", type=int, default=5)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--size", type=int, default=8192)
 ap.add_argument("--no-bind", action="store_true")
+ap.add_argument("--only-transform", action="store_true", help="enqueue the transform stage only (no entropy stage, no LF coder)")
+ap.add_argument("--lanes", type=int, default=0, help="> 0: this many HIP streams, contexts dealt to them in turn (several contexts per stream)")
 a = ap.parse_args()
 if not a.no_bind:
     placement.bind_near_gpu(0)
 img = synth.make_image("photo", a.size, a.size, 16, device=torch.device("cuda", 0))
 lfg = (-(-a.size // 2048)) ** 2
 ctxs = [device.DeviceContext(0, lfg, 0) for _ in range(a.streams)]
+if a.lanes:
+    lanes = [torch.cuda.Stream() for _ in range(a.lanes)]
+    for i, c in enumerate(ctxs):
+        c.set_stream(lanes[i % a.lanes].cuda_stream)
 ext = [torch.cuda.ExternalStream(c.get_stream()) for c in ctxs]
 for c in ctxs:
     c.set_rans_waves(a.rans)
@@ -50,6 +56,10 @@ for rep in range(a.reps):
     first = 0.0
     for i in range(n):
         th = time.perf_counter()
+        if a.only_transform:
+            c = ctxs[i % S]
+            c.per_lf_group_calls = True
+            c.finish_frame = lambda n, c=c: c.run_transform(n)
         ctxs[i % S].encode_image_tensor(img)
         host += time.perf_counter() - th
         if i == 3 * S - 1:
@@ -67,6 +77,6 @@ for rep in range(a.reps):
     t_start = sum(base.elapsed_time(e) for e in evs[4 * S - w:4 * S]) / w
     t_end = sum(base.elapsed_time(e) for e in evs[4 * S + a.frames - w:4 * S + a.frames]) / w
     ms = (t_end - t_start) / a.frames
-    print(f"streams {S} profile {a.profile} lf {a.lf} rans {a.rans}: {ms:.4f} ms/frame = {a.size * a.size / ms / 1e6:.1f} Gpixel/s; "
+    print(f"lanes {a.lanes} streams {S} profile {a.profile} lf {a.lf} rans {a.rans}: {ms:.4f} ms/frame = {a.size * a.size / ms / 1e6:.1f} Gpixel/s; "
           f"host enqueue {host / n * 1e3:.3f} ms/frame (first 3 per stream, unblocked: {first * 1e3:.3f}), issue loop {t_issue / n * 1e3:.3f} ms/frame, wall {wall / n * 1e3:.3f} ms/frame",
           flush=True)

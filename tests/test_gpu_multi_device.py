@@ -1,0 +1,124 @@
+"""GPU: the multi-device tile scheduler INSIDE libhydrium.so.0 (SURVEY 8(e) behind the C boundary).
+
+hyd_send_tile deals a one-frame image's LF groups to the devices HYDAMD_DEVICES names — runs of consecutive tiles, one
+context per device, the running alphabet maximum exchanged by a peer read, the frame assembled on the first shard's GPU
+from every shard's blob read in place (csrc/host/encoder.c finish_frame_multi; reference libhydrium.c:172-203,
+encoder.c:928-957).  A box with one GPU runs the very same code with the device list ALIASED (0,0,0,0: four contexts,
+four streams, every cross-context step taken — only the xGMI hop is missing), which is what these tests do; the device
+list is read once per process, so every case runs in a process of its own.  On more than one physical GPU this path is
+unmeasured (no such box in this environment)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import has_gpu, reference_expected
+from hydrium_amd import build as hbuild
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_ENCODE = r"""
+import hashlib, json, sys
+import numpy as np
+import torch
+from hydrium_amd import api, synth
+from oracle import refprobe
+a = json.loads(sys.argv[1])
+kind, w, h, depth = a["case"]
+if depth == 32:
+    img = synth.make_image_f32(kind, w, h)
+else:                                   # generated on the GPU: a 16384 x 16384 picture takes the CPU most of a minute
+    t = synth.make_image(kind, w, h, depth, device="cuda")
+    torch.cuda.synchronize()
+    img = t.cpu().numpy()
+    img = np.ascontiguousarray(img.view(np.uint16) if depth == 16 else img)
+    del t
+if a.get("nan"):
+    img = img.copy(); img[h // 2, w // 2, 1] = np.nan
+tiles = None
+if a.get("order") == "reversed":
+    ntx, nty = -(-w // 2048), -(-h // 2048)
+    tiles = [(tx, ty) for ty in range(nty) for tx in range(ntx)][::-1]
+try:
+    data = api.encode_image(api.Library(), img, order=tiles)
+    print("OURS", len(data), hashlib.md5(data).hexdigest())
+except api.HydriumError as e:
+    print("OURS ERR", e)
+if a.get("reference"):
+    ref = api.encode_image(refprobe.reference_library(optimised=True), img, order=tiles)
+    print("REF", len(ref), hashlib.md5(ref).hexdigest())
+"""
+
+
+def _run(case, devices, extra_env=None, reference=True, **kw):
+    """-> (our result line, the reference's result line for the same picture, stderr)"""
+    import json
+
+    if reference:
+        assert reference_expected()
+    env = dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="20", HYDAMD_DEVICES=devices, HYDAMD_TRACE="1")
+    env.pop("HYDAMD_DEVICE", None)
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, "-c", _ENCODE, json.dumps(dict(case=list(case), reference=reference, **kw))],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    ours = next(l[5:] for l in lines if l.startswith("OURS "))
+    ref = next((l[4:] for l in lines if l.startswith("REF ")), None)
+    return ours, ref, r.stderr
+
+
+@pytest.mark.parametrize("case,devices", [(("photo", 4296, 4168, 8), "0,0,0,0"), (("photo", 4296, 4168, 8), "0,0"),
+                                          (("photo", 16384, 16384, 8), "0,0,0,0"), (("photo", 8192, 6200, 16), "0,0,0")],
+                         ids=["4296x4168-4dev", "4296x4168-2dev", "16384x16384-4dev", "8192x6200-u16-3dev"])
+def test_frame_dealt_to_an_aliased_device_list_equals_the_reference(case, devices):
+    """the acceptance cases: 4296x4168 (9 LF groups, ragged) and 16384x16384 photo (64 LF groups, configs[3])"""
+    ours, ref, err = _run(case, devices)
+    assert "(shard)" in err, "the multi-device path did not run"
+    assert ours == ref
+
+
+def test_out_of_order_tiles_float_input_and_the_overflow_rerun_across_shards():
+    ours, ref, _ = _run(("photo", 4296, 4168, 8), "0,0,0", order="reversed")
+    assert ours == ref
+    # float samples: growing alphabet from shard to shard (the floor exchange decides log_alphabet_size)
+    ours, ref, _ = _run(("photo", 4100, 4100, 32), "0,0,0,0")
+    assert ours == ref
+    # a shard whose frame outgrows its token arrays reruns it; its blob was stale when the assembler first ran
+    ours, ref, _ = _run(("noise", 4296, 4168, 8), "0,0,0,0", {"HYDAMD_TOKEN_CAP": "40000"})
+    assert ours == ref
+
+
+def test_nan_sample_in_one_shard_is_an_api_error():
+    got, _, _ = _run(("photo", 4100, 4100, 32), "0,0,0,0", nan=True, reference=False)
+    assert got.startswith("ERR") and "NaN" in got
+
+
+def test_small_frames_stay_on_one_device_and_encoders_take_devices_in_turn():
+    """below HYDAMD_SHARD_MIN_LF_GROUPS (8) a frame is not dealt out: 3840x2160 (4 LF groups, configs[4]) runs on one
+    device, and successive encoders take the listed devices in turn"""
+    got, ref, err = _run(("photo", 3840, 2160, 8), "0,0,0,0")
+    assert "(shard)" not in err
+    assert got == ref
+
+
+def test_c_client_unchanged_runs_on_the_device_list(tmp_path):
+    """tests/c/api_client.c, not a line changed, with HYDAMD_DEVICES in its environment"""
+    from oracle import refprobe
+    from test_c_client import _build
+
+    hbuild.build()
+    ours = str(tmp_path / "client_amd")
+    _build(ours, os.path.dirname(hbuild.LIB_PATH), os.path.basename(hbuild.LIB_PATH))
+    env = dict(os.environ, HYDAMD_DEVICES="0,0,0,0", HYDAMD_TRACE="1")
+    env.pop("HYDAMD_DEVICE", None)
+    r = subprocess.run([ours, "6200", "4200"], check=True, capture_output=True, text=True, timeout=600, env=env)
+    assert "(shard)" in r.stderr
+    assert reference_expected()
+    ref_path = refprobe.reference_library().path
+    theirs = str(tmp_path / "client_ref")
+    _build(theirs, os.path.dirname(ref_path), os.path.basename(ref_path))
+    want = subprocess.run([theirs, "6200", "4200"], check=True, capture_output=True, text=True, timeout=600).stdout
+    assert r.stdout == want

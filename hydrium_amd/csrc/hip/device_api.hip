@@ -1461,9 +1461,12 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
     const size_t G = HYDK_GROUPS_PER_LFG, g0 = (size_t)first * G;
     {
         ScopedTimer timer(ctx, HYDAMD_K_TABLES);
-        /* HYDAMD_LF_CODES_RIDE=rans: the passengers in the chain kernel's launch, as until round 4 (A/B measurements) */
+        /* the LF code construction's passengers ride in the chain kernel's launch (2.5 ms long anyway).  HYDAMD_LF_CODES_RIDE=tables
+         * puts them into this launch instead, where they do not ask for the chain kernel's 92 KB of LDS: measured equal in the
+         * pipelined loop (143.5 against 143.3 Gpixel/s) and 0.13 ms worse for one frame alone (the table kernel then lasts
+         * 0.20 instead of 0.07 ms in front of the chains), so it stays an A/B switch */
         if (!(debug_skip() & 1)) {
-        static const bool ride_with_tables = !(getenv("HYDAMD_LF_CODES_RIDE") && !strcmp(getenv("HYDAMD_LF_CODES_RIDE"), "rans"));
+        static const bool ride_with_tables = getenv("HYDAMD_LF_CODES_RIDE") && !strcmp(getenv("HYDAMD_LF_CODES_RIDE"), "tables");
         const bool here = with_lf_codes && ride_with_tables;
         HIP_TRY(ctx, hydk::launch_tables(ctx->hist, ctx->tables, ctx->alpha_max, ctx->nclusters, first, count,
                                          ctx->alpha_floor, ctx->alpha_floor_dev,

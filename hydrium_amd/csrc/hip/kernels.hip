@@ -59,6 +59,9 @@ constexpr int kThreads = 256;
 #ifndef HYDK_K1_SKIP
 #define HYDK_K1_SKIP 0
 #endif
+#ifndef HYDK_K1_PK
+#define HYDK_K1_PK 0 /* 1: the X and Y channels' DCTs as packed f32 operations (two lane-operations per issue slot) */
+#endif
 #ifndef HYDK_K1_ILP
 #define HYDK_K1_ILP 2 /* > 0: pixels of a row whose curves are evaluated in lock step (instruction-level parallelism) */
 #endif
@@ -386,8 +389,12 @@ __device__ __forceinline__ bool lms_mix_f32(float r, float g, float b, int linea
 /* ------------------------------------------------------------------------------------------
  * 8-point DCT in the reference's summation order (encoder.c:639-658)
  * ---------------------------------------------------------------------------------------- */
-__device__ __forceinline__ void dct8(const float (&x)[8], float (&o)[8]) {
-    float dc = x[0];
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+/* T = float, or f32x2: two channels' samples side by side, every operation the same IEEE operation on both halves
+ * (v_pk_mul_f32 / v_pk_add_f32: one issue slot for two lane-operations) */
+template <typename T>
+__device__ __forceinline__ void dct8(const T (&x)[8], T (&o)[8]) {
+    T dc = x[0];
 #pragma unroll
     for (int n = 1; n < 8; n++)
         dc += x[n];
@@ -399,7 +406,7 @@ __device__ __forceinline__ void dct8(const float (&x)[8], float (&o)[8]) {
              * with the rounding of each addition (no intermediate is anywhere near the subnormal range:
              * samples are multiples of 2^-27 or row-pass outputs of such), so the eight products and seven
              * ordered additions collapse to seven ordered additions and one product — same bits */
-            float acc = x[0];
+            T acc = x[0];
 #pragma unroll
             for (int n = 1; n < 8; n++)
                 acc = kDct[3][n] > 0 ? acc + x[n] : acc - x[n];
@@ -408,7 +415,7 @@ __device__ __forceinline__ void dct8(const float (&x)[8], float (&o)[8]) {
         }
         /* the reference starts from +0.0f; 0.0f + p differs from p only in the sign of a zero,
          * which no later stage can observe (every consumer multiplies and truncates to int) */
-        float acc = x[0] * kDct[k - 1][0];
+        T acc = x[0] * kDct[k - 1][0];
 #pragma unroll
         for (int n = 1; n < 8; n++)
             acc += x[n] * kDct[k - 1][n];
@@ -880,6 +887,20 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
             HYDK_PHASE_MARK(0);
             float o[8];
             float *dst = s_rowpass + ab * kS0Block + ar * 8;
+#if HYDK_K1_PK
+            {
+                f32x2 xy[8], oxy[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    xy[k] = f32x2{xv[k], yv[k]};
+                dct8(xy, oxy);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    dst[k] = oxy[k].x;
+                    dst[kS0Chan + k] = oxy[k].y;
+                }
+            }
+#else
             dct8(xv, o);
 #pragma unroll
             for (int k = 0; k < 8; k++)
@@ -888,6 +909,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 dst[kS0Chan + k] = o[k];
+#endif
             dct8(bv, o);
 #pragma unroll
             for (int k = 0; k < 8; k++)
@@ -908,14 +930,34 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
         unsigned long long msk[3] = {0, 0, 0}; /* per channel X, Y, B: non-zero coefficients by zig-zag position */
         int32_t lf_int[3] = {0, 0, 0};
         if (!(HYDK_K1_SKIP & 8) && cb < gbw) {
+#if HYDK_K1_PK
+            f32x2 vxy[8]; /* the X and the Y column transformed side by side */
+            {
+                f32x2 c2[8];
+                const float *s0 = s_rowpass + cb * kS0Block + kh;
+#pragma unroll
+                for (int n = 0; n < 8; n++)
+                    c2[n] = f32x2{s0[n * 8], s0[kS0Chan + n * 8]};
+                dct8(c2, vxy);
+            }
+#endif
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 float col[8], v[8];
                 float *src = s_rowpass + c * kS0Chan + cb * kS0Block + kh;
+#if HYDK_K1_PK
+                if (c < 2) {
+#pragma unroll
+                    for (int kv = 0; kv < 8; kv++)
+                        v[kv] = c == 0 ? vxy[kv].x : vxy[kv].y;
+                } else
+#endif
+                {
 #pragma unroll
                 for (int n = 0; n < 8; n++)
                     col[n] = src[n * 8];
                 dct8(col, v);
+                }
                 /* v[kv] = coefficient with vertical frequency kv, horizontal frequency kh; the
                  * reference leaves it at block row kh, column kv (encoder.c:660-664) */
                 if (job.dbg_dct) {
@@ -1251,8 +1293,8 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
  * K2: per-LF-group ANS tables.  grid = LF groups of the frame (send order), block = 256.
  * With lf_hist != NULL the launch carries num_slots PASSENGER workgroups: workgroup num_slots + s builds the prefix code of
  * LF group s's coefficient stream (lf_huffman.h: 200 us of one wavefront, which depends only on the LF token histograms
- * and not on this kernel's tables).  Until round 4 the passengers rode in the chain kernel's launch — where each of them
- * asked the dispatcher for that kernel's 92 KB of LDS, i.e. for a compute unit with two transform workgroups gone.
+ * and not on this kernel's tables).  An A/B switch (HYDAMD_LF_CODES_RIDE=tables): by default the passengers ride in the
+ * chain kernel's launch, which lasts 2.5 ms anyway.
  * ======================================================================================== */
 __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_all, HydkTables *tabs,
                                                            const uint32_t *alpha_max_all, int nclusters,

@@ -10,11 +10,11 @@ out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 root=$PWD
-python bench.py --steps 20 --warmup 5 > "$out/${tag}_bench_default.json" 2> "$out/bench_default.err"
+python bench.py > "$out/${tag}_bench_default.json" 2> "$out/bench_default.err"
 cd /tmp
 rm -rf /tmp/kt_single /tmp/kt_pipe /tmp/kt_shard /tmp/kt_api
 rocprofv3 --kernel-trace --stats -d /tmp/kt_single -o kt -- python "$root/scripts/one_frame.py" 5 5 2 > /tmp/kt_single.log 2>&1
-rocprofv3 --kernel-trace --stats -d /tmp/kt_pipe -o kt -- python "$root/bench.py" --steps 60 --no-cpu-baseline --no-api --no-legs > /tmp/kt_pipe.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kt_pipe -o kt -- python "$root/bench.py" --steps 256 --no-cpu-baseline --no-api --no-legs > /tmp/kt_pipe.log 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/kt_shard -o kt -- python "$root/bench.py" --mode shard --steps 30 > /tmp/kt_shard.log 2>&1
 rocprofv3 --kernel-trace --memory-copy-trace --stats -d /tmp/kt_api -o kt -- python "$root/scripts/api_frame_times.py" > /tmp/kt_api.log 2>&1
 cd "$root"

@@ -64,7 +64,11 @@ def parse():
                     help="N > 1: bring each frame's sections to rank 0 only (default) or to every rank")
     ap.add_argument("--gather-every", type=int, default=1, help="N > 1: frames whose blobs travel in one RCCL gather")
     ap.add_argument("--exchange", action="store_true",
-                    help="run the multi-GPU exchange path (process group, all-gather per frame) even with one rank")
+                    help="frame mode: also export every frame's results as a blob and gather the blobs with RCCL (one frame per launch "
+                         "group then); without it N ranks code their own frames and only the clock is shared")
+    ap.add_argument("--frames-per-launch", type=int, default=2,
+                    help="frame mode: independent frames coded as ONE launch group per context (hydamd_encode_image_batch): the serial "
+                         "rANS chains of the group run side by side, so a stream is held for one chain's 2.5 ms per group instead of per frame")
     ap.add_argument("--mode", default="frame", choices=("frame", "shard", "batch"),
                     help="frame: one 8192x8192 RGB16 frame per GPU per step (BASELINE configs[2], the contract line); "
                          "shard: ONE 16384x16384 RGB8 frame per step, its LF groups spread over the GPUs (configs[3]); "
@@ -519,7 +523,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or args.exchange  # --exchange: the N > 1 code path in a world of one (self-test on one GPU)
+    exchange = args.exchange  # per-frame blob export + RCCL gather (also in a world of one, as a self-test)
+    use_dist = world > 1 or exchange  # a process group exists: barriers and the slowest rank's clock
+    FPL = 1 if exchange else max(1, args.frames_per_launch)  # frames per launch group (a batch is not exported as one blob)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP extension has no CPU fallback")
     torch.cuda.set_device(local)
@@ -545,7 +551,8 @@ def main():
                            device=torch.device("cuda", local))
     torch.cuda.synchronize()
     lfg = (-(-W // 2048)) * (-(-H // 2048))
-    ctxs = [device.DeviceContext(local, lfg, 0) for _ in range(max(1, args.streams))]
+    ctxs = [device.DeviceContext(local, lfg * FPL, 0) for _ in range(max(1, args.streams))]
+    group = [img] * FPL
     for c in ctxs:
         c.set_rans_waves(args.rans_waves)
         # throughput loop: the LF coder runs at the end of each context's own stream (mode 2), so that
@@ -570,13 +577,17 @@ def main():
     xstate = {"cap": 0, "big": [[None, None] for _ in range(ngroups)], "rows": [None] * ngroups,
               "work": [[None, None] for _ in range(ngroups)]}
     xt = [0.0, 0.0]  # host seconds spent issuing the export + gather
-    xstream = torch.cuda.Stream() if use_dist and per > 1 else None
+    xstream = torch.cuda.Stream() if exchange and per > 1 else None
 
     def step(i):
+        """one launch group (FPL frames) on context i mod S"""
         k = i % len(ctxs)
         ctx = ctxs[k]
-        if not use_dist:
-            ctx.encode_image_tensor(img)
+        if not exchange:
+            if FPL > 1:
+                ctx.encode_image_batch(group)
+            else:
+                ctx.encode_image_tensor(img)
             return ctx
         j = k // per
         half = (i // len(ctxs)) & 1
@@ -616,10 +627,10 @@ def main():
     # initialisation, not measurement: every context codes one frame once so that its freshly
     # allocated buffers have been touched before anything is timed; then the W warm-up steps
     for c in ctxs:
-        c.encode_image_tensor(img)
+        step_init = c.encode_image_batch(group) if FPL > 1 else c.encode_image_tensor(img)
     for c in ctxs:
         c.sync()
-    if use_dist:
+    if exchange:
         # blob size every rank sends: 1.25 x the largest blob of this first frame over all ranks
         probe = torch.zeros(ctxs[0].blob_bound(lfg), dtype=torch.uint8, device=img.device)
         with torch.cuda.stream(ext[0]):
@@ -657,11 +668,18 @@ def main():
     # window, the spread is reported.  The event timers of hydamd_profile stay OFF in these windows (two event records per
     # kernel lengthen every frame's stay in its stream: -4 % measured); the co-residency durations under `kernels` come from
     # a fourth, short, profiled window that is not part of the rate.
-    K = max(args.steps, 8 * S)
+    K = max(args.steps, 8 * S * FPL)   # frames per window
+    K = -(-K // FPL) * FPL              # a whole number of launch groups
+    KG = K // FPL                       # launch groups per window
     WINDOWS = 3
 
-    def timed_run(K, step=step):
-        nprime = 4 * S  # several frame latencies: started together, the contexts take a while to fall into their steady interleaving
+    def timed_run(K, step=step, windows=1, nprime=None):
+        """`windows` consecutive windows of K launch groups each (FPL frames per group for the default `step`), timed by
+        events, in ONE continuous run behind a priming phase.  The GPU's first ~150 ms under this all-VALU load run 10-15 %
+        faster than what follows (clocks settle: the transform kernel alone, back to back on 32 streams, does 216-241
+        Gpixel/s for two chunks of frames and 198-202 for the next seconds: profiles/r04_pipeline_bounds.txt), so the priming
+        phase is 10 launch groups per stream (>= 0.2 s) and what is timed is the sustained rate."""
+        nprime = 10 * S if nprime is None else nprime
         ncool = S
 
         def mark(i):
@@ -674,14 +692,10 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         seq = 0
-        ev_prime, ev_timed = [], []
-        for _ in range(nprime):
+        evs = []
+        for _ in range(nprime + windows * K):
             step(seq)
-            ev_prime.append(mark(seq))
-            seq += 1
-        for _ in range(K):
-            step(seq)
-            ev_timed.append(mark(seq))
+            evs.append(mark(seq))
             seq += 1
         for _ in range(ncool):
             step(seq)
@@ -693,33 +707,36 @@ def main():
         if use_dist:
             dist.barrier()
         wall = time.perf_counter() - t0
-        # all events on one clock: offsets from the first priming frame's completion; the mean completion time of the
-        # last S priming frames and of the last S timed frames — two windows exactly K frames apart
-        base = ev_prime[0]
+        # all events on one clock: offsets from the first priming group's completion; a window boundary is the mean
+        # completion time of the S launch groups in front of it — boundaries exactly K groups apart
+        base = evs[0]
+        done = [base.elapsed_time(e) for e in evs]
         w = min(S, K, nprime)
-        t_start = sum(base.elapsed_time(e) for e in ev_prime[-w:]) / w
-        done = [base.elapsed_time(e) for e in ev_timed]
-        t_end = sum(done[-w:]) / w
-        # every stream's own period inside the interval (it completes one frame per S frame periods)
+        edge = [sum(done[nprime + j * K - w:nprime + j * K]) / w for j in range(windows + 1)]
+        dts = [(edge[j + 1] - edge[j]) * 1e-3 for j in range(windows)]
+        # every stream's own period inside the timed part (it completes one launch group per S group periods)
         periods = []
         for k in range(S):
-            mine = [done[i] for i in range(K) if (nprime + i) % S == k]
+            mine = [done[i] for i in range(nprime, nprime + windows * K) if i % S == k]
             if len(mine) >= 2:
-                periods.append((mine[-1] - mine[0]) / (len(mine) - 1) / S)
-        return dict(dt=(t_end - t_start) * 1e-3, wall=wall, frames=seq, periods=periods)
+                periods.append((mine[-1] - mine[0]) / (len(mine) - 1) / S / FPL)
+        return dict(dt=sorted(dts)[windows // 2], dts=dts, wall=wall, frames=seq, periods=periods)
 
-    windows = [timed_run(K) for _ in range(WINDOWS)]
+    run = timed_run(KG, windows=WINDOWS)
     if use_dist:  # every window's time is the slowest rank's
-        t = torch.tensor([[w["dt"], w["wall"]] for w in windows], dtype=torch.float64, device="cuda")
+        t = torch.tensor(run["dts"] + [run["wall"]], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        for w, row in zip(windows, t.tolist()):
-            w["dt"], w["wall"] = row
-    run = sorted(windows, key=lambda w: w["dt"])[WINDOWS // 2]
-    dt, wall, total_frames = run["dt"], run["wall"], run["frames"]
-    window_rates = [round(world * W * H * K / w["dt"] / 1e6, 1) for w in windows]
+        row = t.tolist()
+        run["dts"], run["wall"] = row[:-1], row[-1]
+        run["dt"] = sorted(run["dts"])[WINDOWS // 2]
+    dt, wall, total_frames = run["dt"], run["wall"], run["frames"] * FPL
+    window_rates = [round(world * W * H * K / x / 1e6, 1) for x in run["dts"]]
+    # the first 100 ms after idle, for the record: a short window right behind a short priming phase (what rounds 1-3 timed)
+    burst = timed_run(2 * S, nprime=2 * S)
     for c in ctxs:
         c.profile(True)
-    timed_run(2 * S)
+    timed_run(2 * S, nprime=2 * S)
+    groups_profiled = FPL
 
     # per-kernel durations from HIP events recorded on the kernels' own streams during the timed region
     kern = {}
@@ -729,27 +746,53 @@ def main():
             a[0] += ms
             a[1] += n
         c.profile(False)
-    payload_bytes = ctxs[0].payload_size()
+    payload_bytes = ctxs[0].payload_size() // FPL
     symbols = sum(int(ctxs[0].read_symbol_counts(s).sum()) for s in range(lfg))
 
-    # what the timed contexts hold, as FILES: the last timed frame of every context — sixteen in flight, lane-form entropy
-    # stage, in-stream LF coder — is exported and put together on the device (hydamd_assembler_*); the files' MD5 is
-    # compared below with the drop-in API's file and with the CPU reference's
+    # What the timed contexts hold.  Every context still holds its last timed launch group — the very launch shape that was
+    # timed (S in flight, FPL frames per group, lane-form entropy stage, in-stream LF coder): each frame's packed HF sections
+    # and coded LF streams are hashed.  The same frame is then coded alone on a context of its own, hashed the same way,
+    # exported and put together on the device (hydamd_assembler_*) into the FILE, whose MD5 is compared below with the
+    # drop-in API's file and with the CPU reference's.
     timed_files = None
     if rank == 0 and args.lf_coder == "on" and W * H > 65536:
+        def frame_digests(c, frames):
+            c.sync()
+            pay = c.read_payload()
+            lfr = c.read_lf_streams(lfg * frames)
+            lfp = c.read_lf_payload()
+            out, off = [], 0
+            for f in range(frames):
+                n = sum(int(((c.read_sections(f * lfg + sl)[0] + 7) // 8).sum()) for sl in range(lfg))
+                h = hashlib.md5(pay[off:off + n])
+                off += n
+                for r in lfr[f * lfg:(f + 1) * lfg]:
+                    o, nb = int(r["offset"]), (int(r["bit_count"]) + 7) // 8
+                    h.update(bytes(r["lengths"]))
+                    h.update(bytes(lfp[o:o + nb]))
+                out.append(h.hexdigest())
+            return out
+
+        held = [d for c in ctxs for d in frame_digests(c, FPL)]
         md = api.HYDImageMetadata(W, H, 0, -1, -1)
-        digests = []
-        with device.Assembler(local) as asm:
+        with device.DeviceContext(local, lfg, 0) as v, device.Assembler(local) as asm:
+            v.set_rans_waves(args.rans_waves)
+            v.set_lf_coder(2)
+            v.encode_image_tensor(img)
+            alone = frame_digests(v, 1)[0]
             asm.plan(md, [list(range(lfg))])
-            out_buf = torch.empty(ctxs[0].blob_bound(lfg) + (1 << 20), dtype=torch.uint8, device=img.device)
-            for k, c in enumerate(ctxs):
-                with torch.cuda.stream(ext[k]):
-                    ptr, cap = c.export_frame_owned(lfg)
-                    asm.run([ptr], [cap], out_buf.data_ptr(), out_buf.numel(), ext[k].cuda_stream)
-                c.sync()
-                digests.append(hashlib.md5(out_buf[:asm.result()].cpu().numpy()).hexdigest())
+            out_buf = torch.empty(v.blob_bound(lfg) + (1 << 20), dtype=torch.uint8, device=img.device)
+            vs = torch.cuda.ExternalStream(v.get_stream())
+            with torch.cuda.stream(vs):
+                ptr, cap = v.export_frame_owned(lfg)
+                asm.run([ptr], [cap], out_buf.data_ptr(), out_buf.numel(), vs.cuda_stream)
+            v.sync()
+            file_md5 = hashlib.md5(out_buf[:asm.result()].cpu().numpy()).hexdigest()
             del out_buf
-        timed_files = {"contexts": len(digests), "all_identical": len(set(digests)) == 1, "md5": digests[0]}
+        timed_files = {"contexts": len(ctxs), "frames_per_launch_group": FPL, "frames_hashed": len(held),
+                       "all_identical": len(set(held)) == 1,
+                       "sections_and_lf_streams_equal_the_frame_coded_alone": set(held) == {alone},
+                       "md5": file_md5, "md5_is": "the frame coded alone, exported and assembled on the device"}
 
     # single-frame latency leg: one stream, one wave per group (the lowest-latency entropy form),
     # each frame synchronised before the next starts; kernels run alone, so these are also the
@@ -799,10 +842,17 @@ def main():
         for c in ctxs:
             c.set_lf_coder(False)
         r2 = timed_run(4 * S)
-        hf_only = {"Mpixel/s": round(W * H * 4 * S / r2["dt"] / 1e6, 1), "frames": 4 * S,
+        hf_only = {"Mpixel/s": round(W * H * 4 * S * FPL / r2["dt"] / 1e6, 1), "frames": 4 * S * FPL,
                    "note": "same loop and same event-window timing, LF coder off: HF group sections only, LF ints left for a host coder"}
         for c in ctxs:
             c.set_lf_coder(2)
+
+    # the same loop with ONE frame per launch group (what rounds 1-3 timed)
+    one_per_group = None
+    if world == 1 and FPL > 1 and not args.no_legs:
+        r1 = timed_run(8 * S, lambda i: ctxs[i % S].encode_image_tensor(img))
+        one_per_group = {"Mpixel/s": round(W * H * 8 * S / r1["dt"] / 1e6, 1), "ms_per_step": round(r1["dt"] / (8 * S) * 1e3, 4), "frames": 8 * S,
+                         "note": "same loop, contexts and timing, hydamd_encode_image: every frame a launch group of its own"}
 
     # and with the frame FINISHED in the loop: every step also exports the context's results and puts the codestream together
     # on the device (hydamd_assembler_*), so that a step ends with the complete .jxl file in HBM instead of its sections
@@ -837,7 +887,7 @@ def main():
     if rank == 0:
         bytes_in = W * H * 3 * (args.depth // 8)
         kernels = {k: {"avg_ms": round(v[0] / max(v[1], 1), 4), "launches": v[1],
-                       "algorithmic_GBs": round(bytes_in / (v[0] / max(v[1], 1) * 1e-3) / 1e9, 1) if v[0] else None}
+                       "algorithmic_GBs": round(bytes_in * groups_profiled / (v[0] / max(v[1], 1) * 1e-3) / 1e9, 1) if v[0] else None}
                    for k, v in kern.items()}
         # dominant kernel = largest share of the timed interval's kernel time; its roofline figure uses
         # the duration measured with the kernel running ALONE (single-frame leg of this same run, same
@@ -889,9 +939,11 @@ def main():
             "ms_per_step": round(dt / K * 1e3, 4),
             "timing": {"method": "HIP events at the end of each frame's stream: completion of the last priming frames -> "
                                  "completion of the last timed frames, pipeline primed before and kept full behind; "
-                                 "at least eight frames per stream are timed per window (timed_frames), three windows, the rate is per frame "
-                                 "of the median window; no event timers inside the windows",
+                                 "one continuous run: ten launch groups per stream of priming (the GPU's first 150 ms under this load run 10-15 % fast), "
+                                 "then three consecutive windows of at least eight launch groups per stream (timed_frames frames each); the rate is "
+                                 "per frame of the median window = the SUSTAINED rate; no event timers inside the windows",
                        "timed_frames": K, "windows": WINDOWS, "Mpixel/s_each_window": window_rates,
+                       "Mpixel/s_first_100ms_after_idle": round(world * W * H * 2 * S * FPL / burst["dt"] / 1e6, 1),
                        "spread_pct": round(100.0 * (max(window_rates) - min(window_rates)) / (sum(window_rates) / len(window_rates)), 2),
                        "value_is": "the median window",
                        "per_stream_ms_per_step": ({"min": round(min(per_stream), 4), "mean": round(sum(per_stream) / len(per_stream), 4),
@@ -905,11 +957,12 @@ def main():
             "config": {"workload": f"{W}x{H} RGB{args.depth} '{args.kind}' frame per GPU (BASELINE configs[2]); "
                                    "hot path device-resident RGB -> packed HF group sections "
                                    "(XYB, DCT, quantise, tokenise, ANS tables, rANS, pack)" +
+                                   (f", {FPL} independent frames per launch group" if FPL > 1 else "") +
                                    (" + prefix-coded LF coefficient streams" if args.lf_coder == "on" else ""),
                        "lf_coder": "gpu, in-stream" if args.lf_coder == "on" else "off",
                        "groups": lfg * 64 if W % 2048 == 0 and H % 2048 == 0 else None, "lf_groups": lfg,
-                       "streams": len(ctxs), "rans_groups_per_workgroup": args.rans_waves, "parallelism": f"{world} x (one frame per GPU)" +
-                                                            (f", one RCCL gather of result blobs per {per} frames, root rotating over the ranks" if use_dist else "")},
+                       "streams": len(ctxs), "frames_per_launch_group": FPL, "rans_groups_per_workgroup": args.rans_waves, "parallelism": f"{world} x (one frame per GPU)" +
+                                                            (f", one RCCL gather of result blobs per {per} frames, root rotating over the ranks" if exchange else ", no collective (independent frames)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_in, "avg_launch_ms": round(dom_ms, 4),
@@ -921,16 +974,17 @@ def main():
             "valu_roofline": valu,
             "hbm_ceiling_under_exact_arithmetic": ceiling,
             "kernels": kernels,
-            "kernels_note": "per-launch durations in a separate short profiled window of the same loop, where the streams' kernels overlap each other",
+            "kernels_note": "per-launch durations (a launch covers frames_per_launch_group frames) in a separate short profiled window of the same loop, where the streams' kernels overlap each other",
             "exchange": ({"blob_capacity_bytes": xstate["cap"], "host_ms_per_step_issuing_export_and_gather":
                           round(xt[1] / max(total_frames + args.warmup, 1) * 1e3, 4),
                           "frames_per_collective": per,
                           "note": "one hydamd_export_frame kernel per frame, one asynchronous RCCL gather per group of frames, no host synchronisation"}
-                         if use_dist else None),
+                         if exchange else None),
             "timed_contexts_as_files": timed_files,
             "single_frame": lat,
             "single_frame_form5": lat5,
             "hf_sections_only": hf_only,
+            "one_frame_per_launch_group": one_per_group,
             "finished_file_per_step": whole_file,
             "symbols_per_pixel": round(symbols / (W * H), 4),
             "section_bytes": payload_bytes,

@@ -43,7 +43,7 @@ hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt
                             hipStream_t stream);
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int first_slot,
                          int num_slots, uint32_t alpha_floor, const uint32_t *alpha_floor_dev, const uint32_t *lf_hist,
-                         HydkLfStream *lf_streams, void *lf_work, hipStream_t stream);
+                         HydkLfStream *lf_streams, void *lf_work, int slots_per_frame, hipStream_t stream);
 hipError_t launch_export(const HydkLfJob *d_jobs, const HydkTables *tabs, const uint32_t *group_bits, const HydkLfStream *lf_streams,
                          const uint8_t *payload, const uint64_t *hf_total, const uint8_t *lf_packed,
                          const unsigned long long *lf_total, const uint32_t *status, int num_slots, int lf_coded, uint8_t *dst,
@@ -199,6 +199,7 @@ struct HydAmdContext {
     uint64_t h_total = 0;
     uint32_t h_status = 0;
     int slots_finished = 0;
+    int slots_per_frame = 0; /* > 0: the slots hold a batch of independent frames of this many LF groups each (hydamd_begin_batch) */
     bool results_valid = false;
     uint32_t *accum = nullptr;       /* [hist | alpha_max | status | lf_hist]: cleared once per frame by k_frame_begin */
     size_t accum_words = 0;
@@ -962,6 +963,7 @@ int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
     ctx->preset_bits = bits; /* hyd_cllog2(num_presets), encoder.c:940 */
     ctx->results_valid = false;
     ctx->slots_finished = 0;
+    ctx->slots_per_frame = 0;
     ctx->transformed = ctx->coded = ctx->lf_coded = 0;
     ctx->want_transform = ctx->want_entropy = 0;
     ctx->host_staged = 0;
@@ -1065,6 +1067,54 @@ int hydamd_encode_image(HydAmdContext *ctx, const void *const src[3], ptrdiff_t 
         }
     if (st == ST_OK)
         st = hydamd_finish_frame(ctx, (int)(lfx * lfy));
+    return st;
+}
+
+/* A BATCH of independent frames of one shape as one launch group: frame k occupies slots k * num_presets ... (preset ids
+ * restart with every frame, and so does the running alphabet maximum of the table kernel), every kernel of the closing
+ * stage covers all of them.  The serial rANS chains of the frames then run side by side: a stream is held for one chain's
+ * 2.5 ms per BATCH instead of per frame — the lever on the frame rate of a queue of frames.  The sections of
+ * frame k follow those of frame k - 1 in the payload (hydamd_read_sections per slot), likewise the packed LF streams. */
+int hydamd_begin_batch(HydAmdContext *ctx, unsigned num_presets, int frames) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (frames < 1 || (size_t)frames * num_presets > (size_t)ctx->max_slots)
+        return fail(ctx, ST_API_ERROR, "the context has too few LF-group slots for this batch");
+    const int st = hydamd_begin_frame(ctx, num_presets);
+    if (st == ST_OK && frames > 1)
+        ctx->slots_per_frame = (int)num_presets;
+    return st;
+}
+
+int hydamd_encode_image_batch(HydAmdContext *ctx, int frames, const void *const *src /* [frames][3] */, ptrdiff_t row_stride,
+                              ptrdiff_t pixel_stride, int sample_fmt, size_t width, size_t height) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (!src || frames < 1)
+        return fail(ctx, ST_API_ERROR, "null pixel pointer");
+    if (width == 0 || height == 0)
+        return fail(ctx, ST_API_ERROR, "empty image");
+    if (sample_fmt != HYDK_FMT_U8 && sample_fmt != HYDK_FMT_U16 && sample_fmt != HYDK_FMT_F32)
+        return fail(ctx, ST_API_ERROR, "Invalid Sample Format");
+    const size_t lfx = (width + 2047) >> 11, lfy = (height + 2047) >> 11, n = lfx * lfy;
+    int st = hydamd_begin_batch(ctx, (unsigned)n, frames);
+    const ptrdiff_t ss = (ptrdiff_t)sample_size(sample_fmt);
+    for (int f = 0; f < frames && st == ST_OK; f++) {
+        const void *const *s3 = src + 3 * (size_t)f;
+        if (!s3[0] || !s3[1] || !s3[2])
+            return fail(ctx, ST_API_ERROR, "null pixel pointer");
+        for (size_t ty = 0; ty < lfy && st == ST_OK; ty++)
+            for (size_t tx = 0; tx < lfx && st == ST_OK; tx++) {
+                const ptrdiff_t off = ((ptrdiff_t)(ty * 2048) * row_stride + (ptrdiff_t)(tx * 2048) * pixel_stride) * ss;
+                const void *p[3] = {(const char *)s3[0] + off, (const char *)s3[1] + off, (const char *)s3[2] + off};
+                const size_t w = width - tx * 2048 < 2048 ? width - tx * 2048 : 2048;
+                const size_t h = height - ty * 2048 < 2048 ? height - ty * 2048 : 2048;
+                st = hydamd_encode_lf_group(ctx, (int)((size_t)f * n + ty * lfx + tx), p, row_stride, pixel_stride, sample_fmt, w, h,
+                                            (unsigned)(ty * lfx + tx));
+            }
+    }
+    if (st == ST_OK)
+        st = hydamd_finish_frame(ctx, (int)((size_t)frames * n));
     return st;
 }
 
@@ -1392,6 +1442,8 @@ static int export_frame(HydAmdContext *ctx, int num_slots, void *device_dst, siz
         return ST_API_ERROR;
     if (num_slots < 1 || num_slots > ctx->coded || num_slots != ctx->slots_finished)
         return fail(ctx, ST_API_ERROR, "export needs the entropy stage of the same slots enqueued first");
+    if (ctx->slots_per_frame)
+        return fail(ctx, ST_API_ERROR, "a batch of frames is not exported as one blob: its sections and LF streams stay in the context's buffers");
     if (ctx->lf_on_device && (ctx->lf_need_gather || ctx->lf_slots != num_slots))
         return fail(ctx, ST_API_ERROR, "export needs the frame's LF streams packed (hydamd_run_entropy does it)");
     if (capacity < sizeof(HydAmdBlobHeader))
@@ -1471,7 +1523,7 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
         HIP_TRY(ctx, hydk::launch_tables(ctx->hist, ctx->tables, ctx->alpha_max, ctx->nclusters, first, count,
                                          ctx->alpha_floor, ctx->alpha_floor_dev,
                                          here ? ctx->lf_hist + (size_t)first * HYDK_LF_CODES : nullptr, ctx->lf_streams + first,
-                                         ctx->lf_work + (size_t)first * hydk::lf_work_bytes(), ctx->stream));
+                                         ctx->lf_work + (size_t)first * hydk::lf_work_bytes(), ctx->slots_per_frame, ctx->stream));
         if (here)
             with_lf_codes = false;
         }

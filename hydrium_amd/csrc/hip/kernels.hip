@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
                                                            const uint32_t *alpha_max_all, int nclusters,
                                                            uint32_t alpha_floor, const uint32_t *alpha_floor_dev,
                                                            int first_slot, int num_slots, const uint32_t *lf_hist,
-                                                           HydkLfStream *lf_streams, void *lf_work) {
+                                                           HydkLfStream *lf_streams, void *lf_work, int slots_per_frame) {
     HYDK_URGENT();
     if ((int)blockIdx.x >= num_slots) {
         __shared__ LfHuffScratch s_huff;
@@ -1349,7 +1349,10 @@ __global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_
         uint32_t mx = alpha_floor; /* maximum over the LF groups other GPUs coded before ours */
         if (alpha_floor_dev)       /* ... when it was exchanged on the device (no host round trip) */
             mx = max(mx, *alpha_floor_dev);
-        for (unsigned sl = 0; sl <= slot; sl++)
+        /* a context that codes a BATCH of independent frames in one launch group (hydamd_begin_batch) holds frame k in slots
+         * k * slots_per_frame ...: the maximum starts afresh with every frame */
+        const unsigned frame_first = slots_per_frame > 0 ? slot - slot % (unsigned)slots_per_frame : 0u;
+        for (unsigned sl = frame_first; sl <= slot; sl++)
             mx = max(mx, alpha_max_all[sl]);
         uint32_t lg = mx > 1 ? 32 - __clz((int)(mx - 1)) : 0; /* ceil(log2(mx)) */
         s_log_alpha = max(lg, 5u);
@@ -2298,9 +2301,9 @@ hipError_t transform_footprint(int fmt, int xmode, int *lds_bytes, int *register
  * lf_hist / lf_streams / lf_work already point at the first of them */
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int first_slot,
                          int num_slots, uint32_t alpha_floor, const uint32_t *alpha_floor_dev, const uint32_t *lf_hist,
-                         HydkLfStream *lf_streams, void *lf_work, hipStream_t stream) {
+                         HydkLfStream *lf_streams, void *lf_work, int slots_per_frame, hipStream_t stream) {
     hipLaunchKernelGGL(k_build_tables, dim3(lf_hist ? 2 * num_slots : num_slots), dim3(kThreads), 0, stream, hist, tabs, alpha_max,
-                       nclusters, alpha_floor, alpha_floor_dev, first_slot, num_slots, lf_hist, lf_streams, lf_work);
+                       nclusters, alpha_floor, alpha_floor_dev, first_slot, num_slots, lf_hist, lf_streams, lf_work, slots_per_frame);
     return hipGetLastError();
 }
 

@@ -66,6 +66,8 @@ def dll(path: Optional[str] = None):
         d.hydamd_encode_lf_group.argtypes = lf_args
         d.hydamd_encode_lf_group_host.argtypes = lf_args
         d.hydamd_encode_image.argtypes = [vp, C.POINTER(vp), C.c_ssize_t, C.c_ssize_t, i, sz, sz]
+        d.hydamd_encode_image_batch.argtypes = [vp, i, C.POINTER(vp), C.c_ssize_t, C.c_ssize_t, i, sz, sz]
+        d.hydamd_begin_batch.argtypes = [vp, u, i]
         d.hydamd_finish_frame.argtypes = [vp, i]
         d.hydamd_run_transform.argtypes = [vp, i]
         d.hydamd_run_entropy.argtypes = [vp, i]
@@ -272,6 +274,24 @@ class DeviceContext:
                                      min(2048, w - x0), min(2048, h - y0), ty * lfx + tx)
         self.finish_frame(n)
         return n
+
+    def encode_image_batch(self, imgs):
+        """Enqueue a batch of interleaved (H, W, 3) torch CUDA tensors of one shape as one launch group
+        (hydamd_encode_image_batch): frame k in slots k * n ... (k + 1) * n - 1."""
+        h, w, _ = imgs[0].shape
+        isz = imgs[0].element_size()
+        fmt = {1: 0, 2: 1, 4: 2}[isz]
+        n = (-(-w // 2048)) * (-(-h // 2048))
+        if n * len(imgs) > self.max_lf_groups:
+            raise ValueError("context has too few LF-group slots for this batch")
+        ptrs = []
+        for t in imgs:
+            assert t.shape == imgs[0].shape and t.element_size() == isz
+            b = t.data_ptr()
+            ptrs += [b, b + isz, b + 2 * isz]
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        self._ck(self.d.hydamd_encode_image_batch(self.h, len(imgs), arr, 3 * w, 3, fmt, w, h))
+        return n * len(imgs)
 
     def encode_image_host(self, img: np.ndarray):
         """Same from a host numpy image, through the pinned staging path."""

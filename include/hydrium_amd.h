@@ -111,6 +111,17 @@ HYDAMD_EXPORT int hydamd_encode_lf_group(HydAmdContext *ctx, int slot, const voi
 HYDAMD_EXPORT int hydamd_encode_image(HydAmdContext *ctx, const void *const src[3], ptrdiff_t row_stride,
                                       ptrdiff_t pixel_stride, int sample_fmt, size_t width, size_t height);
 
+/* A BATCH of `frames` independent images of one shape as ONE launch group (for a queue of frames: the serial rANS chains
+ * of the batch run side by side, so a stream is held for one chain's duration per batch instead of per frame; bench.py
+ * codes two 8192x8192 frames per group).  hydamd_begin_batch = hydamd_begin_frame with frame k in slots k * num_presets ...
+ * (k + 1) * num_presets - 1, presets 0 .. num_presets - 1 in each; hydamd_encode_image_batch = hydamd_encode_image for
+ * src[3 k .. 3 k + 2] of every frame, then hydamd_finish_frame over all slots.  Results per slot as usual
+ * (hydamd_read_sections, hydamd_read_tables, hydamd_read_lf_streams); frame k's sections follow frame k - 1's in the
+ * payload.  A batch is not exported as a blob (hydamd_export_frame*: HYD_API_ERROR): code one frame per context for that. */
+HYDAMD_EXPORT int hydamd_begin_batch(HydAmdContext *ctx, unsigned num_presets, int frames);
+HYDAMD_EXPORT int hydamd_encode_image_batch(HydAmdContext *ctx, int frames, const void *const *src, ptrdiff_t row_stride,
+                                            ptrdiff_t pixel_stride, int sample_fmt, size_t width, size_t height);
+
 /* Same, from HOST pointers: the samples are gathered into pinned staging (the caller's buffers may
  * be reused as soon as this returns, as after hyd_send_tile) and copied to the GPU on the stream. */
 HYDAMD_EXPORT int hydamd_encode_lf_group_host(HydAmdContext *ctx, int slot, const void *const src[3],

@@ -25,15 +25,21 @@ ap.add_argument("--lf", type=int, default=2)
 ap.add_argument("--rans", type=int, default=5)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--size", type=int, default=8192)
+ap.add_argument("--height", type=int, default=0, help="frame height if not square: a frame of k x 8192 rows stands for k frames coded as one launch group")
 ap.add_argument("--no-bind", action="store_true")
 ap.add_argument("--only-transform", action="store_true", help="enqueue the transform stage only (no entropy stage, no LF coder)")
+ap.add_argument("--batch", type=int, default=1, help="frames per launch group (hydamd_encode_image_batch)")
 ap.add_argument("--lanes", type=int, default=0, help="> 0: this many HIP streams, contexts dealt to them in turn (several contexts per stream)")
 a = ap.parse_args()
 if not a.no_bind:
     placement.bind_near_gpu(0)
-img = synth.make_image("photo", a.size, a.size, 16, device=torch.device("cuda", 0))
-lfg = (-(-a.size // 2048)) ** 2
-ctxs = [device.DeviceContext(0, lfg, 0) for _ in range(a.streams)]
+H = a.height or a.size
+img = synth.make_image("photo", a.size, H, 16, device=torch.device("cuda", 0))
+lfg = (-(-a.size // 2048)) * (-(-H // 2048))
+ctxs = [device.DeviceContext(0, lfg * a.batch, 0) for _ in range(a.streams)]
+if a.batch > 1:
+    for c in ctxs:
+        c.encode_image_tensor = lambda im, c=c: c.encode_image_batch([im] * a.batch)
 if a.lanes:
     lanes = [torch.cuda.Stream() for _ in range(a.lanes)]
     for i, c in enumerate(ctxs):
@@ -76,7 +82,17 @@ for rep in range(a.reps):
     base = evs[0]
     t_start = sum(base.elapsed_time(e) for e in evs[4 * S - w:4 * S]) / w
     t_end = sum(base.elapsed_time(e) for e in evs[4 * S + a.frames - w:4 * S + a.frames]) / w
-    ms = (t_end - t_start) / a.frames
-    print(f"lanes {a.lanes} streams {S} profile {a.profile} lf {a.lf} rans {a.rans}: {ms:.4f} ms/frame = {a.size * a.size / ms / 1e6:.1f} Gpixel/s; "
+    ms = (t_end - t_start) / a.frames / a.batch
+    # the rate over time: completion times of successive chunks of 2 S launch groups
+    done = [base.elapsed_time(e) for e in evs]
+    chunk = 2 * S
+    marks = [sum(done[k - w:k]) / w for k in range(4 * S, len(done) + 1, chunk)]
+    trend = " ".join(f"{a.size * H * a.batch * chunk / (marks[j + 1] - marks[j]) / 1e6:.0f}" for j in range(len(marks) - 1))
+    print(f"   Gpixel/s in successive chunks of {chunk} launch groups: {trend}", flush=True)
+    vals = [a.size * H * a.batch * chunk / (marks[j + 1] - marks[j]) / 1e6 for j in range(len(marks) - 1)]
+    if len(vals) >= 8:
+        mid = sorted(vals[3:-2])
+        print(f"   SUSTAINED (median chunk, first three and last two left out): {mid[len(mid) // 2]:.1f} Gpixel/s", flush=True)
+    print(f"batch {a.batch} lanes {a.lanes} streams {S} profile {a.profile} lf {a.lf} rans {a.rans}: {ms:.4f} ms/frame = {a.size * H / ms / 1e6:.1f} Gpixel/s; "
           f"host enqueue {host / n * 1e3:.3f} ms/frame (first 3 per stream, unblocked: {first * 1e3:.3f}), issue loop {t_issue / n * 1e3:.3f} ms/frame, wall {wall / n * 1e3:.3f} ms/frame",
           flush=True)

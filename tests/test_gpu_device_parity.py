@@ -251,3 +251,49 @@ def test_transform_kernel_keeps_its_place_beside_the_entropy_stage():
             lds, regs = ctx.transform_footprint(fmt)
             assert 0 < lds <= 26 * 1280, (fmt, lds)
             assert 0 < regs <= 128, (fmt, regs)
+
+
+def test_batch_of_frames_as_one_launch_group(image):
+    """hydamd_encode_image_batch: three different pictures of one shape (two LF groups each, ragged) coded as ONE launch
+    group — frame k in slots 2k, 2k + 1, presets and the running alphabet maximum restarting with every frame — leave
+    exactly the tables, sections and coded LF streams each picture leaves when a context codes it alone (which the other
+    tests of this module tie to the oracle and the API tests to the reference)."""
+    from hydrium_amd import device
+
+    pics = [_torch_image(image(kind, 2300, 1500, depth, seed=700 + k)) for k, (kind, depth) in
+            enumerate([("photo", 8), ("noise", 8), ("smooth", 8)])]
+    alone = []
+    with device.DeviceContext(0, 2, 0) as ctx:
+        ctx.set_rans_waves(5)
+        ctx.set_lf_coder(2)
+        for t in pics:
+            ctx.encode_image_tensor(t)
+            ctx.sync()
+            lf = ctx.read_lf_streams(2)
+            lfp = ctx.read_lf_payload()
+            alone.append(dict(payload=ctx.read_payload(), tables=[ctx.read_tables(s) for s in range(2)],
+                              sections=[ctx.read_sections(s)[0] for s in range(2)],
+                              lf=[(int(r["bit_count"]), bytes(r["lengths"]), bytes(lfp[int(r["offset"]):int(r["offset"]) + (int(r["bit_count"]) + 7) // 8])) for r in lf]))
+    with device.DeviceContext(0, 6, 0) as ctx:
+        ctx.set_rans_waves(5)
+        ctx.set_lf_coder(2)
+        for rep in range(2):  # twice: the context's buffers are reused from batch to batch
+            assert ctx.encode_image_batch(pics) == 6
+            ctx.sync()
+            assert ctx.read_payload() == b"".join(a["payload"] for a in alone)
+            lf = ctx.read_lf_streams(6)
+            lfp = ctx.read_lf_payload()
+            for k, a in enumerate(alone):
+                for s in range(2):
+                    f, al, la, rm = ctx.read_tables(2 * k + s)
+                    f0, al0, la0, rm0 = a["tables"][s]
+                    assert np.array_equal(f, f0) and np.array_equal(al, al0) and (la, rm) == (la0, rm0), (k, s)
+                    assert np.array_equal(ctx.read_sections(2 * k + s)[0], a["sections"][s])
+                    r = lf[2 * k + s]
+                    got = (int(r["bit_count"]), bytes(r["lengths"]), bytes(lfp[int(r["offset"]):int(r["offset"]) + (int(r["bit_count"]) + 7) // 8]))
+                    assert got == a["lf"][s], (k, s)
+        with pytest.raises(device.DeviceError):
+            ctx.export_frame_owned(6)  # a batch is not one frame's blob
+        ctx.encode_image_tensor(pics[0])  # and the context codes single frames again afterwards
+        ctx.sync()
+        assert ctx.read_payload() == alone[0]["payload"]

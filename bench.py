@@ -944,6 +944,8 @@ def main():
                                  "per frame of the median window = the SUSTAINED rate; no event timers inside the windows",
                        "timed_frames": K, "windows": WINDOWS, "Mpixel/s_each_window": window_rates,
                        "Mpixel/s_first_100ms_after_idle": round(world * W * H * 2 * S * FPL / burst["dt"] / 1e6, 1),
+                       "first_100ms_note": "a window of two launch groups per stream right behind two of priming, from an idle GPU: the method of "
+                                           "rounds 1-3 (round 3's driver line, 136.9 Gpixel/s, was measured this way); `value` is the sustained rate",
                        "spread_pct": round(100.0 * (max(window_rates) - min(window_rates)) / (sum(window_rates) / len(window_rates)), 2),
                        "value_is": "the median window",
                        "per_stream_ms_per_step": ({"min": round(min(per_stream), 4), "mean": round(sum(per_stream) / len(per_stream), 4),

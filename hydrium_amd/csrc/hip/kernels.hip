@@ -36,34 +36,27 @@ constexpr int kThreads = 256;
 #ifndef HYDK_K1_WAVES
 #define HYDK_K1_WAVES 4 /* waves per SIMD the transform kernel is compiled for (register budget 512 / this) */
 #endif
-/* Build-time variants of the transform kernel, for A/B measurements (scripts/k1_variants.py); the defaults are the
- * product.  HYDK_K1_GATHER: bit i set = LUT i of a pixel is a gather from the uploaded table instead of a register
- * evaluation (0-2 transfer curve of R, G, B; 3-5 bias curve of L, M, S); HYDK_K1_WAVELOCAL: a wavefront row-transforms
- * exactly the eight blocks whose columns it transforms next, so no workgroup barrier separates the two;
- * HYDK_K1_TOK: form of the token walk; HYDK_K1_SKIP: timing-only builds that leave a stage out (wrong bytes). */
+/* Build-time variants of the transform kernel, for A/B measurements (scripts/k1_variants.py; results in
+ * profiles/r04_k1_variants.txt and DESIGN.md 3, 9); the defaults are the product.
+ *   HYDK_K1_GATHER     bit i set = LUT i of a pixel is a gather from the uploaded table instead of a register evaluation
+ *                      (0-2 transfer curve of R, G, B; 3-5 bias curve of L, M, S): one bias gather takes 7 % off the kernel
+ *                      alone and nothing off the pipelined loop, more gathers cost more than they save
+ *   HYDK_K1_ILP        pixels of a row whose curves are evaluated in lock step (0: one value at a time, as until round 3)
+ *   HYDK_K1_WAVELOCAL  a wavefront row-transforms exactly the eight blocks whose columns it transforms next, so no
+ *                      workgroup barrier separates the two phases
+ *   HYDK_K1_SKIP       timing-only builds that leave a stage out (wrong bytes): 1 token walk, 2 curves, 4 bitmaps, 8 column pass
+ *   HYDK_K1_PADLDS / HYDK_K1_WAVES_EXACT   occupancy experiments: extra LDS per workgroup / exactly n wavefronts per SIMD */
 #ifndef HYDK_K1_GATHER
 #define HYDK_K1_GATHER 0
-#endif
-#ifndef HYDK_K1_GATHER_ODD
-#define HYDK_K1_GATHER_ODD 0 /* the same, for the odd pixels of a row only (needs HYDK_K1_ILP >= 2) */
-#endif
-#ifndef HYDK_K1_GATHER_EARLY
-#define HYDK_K1_GATHER_EARLY 0 /* 1: L of every pixel is a gather, all eight issued before M and S are evaluated */
 #endif
 #ifndef HYDK_K1_WAVELOCAL
 #define HYDK_K1_WAVELOCAL 1
 #endif
-#ifndef HYDK_K1_TOK
-#define HYDK_K1_TOK 7 /* 1: hybrid-uint split through the float conversion; 2: every token straight into the LDS histogram; 4: global_* instead of flat_* memory instructions; 8: the pipelined walk over zig-zag-ordered coefficients */
-#endif
 #ifndef HYDK_K1_SKIP
 #define HYDK_K1_SKIP 0
 #endif
-#ifndef HYDK_K1_PK
-#define HYDK_K1_PK 0 /* 1: the X and Y channels' DCTs as packed f32 operations (two lane-operations per issue slot) */
-#endif
 #ifndef HYDK_K1_ILP
-#define HYDK_K1_ILP 2 /* > 0: pixels of a row whose curves are evaluated in lock step (instruction-level parallelism) */
+#define HYDK_K1_ILP 2
 #endif
 constexpr int kS0Block = 72;            /* floats per block in the row-pass buffer: 64 + 8 pad -> conflict-free column reads */
 constexpr int kS0Chan = 32 * kS0Block;  /* floats per channel */
@@ -389,12 +382,8 @@ __device__ __forceinline__ bool lms_mix_f32(float r, float g, float b, int linea
 /* ------------------------------------------------------------------------------------------
  * 8-point DCT in the reference's summation order (encoder.c:639-658)
  * ---------------------------------------------------------------------------------------- */
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-/* T = float, or f32x2: two channels' samples side by side, every operation the same IEEE operation on both halves
- * (v_pk_mul_f32 / v_pk_add_f32: one issue slot for two lane-operations) */
-template <typename T>
-__device__ __forceinline__ void dct8(const T (&x)[8], T (&o)[8]) {
-    T dc = x[0];
+__device__ __forceinline__ void dct8(const float (&x)[8], float (&o)[8]) {
+    float dc = x[0];
 #pragma unroll
     for (int n = 1; n < 8; n++)
         dc += x[n];
@@ -406,7 +395,7 @@ __device__ __forceinline__ void dct8(const T (&x)[8], T (&o)[8]) {
              * with the rounding of each addition (no intermediate is anywhere near the subnormal range:
              * samples are multiples of 2^-27 or row-pass outputs of such), so the eight products and seven
              * ordered additions collapse to seven ordered additions and one product — same bits */
-            T acc = x[0];
+            float acc = x[0];
 #pragma unroll
             for (int n = 1; n < 8; n++)
                 acc = kDct[3][n] > 0 ? acc + x[n] : acc - x[n];
@@ -415,7 +404,7 @@ __device__ __forceinline__ void dct8(const T (&x)[8], T (&o)[8]) {
         }
         /* the reference starts from +0.0f; 0.0f + p differs from p only in the sign of a zero,
          * which no later stage can observe (every consumer multiplies and truncates to int) */
-        T acc = x[0] * kDct[k - 1][0];
+        float acc = x[0] * kDct[k - 1][0];
 #pragma unroll
         for (int n = 1; n < 8; n++)
             acc += x[n] * kDct[k - 1][n];
@@ -529,16 +518,13 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
  * bias LUT's range and the scaled DCT has unit gain), so token < 64, residue < 2^13 and one record fits
  * 32 bits: token | cluster << 7 | residue bit count << 11 | residue << 16.  Float input has no such
  * bound and keeps the 8-byte record: lo = token | cluster << 8 | bit count << 16, hi = residue. */
-constexpr bool kK1GlobalMem = (HYDK_K1_TOK & 4) != 0;
 template <int FMT>
 __device__ __forceinline__ void store_record(void *tok, uint32_t at, uint32_t token, uint32_t cluster, uint32_t rbits,
                                              uint32_t residue) {
     if (FMT == HYDK_FMT_F32)
         ((uint64_t *)tok)[at] = ((uint64_t)residue << 32) | HYDK_REC_LO(token, cluster, rbits);
-    else if (kK1GlobalMem)
-        HYDK_GLOBAL(uint32_t, tok)[at] = HYDK_REC32(token, cluster, rbits, residue);
     else
-        ((uint32_t *)tok)[at] = HYDK_REC32(token, cluster, rbits, residue);
+        HYDK_GLOBAL(uint32_t, tok)[at] = HYDK_REC32(token, cluster, rbits, residue);
 }
 
 #ifdef HYDK_K1_WAVES_EXACT /* register allocation padded so that exactly this many wavefronts fit a SIMD (occupancy experiments) */
@@ -619,16 +605,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
 
     /* column / token phases: thread (block cb, horizontal frequency kh) */
     const int cb = t >> 3, kh = t & 7;
-#if HYDK_K1_TOK & 8
-    /* the quantised coefficients go back into the block's 64 words in ZIG-ZAG order (this thread's eight land at
-     * kZigzag[kv][kh]): the token walk then reads position j at word j, no index table on its address path.  In place
-     * is safe: a block's eight threads are neighbours in one wavefront, whose LDS operations execute in order — every
-     * lane's column reads of a channel are done before any lane's stores of that channel. */
-    uint32_t zz[8];
-#pragma unroll
-    for (int kv = 0; kv < 8; kv++)
-        zz[kv] = kZigzag[kv][kh];
-#endif
     const uint32_t nib_row = (uint32_t)kh * (uint32_t)sizeof(kNibbleMasks.m[0]); /* 256 bytes per kh */
     /* first cluster holding coefficient contexts, by scheme (encoder.c:862-901) */
     const int coef_cl_lo = job.scheme == 0 ? 3 : job.scheme == 3 ? 0 : 1;
@@ -659,7 +635,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                                                     (long long)(px0 + ab * 8) * 3) * (long long)sizeof(sample_t));
 #pragma unroll
             for (int k = 0; k < kWords; k++)
-                nxt[k] = kK1GlobalMem ? HYDK_GLOBAL(const uint32_t, p)[k] : p[k];
+                nxt[k] = HYDK_GLOBAL(const uint32_t, p)[k];
         }
     };
     prefetch(0);
@@ -670,7 +646,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
     bool overflowed = false; /* the group outgrew its token array: stop storing, report, let the host rerun the frame */
     if (t == 0)
         s_rbits = 0;
-    unsigned long long zero_tokens = 0; /* six 10-bit counters: zero-valued coefficient tokens per cluster */
     bool bad_sample = false;
     HYDK_PHASE_INIT();
     __syncthreads();
@@ -702,67 +677,27 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                 }
                 auto row_to_xyb = [&](auto curve_tag) {
                     constexpr int CURVE = decltype(curve_tag)::value;
-#if HYDK_K1_GATHER_EARLY
-                    if (FMT == HYDK_FMT_U16 && !LUTS) {
-                        /* all eight pixels' table indices first, the gathers of the L values right behind them, then the
-                         * register evaluation of M and S — some 1500 cycles of this wavefront's own work in which the
-                         * gathered values arrive, whatever else loads the memory system */
-                        constexpr int P = 2;
-                        uint32_t idx[24];
-                        float lg[8];
-                        const auto *gl = HYDK_GLOBAL(const float, job.bias_lut);
-#pragma unroll
-                        for (int i0 = 0; i0 < 8; i0 += P) {
-                            uint32_t smp[3 * P], lin[3 * P];
-#pragma unroll
-                            for (int k = 0; k < 3 * P; k++) {
-                                const int si = i0 * 3 + k;
-                                smp[k] = (w[si >> 1] >> (16 * (si & 1))) & 0xFFFF;
-                            }
-                            input_lut16_eval_n<CURVE, 3 * P>(smp, lin);
-#pragma unroll
-                            for (int q = 0; q < P; q++) {
-                                const uint32_t r = lin[3 * q], g = lin[3 * q + 1], b = lin[3 * q + 2];
-                                const uint32_t bb = __umul24(5112u, b);
-                                idx[3 * (i0 + q)] = umad24(19661u, r, umad24(40761u, g, bb)) >> 16;
-                                idx[3 * (i0 + q) + 1] = umad24(15073u, r, umad24(45350u, g, bb)) >> 16;
-                                idx[3 * (i0 + q) + 2] = umad24(15953u, r, umad24(13419u, g, __umul24(36163u, b))) >> 16;
-                                lg[i0 + q] = gl[idx[3 * (i0 + q)]];
-                            }
-                        }
-#pragma unroll
-                        for (int i0 = 0; i0 < 8; i0 += P) {
-                            uint32_t eidx[2 * P];
-                            float eb[2 * P];
-#pragma unroll
-                            for (int q = 0; q < P; q++) {
-                                eidx[2 * q] = idx[3 * (i0 + q) + 1];
-                                eidx[2 * q + 1] = idx[3 * (i0 + q) + 2];
-                            }
-                            bias_lut_eval_n<XMODE, 2 * P>(eidx, eb);
-#pragma unroll
-                            for (int q = 0; q < P; q++) {
-                                const float Y = (lg[i0 + q] + eb[2 * q]) * 0.5f;
-                                yv[i0 + q] = Y;
-                                xv[i0 + q] = Y - eb[2 * q];
-                                bv[i0 + q] = eb[2 * q + 1] - Y;
-                            }
-                        }
-                        return;
-                    }
-#elif HYDK_K1_ILP
-                    if (FMT == HYDK_FMT_U16 && !LUTS) {
+#if HYDK_K1_ILP
+                    if (FMT != HYDK_FMT_F32 && !LUTS) {
                         constexpr int P = HYDK_K1_ILP; /* pixels evaluated in lock step */
 #pragma unroll
                         for (int i0 = 0; i0 < 8; i0 += P) {
                             uint32_t smp[3 * P], lin[3 * P], idx[3 * P];
                             float bia[3 * P];
+                            if (FMT == HYDK_FMT_U8) { /* 8-bit samples: the 256-entry transfer table sits in LDS */
 #pragma unroll
-                            for (int k = 0; k < 3 * P; k++) {
-                                const int si = i0 * 3 + k;
-                                smp[k] = (w[si >> 1] >> (16 * (si & 1))) & 0xFFFF;
+                                for (int k = 0; k < 3 * P; k++) {
+                                    const int si = i0 * 3 + k;
+                                    lin[k] = s_lut8[(w[si >> 2] >> (8 * (si & 3))) & 0xFF];
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 3 * P; k++) {
+                                    const int si = i0 * 3 + k;
+                                    smp[k] = (w[si >> 1] >> (16 * (si & 1))) & 0xFFFF;
+                                }
+                                input_lut16_eval_n<CURVE, 3 * P>(smp, lin);
                             }
-                            input_lut16_eval_n<CURVE, 3 * P>(smp, lin);
 #pragma unroll
                             for (int q = 0; q < P; q++) { /* format.c:48-56 */
                                 const uint32_t r = lin[3 * q], g = lin[3 * q + 1], b = lin[3 * q + 2];
@@ -772,10 +707,8 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                                 idx[3 * q + 2] = umad24(15953u, r, umad24(13419u, g, __umul24(36163u, b))) >> 16;
                             }
                             /* which of the 3 * P bias values come from the uploaded table through the (otherwise idle)
-                             * texture path: HYDK_K1_GATHER bits 3-5 for every pixel, HYDK_K1_GATHER_ODD for odd ones on top */
-                            constexpr auto gathered = [](int k) constexpr {
-                                return (((HYDK_K1_GATHER >> 3) | (((k / 3) & 1) ? (HYDK_K1_GATHER_ODD >> 3) : 0)) >> (k % 3) & 1) != 0;
-                            };
+                             * texture path: HYDK_K1_GATHER bits 3-5 */
+                            constexpr auto gathered = [](int k) constexpr { return ((HYDK_K1_GATHER >> 3) >> (k % 3) & 1) != 0; };
                             constexpr int NG = [&]() constexpr { int n = 0; for (int k = 0; k < 3 * P; k++) n += gathered(k); return n; }();
                             if (NG == 0)
                                 bias_lut_eval_n<XMODE, 3 * P>(idx, bia);
@@ -887,20 +820,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
             HYDK_PHASE_MARK(0);
             float o[8];
             float *dst = s_rowpass + ab * kS0Block + ar * 8;
-#if HYDK_K1_PK
-            {
-                f32x2 xy[8], oxy[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    xy[k] = f32x2{xv[k], yv[k]};
-                dct8(xy, oxy);
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    dst[k] = oxy[k].x;
-                    dst[kS0Chan + k] = oxy[k].y;
-                }
-            }
-#else
             dct8(xv, o);
 #pragma unroll
             for (int k = 0; k < 8; k++)
@@ -909,7 +828,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 dst[kS0Chan + k] = o[k];
-#endif
             dct8(bv, o);
 #pragma unroll
             for (int k = 0; k < 8; k++)
@@ -930,34 +848,14 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
         unsigned long long msk[3] = {0, 0, 0}; /* per channel X, Y, B: non-zero coefficients by zig-zag position */
         int32_t lf_int[3] = {0, 0, 0};
         if (!(HYDK_K1_SKIP & 8) && cb < gbw) {
-#if HYDK_K1_PK
-            f32x2 vxy[8]; /* the X and the Y column transformed side by side */
-            {
-                f32x2 c2[8];
-                const float *s0 = s_rowpass + cb * kS0Block + kh;
-#pragma unroll
-                for (int n = 0; n < 8; n++)
-                    c2[n] = f32x2{s0[n * 8], s0[kS0Chan + n * 8]};
-                dct8(c2, vxy);
-            }
-#endif
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 float col[8], v[8];
                 float *src = s_rowpass + c * kS0Chan + cb * kS0Block + kh;
-#if HYDK_K1_PK
-                if (c < 2) {
-#pragma unroll
-                    for (int kv = 0; kv < 8; kv++)
-                        v[kv] = c == 0 ? vxy[kv].x : vxy[kv].y;
-                } else
-#endif
-                {
 #pragma unroll
                 for (int n = 0; n < 8; n++)
                     col[n] = src[n * 8];
                 dct8(col, v);
-                }
                 /* v[kv] = coefficient with vertical frequency kv, horizontal frequency kh; the
                  * reference leaves it at block row kh, column kv (encoder.c:660-664) */
                 if (job.dbg_dct) {
@@ -984,12 +882,8 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                         nlo |= nz ? 8u << kv : 0u;
                     else
                         nhi |= nz ? 8u << (kv - 4) : 0u;
-#if HYDK_K1_TOK & 8
-                    ((int *)(s_rowpass + c * kS0Chan + cb * kS0Block))[zz[kv]] = qq;
-#else
                     /* the thread's own column: nobody else reads or writes these eight words */
                     ((int *)src)[kv * 8] = qq;
-#endif
                 }
                 if (job.dbg_quant) {
                     int32_t *d = job.dbg_quant + (size_t)c * kDbgPitch * kDbgPitch +
@@ -1008,10 +902,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
             if (kh == 0) {
 #pragma unroll
                 for (int c = 0; c < 3; c++)
-                    if (kK1GlobalMem)
-                        HYDK_GLOBAL(int32_t, job.dc)[(size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH + (size_t)((py0 >> 3) + s) * HYDK_DC_PITCH + (px0 >> 3) + cb] = lf_int[c];
-                    else
-                    job.dc[(size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH + (size_t)((py0 >> 3) + s) * HYDK_DC_PITCH + (px0 >> 3) + cb] = lf_int[c];
+                    HYDK_GLOBAL(int32_t, job.dc)[(size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH + (size_t)((py0 >> 3) + s) * HYDK_DC_PITCH + (px0 >> 3) + cb] = lf_int[c];
             }
 #pragma unroll
             for (int c = 0; c < 3 && !(HYDK_K1_SKIP & 4); c++) { /* the block's bitmap = OR over its eight threads */
@@ -1063,103 +954,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
             const uint32_t per = strip_total >> 8, extra = strip_total & 255u;
             uint32_t p = (uint32_t)t * per + min((uint32_t)t, extra);
             const uint32_t pend = overflowed ? 0u : p + per + ((uint32_t)t < extra ? 1u : 0u);
-#if HYDK_K1_TOK & 8
-            if (!(HYDK_K1_SKIP & 1) && p < pend) {
-                /* ---- the pipelined walk: every LDS value a symbol needs is requested while the symbol before it is
-                 * being coded (its coefficient, the frequency context of its position, the count context of the
-                 * non-zeros still to come, and — a segment ahead — the next segment's descriptor), so an iteration's
-                 * critical path is arithmetic only; stepping to the next segment is a handful of selects, no branch ---- */
-                uint32_t b = 0;
-#pragma unroll
-                for (uint32_t step = 16; step; step >>= 1)
-                    b += s_boff[b + step] <= p ? step : 0u;
-                uint32_t j = p - s_boff[b];
-                const uint32_t len = s_blen[b];
-                uint32_t visit = 0;
-                if (j >= (len & 0xffu)) {
-                    j -= len & 0xffu;
-                    visit = 1;
-                    if (j >= ((len >> 8) & 0xffu)) {
-                        j -= (len >> 8) & 0xffu;
-                        visit = 2;
-                    }
-                }
-                uint32_t seg_at = b * 3u + visit;
-                const uint4 seg = s_seg[seg_at];
-                uint2 nseg = *(const uint2 *)&s_seg[seg_at + 1].z; /* {symbols | non-zeros << 8, word offset} of the segment after */
-                uint32_t n = seg.z & 0xffu, nz_total = seg.z >> 8;
-                const unsigned long long m = ((unsigned long long)seg.y << 32) | seg.x;
-                uint32_t remaining = nz_total - (uint32_t)__popcll(m & ((1ull << j) - 1ull));
-                uint32_t prev = j <= 1u ? (uint32_t)(nz_total <= 4u) : (uint32_t)(m >> (j - 1u)) & 1u;
-                const uint32_t coef_base = (uint32_t)coef_cl_lo;
-                const uint32_t prev_mask = job.scheme <= 1 ? 1u : 0u, ctx_mask = job.scheme == 0 ? 6u : 0u;
-                const uint32_t count_mask = job.scheme == 0 ? 3u : 0u;
-                const char *const lds_q = (const char *)s_rowpass;
-                const uint8_t *const lds_f3 = (const uint8_t *)s_jinfo + 1; /* byte 2 j: frequency context of position j, mod 3 */
-                uint32_t qa = (seg.w + j) << 2;  /* byte address of this symbol's coefficient */
-                int coef = *(const int *)(lds_q + qa);
-                uint32_t f3 = lds_f3[2u * j];
-                uint32_t z3 = s_nnz3[remaining & 63u];
-                uint32_t at = (goff + p) << 2;   /* byte offset of the record */
-                char *const tokb = (char *)tok;
-                for (; p < pend; p++) {
-                    /* ---- where the next symbol sits, and its loads ---- */
-                    const uint32_t here = coef != 0 ? 1u : 0u;
-                    const bool is_count = j == 0u;
-                    const bool step = j + 1u == n;
-                    const uint32_t jn = step ? 0u : j + 1u;
-                    const uint32_t qn = step ? nseg.y << 2 : qa + 4u;
-                    const uint32_t rem_n = step ? nseg.x >> 8 : remaining - here;
-                    const int coef_n = *(const int *)(lds_q + qn);
-                    const uint32_t f3_n = lds_f3[2u * jn];
-                    const uint32_t z3_n = s_nnz3[rem_n & 63u];
-                    /* ---- this symbol ---- */
-                    const uint32_t value = is_count ? nz_total : pack_signed(coef);
-                    const uint32_t u = visit + z3 + f3;
-                    const uint32_t cluster = is_count ? (visit & count_mask)
-                                                      : coef_base + (prev & prev_mask) + ((0x1248u >> (u + u)) & ctx_mask);
-                    uint32_t token, rbits, residue;
-                    if (FMT != HYDK_FMT_F32) {
-                        const uint32_t fb = __float_as_uint((float)value) >> 22;
-                        const bool big = value >= 16u;
-                        token = big ? fb - 246u : value;
-                        rbits = big ? (fb >> 1) - 128u : 0u;
-                        residue = __builtin_amdgcn_ubfe(value, 0u, rbits);
-                        *HYDK_GLOBAL(uint32_t, tokb + at) = HYDK_REC32(token, cluster, rbits, residue);
-                    } else {
-                        if (value < 16) {
-                            token = value;
-                            rbits = 0;
-                            residue = 0;
-                        } else {
-                            const int nb = 30 - __clz((int)value);
-                            rbits = (uint32_t)nb;
-                            residue = value & ((1u << nb) - 1u);
-                            token = 16u + (((uint32_t)(nb - 3) << 1) | ((value >> nb) & 1u));
-                        }
-                        *HYDK_GLOBAL(uint64_t, tokb + 2u * at) = ((uint64_t)residue << 32) | HYDK_REC_LO(token, cluster, rbits);
-                    }
-                    rb_sum += rbits;
-                    atomicAdd(&s_hist[cluster * kHistW + (FMT == HYDK_FMT_F32 ? (int)min(token, (uint32_t)kHistW - 1u) : (int)token)], 1u);
-                    /* ---- walk on ---- */
-                    prev = is_count ? (uint32_t)(nz_total <= 4u) : here;
-                    if (step) { /* selects: the next segment's descriptor is already in registers */
-                        seg_at++;
-                        visit = visit == 2u ? 0u : visit + 1u;
-                        n = nseg.x & 0xffu;
-                        nz_total = nseg.x >> 8;
-                        nseg = *(const uint2 *)&s_seg[seg_at + 1].z;
-                    }
-                    j = jn;
-                    qa = qn;
-                    remaining = rem_n;
-                    coef = coef_n;
-                    f3 = f3_n;
-                    z3 = z3_n;
-                    at += 4u;
-                }
-            }
-#else
             if (!(HYDK_K1_SKIP & 1) && p < pend) {
                 uint32_t b = 0;
 #pragma unroll
@@ -1201,7 +995,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                                                       : coef_base + (prev & prev_mask) + ((0x1248u >> (u + u)) & ctx_mask);
                     /* hybrid-uint split, config (4,1,0) (entropy.c:427-444) */
                     uint32_t token, rbits, residue;
-                    if ((HYDK_K1_TOK & 1) && FMT != HYDK_FMT_F32) {
+                    if (FMT != HYDK_FMT_F32) {
                         /* value < 2^14 converts exactly: its float's exponent and top mantissa bit are floor(log2) and
                          * the bit below the leading one, i.e. the token's two variable parts (entropy.c:427-444) */
                         const uint32_t fb = __float_as_uint((float)value) >> 22; /* 2 * (127 + floor(log2)) + next bit */
@@ -1221,12 +1015,9 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                     }
                     store_record<FMT>(tok, goff + p, token, cluster, rbits, residue);
                     rb_sum += rbits;
-                    if (HYDK_K1_TOK & 2)
-                        atomicAdd(&s_hist[cluster * kHistW + (FMT == HYDK_FMT_F32 ? (int)min(token, (uint32_t)kHistW - 1u) : (int)token)], 1u);
-                    else if (token == 0 && !is_count)
-                        zero_tokens += 1ull << (10 * (cluster - coef_base)); /* at most 24 x 32 per thread and group */
-                    else
-                        atomicAdd(&s_hist[cluster * kHistW + (int)min(token, (uint32_t)kHistW - 1u)], 1u);
+                    /* every token straight into the LDS histogram (until round 3 zero tokens were counted in packed per-thread
+                     * counters inside a divergent branch: twelve instructions to save an atomic that costs nothing) */
+                    atomicAdd(&s_hist[cluster * kHistW + (FMT == HYDK_FMT_F32 ? (int)min(token, (uint32_t)kHistW - 1u) : (int)token)], 1u);
                     /* walk on: the DC slot read for a count symbol is zero, so it leaves `remaining` alone */
                     const uint32_t here = coef != 0 ? 1u : 0u;
                     remaining -= here;
@@ -1241,7 +1032,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                     }
                 }
             }
-#endif
         }
         goff += strip_total;
         HYDK_PHASE_MARK(6);
@@ -1249,12 +1039,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
         __syncthreads();
     }
 
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const uint32_t n0 = (uint32_t)(zero_tokens >> (10 * k)) & 1023u;
-        if (n0)
-            atomicAdd(&s_hist[(coef_cl_lo + k) * kHistW], n0);
-    }
     __syncthreads();
     uint32_t top_token = 0;
     for (int i = t; i < HYDK_MAX_CLUSTERS * kHistW; i += kThreads) {

@@ -2,7 +2,7 @@
 """A/B of build-time variants of the transform kernel (k_transform_tokenize) on one GPU box.
 
 Every variant is the product library with kernels.hip recompiled under extra -D flags (HYDK_K1_GATHER,
-HYDK_K1_WAVELOCAL, HYDK_K1_TOK, HYDK_K1_SKIP, ...: see the head of kernels.hip).  The run leg times the kernel ALONE
+HYDK_K1_WAVELOCAL, HYDK_K1_ILP, HYDK_K1_SKIP, ...: see the head of kernels.hip; the variants that lost were removed again, git history has them).  The run leg times the kernel ALONE
 (one 8192x8192 RGB16 photo frame at a time, the library's own event timers) and hashes the frame's HF sections, so
 a variant that changes a byte shows at once.  Variants alternate over the rounds, so box drift hits all alike.
 

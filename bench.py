@@ -55,9 +55,10 @@ def parse():
     ap.add_argument("--depth", type=int, default=16, choices=(8, 16))
     ap.add_argument("--kind", default="photo")
     ap.add_argument("--streams", type=int, default=32, help="frames in flight (one context + HIP stream each)")
-    ap.add_argument("--rans-waves", type=int, default=5, choices=(4, 5),
+    ap.add_argument("--rans-waves", type=int, default=6, choices=(4, 5, 6),
                     help="entropy-stage form, see hydamd_set_rans_waves: 5 = one lane per group, a wavefront per LF group "
-                         "(throughput); 4 = one wave per group (lowest single-frame latency)")
+                         "(throughput); 6 = the same with packed tables (62 KB of LDS per chain, not 80: +4 %% in the pipelined loop, "
+                         "chains 11 %% slower alone); 4 = one wave per group (lowest single-frame latency)")
     ap.add_argument("--lf-coder", default="on", choices=("on", "off"),
                     help="code the LF coefficient streams on the GPU inside the timed loop (default) or leave them out")
     ap.add_argument("--collective", default="gather", choices=("gather", "all-gather"),
@@ -153,7 +154,7 @@ def shard_leg(args, steps, warmup, size=16384, kind=None, assemble="device"):
     shards = [multigpu.Shard(local, mine, W, H) for _ in range(depth_in_flight)]
     for sh in shards:
         if sh.ctx:
-            sh.ctx.set_rans_waves(args.rans_waves)
+            sh.ctx.set_rans_waves(min(args.rans_waves, 5))  # one frame at a time per set of contexts: the chains' own speed counts
             # the LF coder in the context's own stream (its code construction rides in the chain kernel's launch): one
             # stream per frame in flight, as in frame mode — side streams alias onto the hardware queues of other frames
             sh.ctx.set_lf_coder(2)
@@ -358,7 +359,7 @@ def batch_device_leg(args, frames, contexts=16, rounds=4):
     S = max(1, min(contexts, len(mine) or 1))
     ctxs = [device.DeviceContext(local, 4, 0) for _ in range(S)]
     for c in ctxs:
-        c.set_rans_waves(5)
+        c.set_rans_waves(6)
         c.set_lf_coder(2)
     want = {}
     for k in range(distinct):  # reference digests: one context, one frame at a time
@@ -802,7 +803,7 @@ def main():
     if world == 1:
         c0 = ctxs[0]
         # the throughput form's own un-overlapped durations
-        c0.set_rans_waves(5)
+        c0.set_rans_waves(max(5, args.rans_waves))
         c0.set_lf_coder(2 if args.lf_coder == "on" else 0)  # in-stream: no kernel of the frame overlaps another
         c0.encode_image_tensor(img)
         c0.sync()
@@ -894,7 +895,7 @@ def main():
         # form): per-launch durations inside the interval are co-residency figures (a launch there shares
         # the GPU with the other streams' kernels and lasts several frame periods)
         dom = max(kern, key=lambda k: kern[k][0])
-        alone = (lat5 or {}).get("kernel_avg_ms", {}) if args.rans_waves == 5 else (lat or {}).get("kernel_avg_ms", {})
+        alone = (lat5 or {}).get("kernel_avg_ms", {}) if args.rans_waves >= 5 else (lat or {}).get("kernel_avg_ms", {})
         dom_ms = alone.get(dom) or kern[dom][0] / max(kern[dom][1], 1)
         achieved = bytes_in / (dom_ms * 1e-3) / 1e9
         k1_ms = alone.get("transform_tokenize")
@@ -937,6 +938,11 @@ def main():
             "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / K * 1e3, 4),
+            "value_is": "the SUSTAINED rate: median of three consecutive 512-frame windows of one continuous run behind 0.2 s of priming "
+                        "(it equals the barrier-to-barrier rate of the whole run, timing.Mpixel/s_wall, within a few per cent)",
+            "value_by_the_method_of_rounds_1_to_3": round(world * W * H * 2 * S * FPL / burst["dt"] / 1e6, 1),
+            "value_by_the_method_of_rounds_1_to_3_is": "a short event window right behind a short priming phase, from an idle GPU (BENCH_r03: 136 941 by this "
+                                                       "method); the GPU's first 150 ms under this load run 10-15 % faster than what follows (DESIGN.md 4)",
             "timing": {"method": "HIP events at the end of each frame's stream: completion of the last priming frames -> "
                                  "completion of the last timed frames, pipeline primed before and kept full behind; "
                                  "one continuous run: ten launch groups per stream of priming (the GPU's first 150 ms under this load run 10-15 % fast), "
@@ -984,7 +990,7 @@ def main():
                          if exchange else None),
             "timed_contexts_as_files": timed_files,
             "single_frame": lat,
-            "single_frame_form5": lat5,
+            "single_frame_form5": lat5,  # the loop's own lane-per-group form (5, or 6 = packed tables), un-overlapped
             "hf_sections_only": hf_only,
             "one_frame_per_launch_group": one_per_group,
             "finished_file_per_step": whole_file,

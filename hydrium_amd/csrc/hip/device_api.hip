@@ -54,7 +54,7 @@ hipError_t launch_rans(const HydkLfJob *d_jobs, const uint32_t *sym_count, const
 hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint16_t *aux,
                              uint16_t *flags, uint32_t aux_pitch, uint32_t *final_state, uint32_t *group_bits, int preset_bits,
                              int nclusters, int num_slots, const uint32_t *status, const uint32_t *lf_hist,
-                             HydkLfStream *lf_streams, void *lf_work, hipStream_t stream);
+                             HydkLfStream *lf_streams, void *lf_work, bool packed_tables, hipStream_t stream);
 hipError_t launch_lf_front(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, void *work, int num_slots,
                            hipStream_t stream);
 hipError_t launch_lf_back(const HydkLfJob *d_jobs, const unsigned long long *recs, HydkLfStream *streams, uint32_t *bits,
@@ -115,7 +115,7 @@ struct HydAmdContext {
     int use_luts = 2;               /* XYB mode: 0 registers + fast reciprocal, 1 registers + IEEE division, 2 LUT gathers */
     int best_register_mode = 2;     /* best mode that passed the bit-exactness self-test */
     int register_luts_ok = 0;
-    int rans_lanes = 0;             /* entropy-stage form: 0 wave per group (form 4), 1 lane per group (form 5; float frames still take form 4) */
+    int rans_lanes = 0;             /* entropy-stage form: 0 wave per group (form 4), 1 lane per group (form 5; float frames still take form 4), 2 the same with packed tables (form 6) */
     uint32_t tok_cap = HYDK_DEFAULT_TOKEN_CAP; /* token records per group the arrays below hold */
     uint32_t rec_bytes = 4;         /* their record size: 4 until a float LF group is recorded, then 8 */
     uint32_t bit_pitch_words = 0;   /* words per group in bitbuf (0: not allocated yet) */
@@ -845,8 +845,8 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     ctx->use_luts = ctx->best_register_mode;
     if (const char *env = getenv("HYDAMD_RANS_WAVES")) {
         const int w = atoi(env);
-        if (w == 4 || w == 5)
-            ctx->rans_lanes = w == 5;
+        if (w >= 4 && w <= 6)
+            ctx->rans_lanes = w - 4;
         else if (w >= 1 && w <= 3)
             ctx->rans_lanes = retired_rans_form(w);
     }
@@ -929,9 +929,9 @@ int hydamd_set_rans_waves(HydAmdContext *ctx, int waves) {
         ctx->rans_lanes = retired_rans_form(waves);
         return ST_OK;
     }
-    if (waves != 4 && waves != 5)
-        return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group) or 5 (lane per group)");
-    ctx->rans_lanes = waves == 5;
+    if (waves < 4 || waves > 6)
+        return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group), 5 (lane per group) or 6 (lane per group, packed tables)");
+    ctx->rans_lanes = waves - 4;
     return ST_OK;
 }
 
@@ -1502,6 +1502,13 @@ HydAmdAssembler *hydamd_context_assembler(HydAmdContext *ctx) {
 /* HYDAMD_DEBUG_SKIP (bit mask, measurements only — the frame's bytes are then stale or wrong): leave a stage of the closing
  * sequence out of the stream: 1 table kernel, 2 rANS chains, 4 section scan + emit, 8 the LF coder's kernels.
  * scripts/pipe_probe.py uses it to price each stage's share of the pipelined frame rate. */
+namespace {
+__global__ __launch_bounds__(64) void k_sleep_probe(unsigned long long ticks_100mhz) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz)
+        __builtin_amdgcn_s_sleep(127);
+}
+} /* namespace */
 static int debug_skip() {
     static const int v = getenv("HYDAMD_DEBUG_SKIP") ? atoi(getenv("HYDAMD_DEBUG_SKIP")) : 0;
     return v;
@@ -1538,7 +1545,14 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
         if (with_lf_codes && !lanes)
             return fail(ctx, ST_INTERNAL_ERROR, "LF code construction can only ride with the lane-form entropy stage");
         (void)lanes;
-        if (debug_skip() & 2) {
+        if (debug_skip() & 16) { /* ... 16: sleeping wavefronts of the chains' duration in their place: HYDAMD_DEBUG_SLEEP_WGS of them
+                                  * (default 1), each holding HYDAMD_DEBUG_SLEEP_LDS bytes of LDS (default 0) */
+            static const int wgs = getenv("HYDAMD_DEBUG_SLEEP_WGS") ? atoi(getenv("HYDAMD_DEBUG_SLEEP_WGS")) : 1;
+            static const int lds = getenv("HYDAMD_DEBUG_SLEEP_LDS") ? atoi(getenv("HYDAMD_DEBUG_SLEEP_LDS")) : 0;
+            if (lds > 65536)
+                (void)hipFuncSetAttribute((const void *)k_sleep_probe, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL(k_sleep_probe, dim3(wgs > 0 ? wgs * count : 1), dim3(64), (size_t)lds, ctx->stream, 250000ull);
+        } else if (debug_skip() & 2) {
         } else if (lanes) {
             HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, ctx->sym_count + g0, ctx->tables + first,
                                                  ctx->rans_aux + g0 * ctx->tok_cap, ctx->rans_flags + g0 * (ctx->tok_cap / 16),
@@ -1546,7 +1560,7 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
                                                  ctx->nclusters, count, ctx->status,
                                                  with_lf_codes ? ctx->lf_hist + (size_t)first * HYDK_LF_CODES : nullptr,
                                                  ctx->lf_streams + first, ctx->lf_work + (size_t)first * hydk::lf_work_bytes(),
-                                                 ctx->stream));
+                                                 ctx->rans_lanes == 2, ctx->stream));
         } else {
             const int st = ensure_bitbuf(ctx);
             if (st != ST_OK)
@@ -1885,6 +1899,42 @@ int hydamd_debug_transform_footprint(HydAmdContext *ctx, int sample_fmt, int *ld
         return ST_API_ERROR;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hydk::transform_footprint(sample_fmt, ctx->use_luts, lds_bytes, registers));
+    return ST_OK;
+}
+
+/* The shader clock right now, in MHz, seen from inside a kernel: a single wavefront spins for ~20 us and compares the shader
+ * clock counter (s_memtime) with the constant 100 MHz reference (s_memrealtime).  On a stream of its own, so that it can be
+ * asked while the context's frames are running (scripts/pipe_probe.py --clock: the pipelined loop's rate settles lower
+ * after its first 150 ms and the clock does not — DESIGN.md 4). */
+namespace {
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *out) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < 2000ull) /* 20 us of the 100 MHz counter */
+        r1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+}
+} /* namespace */
+
+int hydamd_debug_shader_clock_mhz(HydAmdContext *ctx, double *mhz) {
+    if (!ctx || !mhz)
+        return ST_API_ERROR;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    static hipStream_t side = nullptr;
+    static unsigned long long *h = nullptr;
+    if (!side) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipHostMalloc((void **)&h, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, side, h);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(side));
+    *mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
     return ST_OK;
 }
 

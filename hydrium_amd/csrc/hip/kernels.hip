@@ -515,16 +515,17 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
 }
 
 /* Token records.  Integer input: |quantised coefficient| <= 0.42 * 1969 * 5 < 2^13 (XYB is bounded by the
- * bias LUT's range and the scaled DCT has unit gain), so token < 64, residue < 2^13 and one record fits
- * 32 bits: token | cluster << 7 | residue bit count << 11 | residue << 16.  Float input has no such
- * bound and keeps the 8-byte record: lo = token | cluster << 8 | bit count << 16, hi = residue. */
+ * bias LUT's range and the scaled DCT has unit gain), so token < 36, residue < 2^13 and one record fits
+ * 32 bits: symbol | residue bit count << 11 | residue << 16, symbol = cluster * 40 + token — the histogram bin,
+ * which the caller has at hand.  Float input has no such bound and keeps the 8-byte record:
+ * lo = token | cluster << 8 | bit count << 16, hi = residue. */
 template <int FMT>
-__device__ __forceinline__ void store_record(void *tok, uint32_t at, uint32_t token, uint32_t cluster, uint32_t rbits,
-                                             uint32_t residue) {
+__device__ __forceinline__ void store_record(void *tok, uint32_t at, uint32_t token, uint32_t cluster, uint32_t symbol,
+                                             uint32_t rbits, uint32_t residue) {
     if (FMT == HYDK_FMT_F32)
         ((uint64_t *)tok)[at] = ((uint64_t)residue << 32) | HYDK_REC_LO(token, cluster, rbits);
     else
-        HYDK_GLOBAL(uint32_t, tok)[at] = HYDK_REC32(token, cluster, rbits, residue);
+        HYDK_GLOBAL(uint32_t, tok)[at] = HYDK_REC32(symbol, rbits, residue);
 }
 
 #ifdef HYDK_K1_WAVES_EXACT /* register allocation padded so that exactly this many wavefronts fit a SIMD (occupancy experiments) */
@@ -562,7 +563,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
     /* integer input cannot produce a token above 35 (see store_record): 40 bins per cluster suffice.  LDS is
      * handed out in granules of 1280 bytes (measured: a 33 284-byte build lost the co-residency a 33 232-byte
      * one has): at <= 26 granules two of these workgroups fit beside an entropy-stage workgroup (75 granules) */
-    constexpr int kHistW = FMT == HYDK_FMT_F32 ? 72 : 40; /* float input: the (4,1,0) configuration ends at token 71 */
+    constexpr int kHistW = FMT == HYDK_FMT_F32 ? 72 : (int)HYDK_REC32_TOKENS; /* float input: the (4,1,0) configuration ends at token 71 */
     __shared__ uint32_t s_hist[HYDK_MAX_CLUSTERS * kHistW];
     __shared__ uint16_t s_lut8[256];
     __shared__ uint8_t s_nnz3[64];                    /* coefficient-count context offset (encoder.c:60-66) mod 3 */
@@ -1013,11 +1014,12 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                         residue = value & ((1u << nb) - 1u);
                         token = 16u + (((uint32_t)(nb - 3) << 1) | ((value >> nb) & 1u));
                     }
-                    store_record<FMT>(tok, goff + p, token, cluster, rbits, residue);
+                    const uint32_t bin = cluster * kHistW + (FMT == HYDK_FMT_F32 ? min(token, (uint32_t)kHistW - 1u) : token);
+                    store_record<FMT>(tok, goff + p, token, cluster, bin, rbits, residue);
                     rb_sum += rbits;
                     /* every token straight into the LDS histogram (until round 3 zero tokens were counted in packed per-thread
                      * counters inside a divergent branch: twelve instructions to save an atomic that costs nothing) */
-                    atomicAdd(&s_hist[cluster * kHistW + (FMT == HYDK_FMT_F32 ? (int)min(token, (uint32_t)kHistW - 1u) : (int)token)], 1u);
+                    atomicAdd(&s_hist[bin], 1u);
                     /* walk on: the DC slot read for a count symbol is zero, so it leaves `remaining` alone */
                     const uint32_t here = coef != 0 ? 1u : 0u;
                     remaining -= here;
@@ -1522,21 +1524,38 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
  * grid = LF groups, block = 64.
  * ======================================================================================== */
 
+constexpr bool rec32_cluster_is_exact() {
+    for (uint32_t s = 0; s < 2048u; s++)
+        if (HYDK_REC32_CLUSTER(s) != s / HYDK_REC32_TOKENS)
+            return false;
+    return true;
+}
+static_assert(rec32_cluster_is_exact(), "HYDK_REC32_CLUSTER: symbol / 40 by multiplication");
+constexpr int kLaneTokens = (int)HYDK_REC32_TOKENS; /* integer formats: the record's symbol is cluster * 40 + token */
+
 struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs besides the state */
     uint32_t thr;   /* (f << 20) - 1: renormalise when state > thr (entropy.c:1092) */
     uint32_t magic; /* floor(2^32 / f) */
     uint32_t negf;  /* -f */
-    uint32_t tab2;  /* byte offset of the symbol's slot list in s_inv: 2 * (cluster * 4096 + base) */
+    uint32_t tab2;  /* index of the symbol's slot list in the slot planes: cluster * 4096 + base */
 };
 
+template <bool PACK>
 __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
                                                    const HydkTables *tabs, uint16_t *aux_all, uint16_t *flags_all,
                                                    uint32_t aux_pitch /* symbols per group in aux / flags */,
                                                    uint32_t *final_state_all, uint32_t *group_bits_all, int nclusters,
                                                    int preset_bits, const uint32_t *status, int num_slots,
                                                    const uint32_t *lf_hist, HydkLfStream *lf_streams, void *lf_work) {
-    __shared__ uint16_t s_inv[kInvEntries / 2];                       /* plain inverse slot table, 72 KiB */
-    __shared__ uint4 s_ops[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];        /* 18 KiB */
+    /* The workgroup HOLDS its LDS for the whole walk, and in the pipelined loop that (times the walk's duration, which
+     * doubles beside other frames' transform workgroups) is most of what the chains cost the kernels around them
+     * (profiles/r04_pipeline_bounds.txt).  PACK (form 6): the 12-bit slots as a byte plane and a nibble plane — both
+     * reads leave together, one LDS latency, three more dependent instructions a step: 62 KB instead of 80, so a
+     * compute unit that hosts a chain takes three transform workgroups, not two; the chain alone is 11 % slower. */
+    __shared__ uint8_t s_lo[PACK ? kInvEntries / 2 : 16];             /* slot & 255: 36 KiB */
+    __shared__ uint8_t s_hi[PACK ? kInvEntries / 4 : 16];             /* slot >> 8, two per byte: 18 KiB */
+    __shared__ uint16_t s_inv[PACK ? 8 : kInvEntries / 2];            /* or the plain inverse slot table, 72 KiB */
+    __shared__ uint4 s_ops[HYDK_MAX_CLUSTERS * kLaneTokens];          /* 5.6 KiB */
     HYDK_URGENT();
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= num_slots) {
@@ -1554,21 +1573,36 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
         return; /* the transform stage ran out of token space: the host reruns the frame */
     {
         const uint4 *src = (const uint4 *)&tab->inv1[0][0];
-        uint4 *dst = (uint4 *)s_inv;
-        for (int i = lane; i < nclusters * HYDK_ANS_SLOTS / 8; i += 64)
-            dst[i] = src[i];
-        for (int i = lane; i < nclusters * HYDK_ALPHABET; i += 64) {
-            const uint32_t fbv = (&tab->fb[0][0])[i], f = fbv & 0xFFFFu;
+        for (int i = lane; i < nclusters * HYDK_ANS_SLOTS / 8 && !PACK; i += 64)
+            ((uint4 *)s_inv)[i] = src[i];
+        for (int i = lane; i < nclusters * HYDK_ANS_SLOTS / 8 && PACK; i += 64) { /* eight slots a turn */
+            const uint4 v = src[i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t lo[2], hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t pair = (w[k] & 0xFFu) | ((w[k] >> 8) & 0xFF00u);
+                if (k & 1)
+                    lo[k >> 1] |= pair << 16;
+                else
+                    lo[k >> 1] = pair;
+                hi |= (((w[k] >> 8) & 0xFu) | ((w[k] >> 20) & 0xF0u)) << (8 * k);
+            }
+            ((uint2 *)s_lo)[i] = uint2{lo[0], lo[1]};
+            ((uint32_t *)s_hi)[i] = hi;
+        }
+        for (int i = lane; i < nclusters * kLaneTokens; i += 64) {
+            const int c = i / kLaneTokens, at = c * HYDK_ALPHABET + i % kLaneTokens;
+            const uint32_t fbv = (&tab->fb[0][0])[at], f = fbv & 0xFFFFu;
             uint4 o;
             o.x = f ? (f << 20) - 1u : 0xFFFFFFFFu;
-            o.y = (&tab->magic[0][0])[i];
+            o.y = (&tab->magic[0][0])[at];
             o.z = 0u - f;
-            o.w = 2u * ((uint32_t)(i / HYDK_ALPHABET) * HYDK_ANS_SLOTS + (fbv >> 16));
+            o.w = (uint32_t)c * HYDK_ANS_SLOTS + (fbv >> 16);
             s_ops[i] = o;
         }
     }
     __syncthreads();
-    const unsigned char *inv_bytes = (const unsigned char *)s_inv;
     const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + lane;
     const int n = lane < ngroups ? (int)sym_count_all[G] : 0;
     /* 4-byte records, 4 per uint4 (tok_cap is a multiple of 16: rounds never straddle a group's array) */
@@ -1591,11 +1625,14 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     for (int q = 0; q < 4; q++)
         nx[q] = rj >= 0 ? tok[rj * 4 + q] : uint4{0, 0, 0, 0};
 
+#define HYDK_LANE_SLOT(ei) \
+    (PACK ? (uint32_t)s_lo[ei] | (__builtin_amdgcn_ubfe((uint32_t)s_hi[(ei) >> 1], ((ei) & 1u) << 2, 4u) << 8) : (uint32_t)s_inv[ei])
 /* one symbol: record `rec` (position `pos` of the round, walked from 15 down to 0); PRED: the step
  * only counts if VALID (first round of a lane) */
 #define HYDK_LANE_STEP(rec, pos, PRED, VALID)                                                                    \
     do {                                                                                                         \
-        const uint4 o = s_ops[(PRED) && !(VALID) ? 0u : (rec) & 0x7FFu]; /* beyond the stream's end: stale bytes */ \
+        /* the record's symbol is the row of s_ops; beyond the stream's end: stale bytes */                     \
+        const uint4 o = s_ops[(PRED) && !(VALID) ? 0u : (rec) & 0x7FFu]; /* (an LDS read past the table returns 0) */ \
         uint32_t x;                                                                                              \
         /* refill test, renormalised state, and the flag shifted into the round's flag word */                  \
         asm("v_cmp_gt_u32 vcc, %2, %3\n\t"                                                                       \
@@ -1614,7 +1651,8 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
         const uint32_t r1 = r0 + o.z;                                                                            \
         const uint32_t r = min(r0, r1);                                                                          \
         q += (int)r1 >= 0;                                                                                       \
-        const uint32_t nstate = (q << 12) | *(const uint16_t *)(inv_bytes + o.w + 2u * r);                       \
+        const uint32_t ei = o.w + r;                                                                             \
+        const uint32_t nstate = (q << 12) | HYDK_LANE_SLOT(ei);                                                  \
         state = (PRED) && !(VALID) ? state : nstate;                                                             \
     } while (0)
 
@@ -1651,6 +1689,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
         rj = rjn;
     }
 #undef HYDK_LANE_STEP
+#undef HYDK_LANE_SLOT
     if (lane < ngroups) {
         final_state_all[G] = state;
         /* [preset id][final state][per symbol: refill word, residue bits] (encoder.c:945, entropy.c:1127-1147) */
@@ -2103,10 +2142,14 @@ hipError_t launch_rans(const HydkLfJob *d_jobs, const uint32_t *sym_count, const
 hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint16_t *aux,
                              uint16_t *flags, uint32_t aux_pitch, uint32_t *final_state, uint32_t *group_bits, int preset_bits,
                              int nclusters, int num_slots, const uint32_t *status, const uint32_t *lf_hist,
-                             HydkLfStream *lf_streams, void *lf_work, hipStream_t stream) {
-    hipLaunchKernelGGL(k_rans_lanes, dim3(lf_hist ? 2 * num_slots : num_slots), dim3(64), 0, stream, d_jobs, sym_count, tabs,
-                       aux, flags, aux_pitch, final_state, group_bits, nclusters, preset_bits, status, num_slots, lf_hist,
-                       lf_streams, lf_work);
+                             HydkLfStream *lf_streams, void *lf_work, bool packed_tables, hipStream_t stream) {
+    const dim3 grid(lf_hist ? 2 * num_slots : num_slots);
+    if (packed_tables)
+        hipLaunchKernelGGL(k_rans_lanes<true>, grid, dim3(64), 0, stream, d_jobs, sym_count, tabs, aux, flags, aux_pitch,
+                           final_state, group_bits, nclusters, preset_bits, status, num_slots, lf_hist, lf_streams, lf_work);
+    else
+        hipLaunchKernelGGL(k_rans_lanes<false>, grid, dim3(64), 0, stream, d_jobs, sym_count, tabs, aux, flags, aux_pitch,
+                           final_state, group_bits, nclusters, preset_bits, status, num_slots, lf_hist, lf_streams, lf_work);
     return hipGetLastError();
 }
 

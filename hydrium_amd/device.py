@@ -66,6 +66,7 @@ def dll(path: Optional[str] = None):
         d.hydamd_encode_lf_group.argtypes = lf_args
         d.hydamd_encode_lf_group_host.argtypes = lf_args
         d.hydamd_encode_image.argtypes = [vp, C.POINTER(vp), C.c_ssize_t, C.c_ssize_t, i, sz, sz]
+        d.hydamd_debug_shader_clock_mhz.argtypes = [vp, C.POINTER(C.c_double)]
         d.hydamd_encode_image_batch.argtypes = [vp, i, C.POINTER(vp), C.c_ssize_t, C.c_ssize_t, i, sz, sz]
         d.hydamd_begin_batch.argtypes = [vp, u, i]
         d.hydamd_finish_frame.argtypes = [vp, i]
@@ -444,6 +445,11 @@ class DeviceContext:
 
         cap = self.max_lf_groups * LF_BITWORDS * 4
         return self._device_view("lf", int(self.d.hydamd_lf_payload_device(self.h) or 0), cap)[: self.lf_payload_size()]
+
+    def shader_clock_mhz(self) -> float:
+        v = C.c_double(0)
+        self._ck(self.d.hydamd_debug_shader_clock_mhz(self.h, C.byref(v)))
+        return v.value
 
     def transform_footprint(self, sample_fmt: int):
         """(static LDS bytes, registers per thread) of the transform kernel instance serving `sample_fmt` (0 u8, 1 u16, 2 f32)."""

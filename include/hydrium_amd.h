@@ -88,6 +88,10 @@ HYDAMD_EXPORT int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode);
  *       parallel kernel writes the bits straight into the payload; a fifteenth of the instructions and
  *       a sixty-fourth of the wavefronts of form 4 — best when many frames are in flight.  LF groups
  *       with float samples are still coded by form 4.
+ *   6   form 5 with its coding tables packed (12-bit slots as a byte and a nibble plane, operands for the 40
+ *       tokens an integer frame can hold): 62 KB of LDS per chain instead of 80, at three more dependent
+ *       instructions a symbol.  Alone the chains take 11 % longer; with many frames in flight on one device
+ *       the compute units that host a chain take a third transform workgroup and the loop gains 4 %.
  * Round 1's row forms 1-3 are gone: asking for one of them (here or through HYDAMD_RANS_WAVES) selects
  * form 5, which replaced them, and says so once on stderr. */
 HYDAMD_EXPORT int hydamd_set_rans_waves(HydAmdContext *ctx, int waves);
@@ -205,6 +209,9 @@ HYDAMD_EXPORT int hydamd_debug_lf_code(HydAmdContext *ctx, const uint32_t hist[H
  * context runs): static LDS bytes and registers per thread.  LDS is allocated in granules of 1280 bytes and two
  * transform workgroups share a CU with one entropy-stage workgroup only at <= 26 granules: a test holds that line. */
 HYDAMD_EXPORT int hydamd_debug_transform_footprint(HydAmdContext *ctx, int sample_fmt, int *lds_bytes, int *registers);
+/* the shader clock in MHz as a 20 us single-wavefront kernel on a stream of its own sees it (s_memtime against the 100 MHz
+ * s_memrealtime); blocks the caller for those 20 us plus the launch, not the context's stream */
+HYDAMD_EXPORT int hydamd_debug_shader_clock_mhz(HydAmdContext *ctx, double *mhz);
 
 /* ---- parity / debug read-backs ---- */
 HYDAMD_EXPORT int hydamd_read_symbol_counts(HydAmdContext *ctx, int slot, uint32_t counts[HYDAMD_GROUPS_PER_LFG]);

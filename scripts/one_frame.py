@@ -1,6 +1,7 @@
 """A few 8192x8192 RGB16 photo frames, one at a time, through the device-level API: the command
 rocprofv3 wraps for per-kernel traces and PMC passes (scripts/collect_pmc.sh).
-usage: python scripts/one_frame.py [frames] [rans form] [lf coder mode]"""
+usage: python scripts/one_frame.py [frames] [rans form] [lf coder mode] [times]
+(a fourth argument prints every stage's time by the library's own event timers)"""
 import os
 import sys
 
@@ -20,3 +21,11 @@ with device.DeviceContext(0, 16, 0) as ctx:
         ctx.encode_image_tensor(img)
         ctx.sync()
     print(ctx.payload_size(), "section bytes")
+    if len(sys.argv) > 4:
+        ctx.profile(True)
+        for _ in range(8):
+            ctx.encode_image_tensor(img)
+            ctx.sync()
+        for k, (ms, n) in ctx.profile_read().items():
+            if n:
+                print(f"   {k:24s} {ms / n:.4f} ms")

@@ -29,6 +29,8 @@ ap.add_argument("--height", type=int, default=0, help="frame height if not squar
 ap.add_argument("--no-bind", action="store_true")
 ap.add_argument("--only-transform", action="store_true", help="enqueue the transform stage only (no entropy stage, no LF coder)")
 ap.add_argument("--batch", type=int, default=1, help="frames per launch group (hydamd_encode_image_batch)")
+ap.add_argument("--cohort", type=int, default=0, help="> 0: drain every context after this many launch groups (does a restart bring the fast first phase back?)")
+ap.add_argument("--clock", type=int, default=0, help="> 0: sample the shader clock (hydamd_debug_shader_clock_mhz) every this many launch groups")
 ap.add_argument("--lanes", type=int, default=0, help="> 0: this many HIP streams, contexts dealt to them in turn (several contexts per stream)")
 a = ap.parse_args()
 if not a.no_bind:
@@ -60,6 +62,7 @@ for rep in range(a.reps):
     t0 = time.perf_counter()
     n = 4 * S + a.frames + S
     first = 0.0
+    clocks = []
     for i in range(n):
         th = time.perf_counter()
         if a.only_transform:
@@ -73,6 +76,11 @@ for rep in range(a.reps):
         e = torch.cuda.Event(enable_timing=True)
         e.record(ext[i % S])
         evs.append(e)
+        if a.cohort and i % a.cohort == a.cohort - 1:
+            for c in ctxs:
+                c.sync()
+        if a.clock and i % a.clock == a.clock - 1:
+            clocks.append(round(ctxs[0].shader_clock_mhz()))
     t_issue = time.perf_counter() - t0
     for c in ctxs:
         c.sync()
@@ -88,6 +96,8 @@ for rep in range(a.reps):
     chunk = 2 * S
     marks = [sum(done[k - w:k]) / w for k in range(4 * S, len(done) + 1, chunk)]
     trend = " ".join(f"{a.size * H * a.batch * chunk / (marks[j + 1] - marks[j]) / 1e6:.0f}" for j in range(len(marks) - 1))
+    if clocks:
+        print("   shader clock, MHz, every", a.clock, "launch groups:", " ".join(str(c) for c in clocks), flush=True)
     print(f"   Gpixel/s in successive chunks of {chunk} launch groups: {trend}", flush=True)
     vals = [a.size * H * a.batch * chunk / (marks[j + 1] - marks[j]) / 1e6 for j in range(len(marks) - 1)]
     if len(vals) >= 8:
@@ -96,3 +106,5 @@ for rep in range(a.reps):
     print(f"batch {a.batch} lanes {a.lanes} streams {S} profile {a.profile} lf {a.lf} rans {a.rans}: {ms:.4f} ms/frame = {a.size * H / ms / 1e6:.1f} Gpixel/s; "
           f"host enqueue {host / n * 1e3:.3f} ms/frame (first 3 per stream, unblocked: {first * 1e3:.3f}), issue loop {t_issue / n * 1e3:.3f} ms/frame, wall {wall / n * 1e3:.3f} ms/frame",
           flush=True)
+    if a.profile:  # every stage's duration as it runs INSIDE the loop, sharing the chip (event timers, context 0)
+        print("   stage times in the loop: " + ", ".join(f"{k} {ms / n:.3f} ms" for k, (ms, n) in ctxs[0].profile_read().items() if n), flush=True)

@@ -1,18 +1,11 @@
-python scripts/k1_variants.py --run --rounds 1 nog 2>&1 | tail -3
-for lib in before_u8 nog; do
-HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$lib.so python - <<PY
-import torch, hashlib
-from hydrium_amd import device, synth
-img = synth.make_image("photo", 8192, 8192, 8, device=torch.device("cuda", 0))
-with device.DeviceContext(0, 16, 0) as ctx:
-    ctx.set_rans_waves(5); ctx.set_lf_coder(0)
-    ctx.encode_image_tensor(img); ctx.sync()
-    md5 = hashlib.md5(ctx.read_payload()).hexdigest()[:12]
-    ctx.profile(True)
-    for _ in range(6):
-        ctx.encode_image_tensor(img); ctx.sync()
-    ms, n = ctx.profile_read()["transform_tokenize"]
-    print("$lib RGB8 8192x8192: K1", round(ms / n, 4), "ms, sections md5", md5)
+pp() { GPU_MAX_HW_QUEUES=22 timeout 300 python scripts/pipe_probe.py --reps 1 --frames 512 --streams 32 "$@" 2>&1 | grep -E "SUSTAINED|stage times" | cut -c60-400; }
+python -m pytest tests/test_gpu_device_parity.py tests/test_gpu_full_size.py -x -q -m gpu 2>&1 | tail -3
+for r in 1 2; do for f in 5 6; do echo -n "form $f B=2: "; pp --batch 2 --rans $f; done; done
+python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/bench.json
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench.json"))
+print(d["value"], d["timing"], d.get("value_by_the_method_of_rounds_1_to_3"))
+for k in ("one_frame_per_launch_group","hf_sections_only","finished_file_per_step","batch_4k_device","batch_4k","shard_16k","single_frame_form5"):
+    print(k, json.dumps(d["config"].get(k) if k in d.get("config",{}) else d.get(k))[:400])
 PY
-done
-timeout 900 python -m pytest tests/test_gpu_device_parity.py tests/test_gpu_api_parity.py -x -q 2>&1 | grep -E "passed|failed"

@@ -164,7 +164,7 @@ def test_planar_and_strided_inputs(image):
         assert ctx.read_payload() == res.stream
 
 
-@pytest.mark.parametrize("form", [4, 5])
+@pytest.mark.parametrize("form", [4, 5, 6])
 def test_frame_that_outgrows_its_buffers_is_rerun_transparently(form):
     """Token arrays and the payload are sized for typical content; a noise frame (2.9 symbols and 1.8
     bytes per pixel) overflows both on the device and hydamd_sync() reruns it with the hard maxima."""
@@ -197,7 +197,7 @@ print("ok")
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("form", [4, 5])
+@pytest.mark.parametrize("form", [4, 5, 6])
 @pytest.mark.parametrize("num_presets,scheme", [(28, 0), (29, 1), (85, 1), (86, 2), (127, 2), (129, 3), (255, 3)])
 def test_every_cluster_scheme_on_the_device(image, num_presets, scheme, form):
     """the 2- and 1-cluster-per-preset maps (frames of 86 to 255 LF groups, reference

@@ -44,7 +44,7 @@ def test_c3_8192_rgb16_all_paths_agree():
     assert multigpu.encode_serial(t, 4) == whole                      # 4 shards
     payloads = []
     with device.DeviceContext(0, 16, 0) as ctx:
-        for form in (4, 5):                                # both entropy-stage forms
+        for form in (4, 5, 6):                             # every entropy-stage form
             ctx.set_rans_waves(form)
             ctx.encode_image_tensor(t)
             ctx.sync()

@@ -26,12 +26,14 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# Frames in flight live on HIP streams of their own, which the runtime deals to GPU_MAX_HW_QUEUES hardware queues.  The loop
-# sits at the knee between two bounds: the transform kernels' instruction issue (capacity) and frames in flight
-# over a frame's time in its stream (latency: 2.5 ms of it is the serial rANS chain).  Round 4 scan on one box
-# (profiles/r04_queue_stream_scan.txt): 16 contexts on 20 queues 133-134 Gpixel/s; 32 contexts on 22 queues 141-143 (on a
-# faster box of the pool 155); 24-48 contexts on 20-28 queues 130-139; 64 queues and more 31-64 (the firmware time-slices
-# hardware queues beyond its slots).  More frames in flight than queues keep every queue's next frame already queued.
+# Frames in flight live on HIP streams of their own, which the runtime deals to GPU_MAX_HW_QUEUES hardware queues in
+# rotation, every stream the process creates taking a turn whether it carries work or not.  Until a context's LF side
+# stream became lazy (device_api.hip ensure_lf_stream) the contexts' main streams sat on every second queue and the best
+# shape was an accident of the rotation (32 contexts on 22 queues, 140 Gpixel/s; 24 on 22: 118).  With one stream per
+# context the loop is flat: 12-20 contexts, each on a queue of its own (20-28 queues), two frames per launch group:
+# 145-149 Gpixel/s sustained (profiles/r04_queue_stream_scan.txt).  MORE THAN 22 QUEUES IN USE and the firmware
+# time-slices them: the host-pointer batch leg (8-10 encoder threads, each context a kernel stream and an LF side stream,
+# plus the shared upload streams) runs 1400 frames/s on 20-22 queues and 500 on 24-28.  So: 22 queues, 16 contexts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "22")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -54,7 +56,7 @@ def parse():
     ap.add_argument("--size", type=int, default=8192, help="frame edge in pixels (per GPU)")
     ap.add_argument("--depth", type=int, default=16, choices=(8, 16))
     ap.add_argument("--kind", default="photo")
-    ap.add_argument("--streams", type=int, default=32, help="frames in flight (one context + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=16, help="contexts (one HIP stream each), frames-per-launch-group frames in flight on each")
     ap.add_argument("--rans-waves", type=int, default=6, choices=(4, 5, 6),
                     help="entropy-stage form, see hydamd_set_rans_waves: 5 = one lane per group, a wavefront per LF group "
                          "(throughput); 6 = the same with packed tables (62 KB of LDS per chain, not 80: +4 %% in the pipelined loop, "
@@ -80,7 +82,7 @@ def parse():
                          "the blobs (round 2)")
     ap.add_argument("--shard-depth", type=int, default=4, help="--mode shard: frames in flight (a context per frame and rank)")
     ap.add_argument("--frames", type=int, default=64, help="--mode batch: frames in the batch")
-    ap.add_argument("--threads", type=int, default=8, help="--mode batch: host threads (encoders) per GPU (the library parks at most 8 device contexts)")
+    ap.add_argument("--threads", type=int, default=10, help="--mode batch: host threads (encoders) per GPU (scan in profiles/r04_batch_host_scan.txt: 8 / 10 / 12 / 16 threads 1456 / 1568 / 1521 / 1376 frames/s)")
     ap.add_argument("--no-legs", action="store_true",
                     help="frame mode: leave out the configs[3] / configs[4] legs (shard_16k, batch_4k) and the LF-off leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1029,8 +1031,9 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             return shard_leg(args, 40, 4, 16384, assemble=args.assemble)
 
-        for name, fn in (("batch_4k_device", lambda: batch_device_leg(args, args.frames)),
-                         ("batch_4k", lambda: batch_leg(args, args.frames, args.threads)), ("shard_16k", shard_16k)):
+        # configs[4] is a batch of 64 frames: 18 ms / 45 ms of work, too short to time; eight batches back to back
+        for name, fn in (("batch_4k_device", lambda: batch_device_leg(args, 8 * args.frames)),
+                         ("batch_4k", lambda: batch_leg(args, 8 * args.frames, args.threads)), ("shard_16k", shard_16k)):
             try:
                 t_leg = time.perf_counter()
                 r = fn()

@@ -641,6 +641,10 @@ static int asm_alloc(HydkAsm *a) {
     ASM_TRY(a, hipMalloc(&a->S.done, sizeof(uint32_t)));
     ASM_TRY(a, hipMemset(a->S.err, 0, sizeof(uint32_t)));
     ASM_TRY(a, hipMemset(a->S.done, 0, sizeof(uint32_t)));
+    /* hipMemset of device memory returns before it has run, in the NULL stream, which non-blocking streams do not wait
+     * for: without this wait the first frame's kernels can pass the memsets (seen as a "malformed blob" once the
+     * caller's stream and the null stream sat on different hardware queues) */
+    ASM_TRY(a, hipStreamSynchronize(nullptr));
     ASM_TRY(a, hipMalloc(&a->S.result, 2 * sizeof(uint64_t)));
     ASM_TRY(a, hipHostMalloc((void **)&a->h_result, 2 * sizeof(uint64_t), hipHostMallocDefault));
     a->h_result[0] = a->h_result[1] = 0;

@@ -192,6 +192,7 @@ struct HydAmdContext {
     int staging_next = 0;
     /* uploads run on their own stream so that tile n + 1 is copied while tile n's transform kernel runs */
     hipStream_t copy_stream = nullptr;
+    bool copy_stream_shared = false; /* one of the device's shared upload streams (acquire_copy_stream): not this context's to destroy */
     hipEvent_t frame_fence = nullptr; /* recorded on the main stream at hydamd_begin_frame */
     bool copy_needs_fence = false;
 
@@ -385,6 +386,35 @@ int record_lf_group(HydAmdContext *ctx, int slot, const void *const src[3], ptrd
     return ST_OK;
 }
 
+/* Upload streams.  The uploads of all contexts end up on the same few DMA engines, and every stream a process creates
+ * takes a turn in the runtime's rotation over the hardware queues (more active streams than about 22 queues and the
+ * firmware time-slices: a batch of encoder threads, each with a kernel stream, an upload stream and an LF side stream,
+ * fell from 1400 to 500 frames/s at 24).  So the contexts of a device share HYDAMD_COPY_STREAMS upload streams
+ * (default 4, dealt in turn; 0 = one per context, as until round 4).  Ordering is by the contexts' own events. */
+constexpr int kMaxSharedCopyStreams = 8;
+static std::mutex g_copy_lock;
+static hipStream_t g_copy_streams[HYDAMD_MAX_PEERS * 2][kMaxSharedCopyStreams];
+static unsigned g_copy_next[HYDAMD_MAX_PEERS * 2];
+
+int acquire_copy_stream(HydAmdContext *ctx) {
+    static const int shared = [] {
+        const char *v = getenv("HYDAMD_COPY_STREAMS");
+        const int n = v && *v ? atoi(v) : 4;
+        return n < 0 ? 0 : n > kMaxSharedCopyStreams ? kMaxSharedCopyStreams : n;
+    }();
+    if (!shared || ctx->device < 0 || ctx->device >= HYDAMD_MAX_PEERS * 2) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        return ST_OK;
+    }
+    std::lock_guard<std::mutex> hold(g_copy_lock);
+    const unsigned k = g_copy_next[ctx->device]++ % (unsigned)shared;
+    if (!g_copy_streams[ctx->device][k])
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&g_copy_streams[ctx->device][k], hipStreamNonBlocking));
+    ctx->copy_stream = g_copy_streams[ctx->device][k];
+    ctx->copy_stream_shared = true;
+    return ST_OK;
+}
+
 int ensure_staging(HydAmdContext *ctx, size_t tile_bytes) {
     if (tile_bytes <= ctx->staging_cap)
         return ST_OK;
@@ -393,8 +423,11 @@ int ensure_staging(HydAmdContext *ctx, size_t tile_bytes) {
      * if their transform kernels have not run yet (HYDAMD_EAGER=0) or have to run again (a frame that
      * outgrows its token arrays, or whose token records are widened for a float tile). */
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (!ctx->copy_stream) /* created on first use: device-pointer users never need it */
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->copy_stream) { /* taken on first use: device-pointer users never need it */
+        const int st = acquire_copy_stream(ctx);
+        if (st != ST_OK)
+            return st;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
     for (int i = 0; i < kStaging; i++) {
         if (ctx->pinned[i])
@@ -609,7 +642,8 @@ void hydamd_destroy(HydAmdContext *ctx) {
     drain_timers(ctx);
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
-        (void)hipStreamDestroy(ctx->copy_stream);
+        if (!ctx->copy_stream_shared)
+            (void)hipStreamDestroy(ctx->copy_stream);
     }
     if (ctx->frame_fence)
         (void)hipEventDestroy(ctx->frame_fence);
@@ -812,7 +846,9 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_lf_total_pinned, sizeof(unsigned long long), hipHostMallocDefault));
     *ctx->h_lf_total_pinned = 0;
     HIP_TRY(ctx, hipMemset(ctx->lf_streams, 0, (slots + 1) * sizeof(HydkLfStream)));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lf_stream, hipStreamNonBlocking));
+    /* lf_stream: created on first use (ensure_lf_stream).  A stream takes a place in the runtime's rotation over the
+     * hardware queues whether it ever carries work or not: thirty-two contexts that code their LF groups in their own
+     * stream would put their main streams on every second queue only */
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->frame_fence, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_fork, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_join, hipEventDisableTiming));
@@ -827,6 +863,9 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_status_pinned, sizeof(uint32_t), hipHostMallocDefault));
     HIP_TRY(ctx, hipMemset(ctx->group_bits, 0, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMemset(ctx->sym_count, 0, slots * G * sizeof(uint32_t)));
+    /* the memsets above run in the NULL stream and return before they have run; the context's own stream is
+     * non-blocking and does not wait for that stream: wait here, once, or its first kernels may pass them */
+    HIP_TRY(ctx, hipStreamSynchronize(nullptr));
     if (debug_planes) {
         HIP_TRY(ctx, hipMalloc(&ctx->dbg_xyb, 3 * kDbgPlane * sizeof(float)));
         HIP_TRY(ctx, hipMalloc(&ctx->dbg_dct, 3 * kDbgPlane * sizeof(float)));
@@ -1141,7 +1180,18 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
 /* The LF coder's token and code kernels for slots [first, first + count), whose transform kernels
  * are already enqueued.  It needs only the LF ints they write: forked onto its own stream so that it
  * overlaps the HF entropy stage; join_lf brings the streams back together. */
+static int ensure_lf_stream(HydAmdContext *ctx) {
+    if (!ctx->lf_stream)
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lf_stream, hipStreamNonBlocking));
+    return ST_OK;
+}
+
 static int lf_range(HydAmdContext *ctx, int first, int count, bool forked) {
+    if (forked) {
+        const int st = ensure_lf_stream(ctx);
+        if (st != ST_OK)
+            return st;
+    }
     hipStream_t where = forked ? ctx->lf_stream : ctx->stream;
     ctx->status_published = false;
     if (forked) {
@@ -1945,6 +1995,11 @@ int hydamd_debug_lf_code(HydAmdContext *ctx, const uint32_t hist[HYDAMD_LF_CODES
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t spare = (size_t)ctx->max_slots; /* the scratch entry behind the frame's slots */
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        const int st = ensure_lf_stream(ctx);
+        if (st != ST_OK)
+            return st;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->lf_stream));
     uint32_t *d_hist = ctx->lf_hist + spare * HYDK_LF_CODES;
     HIP_TRY(ctx, hipMemcpy(d_hist, hist, HYDK_LF_CODES * sizeof(uint32_t), hipMemcpyHostToDevice));

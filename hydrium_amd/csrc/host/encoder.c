@@ -482,7 +482,7 @@ static void drain(HYDEncoder *e) {
  * take the parked total over HYDAMD_CONTEXT_CACHE_MB (default 8192 MB of device memory, counted at 50 MB
  * per slot + staging); HYDAMD_CONTEXT_CACHE=0 turns the parking off and hydamd_trim_cache() empties it.
  * ------------------------------------------------------------------------------------------- */
-#define CTX_POOL_MAX 8
+#define CTX_POOL_MAX 32
 typedef struct ParkedCtx {
     HydAmdContext *ctx;
     size_t slots;

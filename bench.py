@@ -80,7 +80,10 @@ def parse():
                     help="--mode shard: where the frame is put together — on the assembling rank's GPU, into device memory and then "
                          "one D2H copy (default), or written straight into pinned host memory by the kernel; or on its host from "
                          "the blobs (round 2)")
-    ap.add_argument("--shard-depth", type=int, default=4, help="--mode shard: frames in flight (a context per frame and rank)")
+    ap.add_argument("--shard-depth", type=int, default=0,
+                    help="--mode shard: frames in flight (a context per frame and rank, sized for the rank's LF groups); 0 = 8 on one GPU "
+                         "(scan 4 / 6 / 8 / 10 / 12: 2.45 / 1.97 / 1.90 / 1.95 / 1.86 ms per 16K frame), 12 on two, 16 on four and more: a "
+                         "rank's transform stage shrinks with N, its 2.5 ms rANS chains do not")
     ap.add_argument("--frames", type=int, default=64, help="--mode batch: frames in the batch")
     ap.add_argument("--threads", type=int, default=10, help="--mode batch: host threads (encoders) per GPU (scan in profiles/r04_batch_host_scan.txt: 8 / 10 / 12 / 16 threads 1456 / 1568 / 1521 / 1376 frames/s)")
     ap.add_argument("--no-legs", action="store_true",
@@ -152,11 +155,11 @@ def shard_leg(args, steps, warmup, size=16384, kind=None, assemble="device"):
     dev = torch.device("cuda", local)
     slab = synth.make_image(kind, W, band_h, depth, x0=0, y0=y0, device=dev)
     origin = lambda lf: ((lf // lfx) * 2048 - y0, (lf % lfx) * 2048)
-    depth_in_flight = max(2, args.shard_depth)
+    depth_in_flight = max(2, args.shard_depth) if args.shard_depth else (8 if world == 1 else 12 if world == 2 else 16)
     shards = [multigpu.Shard(local, mine, W, H) for _ in range(depth_in_flight)]
     for sh in shards:
         if sh.ctx:
-            sh.ctx.set_rans_waves(min(args.rans_waves, 5))  # one frame at a time per set of contexts: the chains' own speed counts
+            sh.ctx.set_rans_waves(args.rans_waves if args.mode == "shard" else min(args.rans_waves, 5))  # one frame at a time per set of contexts: the chains' own speed counts
             # the LF coder in the context's own stream (its code construction rides in the chain kernel's launch): one
             # stream per frame in flight, as in frame mode — side streams alias onto the hardware queues of other frames
             sh.ctx.set_lf_coder(2)
@@ -255,6 +258,12 @@ def shard_leg(args, steps, warmup, size=16384, kind=None, assemble="device"):
     dist.barrier()
     dt = time.perf_counter() - t0
     host_timed = (host_ms[0], host_ms[1])
+    if os.environ.get("HYDAMD_DEBUG_D2H"):  # per frame: host time issuing the copy, the copy's own duration, host time waiting for it
+        dbg = multigpu.FrameAssembly._dbg
+        issue = [x for x in dbg if len(x) == 4][-16:]
+        print("D2H issue, host ms:", " ".join(f"{x[0] * 1e3:.2f}" for x in issue), file=sys.stderr)
+        print("D2H copy, stream ms:", " ".join(f"{x[1].elapsed_time(x[2]):.2f}" for x in issue), file=sys.stderr)
+        print("D2H wait, host ms:", " ".join([f"{x[0] * 1e3:.2f}" for x in dbg if len(x) == 1][-16:]), file=sys.stderr)
     checking[0] = True
     while handles:
         i, digest = collect()

@@ -204,8 +204,12 @@ class FrameAssembly:
     def _allocate(self, capacity: int):
         import torch
 
+        capacity = (capacity + 255) & ~255
         self.out = (torch.empty(capacity, dtype=torch.uint8).pin_memory() if self.pinned
                     else torch.empty(capacity, dtype=torch.uint8, device=torch.device("cuda", self.dev_index)))
+        # the landing buffer now, not at the first copy: pinning 64 MB takes tens of milliseconds (with eight frames in
+        # flight, five of the eight first copies used to fall inside bench.py's timed interval)
+        self._host = None if self.pinned else torch.empty(capacity, dtype=torch.uint8).pin_memory()
 
     @staticmethod
     def supports(width: int, height: int) -> bool:
@@ -223,7 +227,7 @@ class FrameAssembly:
             # overwrite it wait for it on the device
             import torch
 
-            torch.cuda.current_stream().wait_stream(self._copy_stream)
+            torch.cuda.current_stream().wait_event(self._copied)
         self.asm.plan(self.md, [list(p) for _, p in keep], icc=self.icc)
         self.asm.run_tensors([r for r, _ in keep], self.out)
 
@@ -232,37 +236,71 @@ class FrameAssembly:
         self.size = self.asm.result()
         return self.out[:self.size]
 
+    _dbg = []
+    _copy_streams = {}  # device index -> the one D2H stream of that device
+
     def start_copy(self):
-        """Device output: start the one D2H copy of the finished frame on a stream of its own (the frame is
-        complete: finish() came after the stream's synchronisation), so that it overlaps the next frames' kernels."""
+        """Device output: start the one D2H copy of the finished frame (the frame is complete: finish() came after the
+        stream's synchronisation), so that it overlaps the next frames' kernels.
+        * The copy's length is rounded up to 256 bytes (the buffers have the room): a length that is not a multiple of
+          four sends the runtime down its shader-copy path (__amd_rocclr_copyBuffer in 3 MB pieces), which gets
+          2-7 GB/s beside the transform kernels; the DMA engines do 56 GB/s whatever the CUs do (scripts/d2h_probe.py,
+          scripts/ubench/d2h_kernel.hip).
+        * All assemblies of a device share ONE copy stream — the copies follow each other on the link anyway, a stream
+          per frame in flight takes a hardware queue each — and each has an event of its own to wait for."""
         import os
 
         import torch
 
         if self.pinned or os.environ.get("HYDAMD_BENCH_SKIP_D2H"):  # (the switch exists to measure what the copy costs)
             return
-        if getattr(self, "_host", None) is None or self._host.numel() < self.size:
-            self._host = torch.empty(max(self.size, self.out.numel()), dtype=torch.uint8).pin_memory()
+        if getattr(self, "_host", None) is None or self._host.numel() < self.out.numel():
+            self._host = torch.empty(self.out.numel(), dtype=torch.uint8).pin_memory()
         if getattr(self, "_copy_stream", None) is None:
-            self._copy_stream = torch.cuda.Stream(device=torch.device("cuda", self.dev_index))
+            if self.dev_index not in FrameAssembly._copy_streams:
+                FrameAssembly._copy_streams[self.dev_index] = torch.cuda.Stream(device=torch.device("cuda", self.dev_index))
+            self._copy_stream = FrameAssembly._copy_streams[self.dev_index]
+            self._copied = torch.cuda.Event()
+        n = min(self.out.numel() & ~255, (self.size + 255) & ~255)
+        dbg = os.environ.get("HYDAMD_DEBUG_D2H")
+        if dbg:
+            import time
+            t0 = time.perf_counter()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(self._copy_stream):
-            self._host[:self.size].copy_(self.out[:self.size], non_blocking=True)
+            if dbg:
+                e0.record(self._copy_stream)
+            self._host[:n].copy_(self.out[:n], non_blocking=True)
+            if dbg:
+                e1.record(self._copy_stream)
+            self._copied.record(self._copy_stream)
+        if dbg:
+            FrameAssembly._dbg.append((time.perf_counter() - t0, e0, e1, n))
+        self._copying = True
 
     def to_host(self):
         """The finished frame in pinned host memory: the output buffer itself, or the copy start_copy() began
         (started here if it was not)."""
+        import os
+
         if self.pinned:
             return self.out[:self.size]
-        if getattr(self, "_copy_stream", None) is None or getattr(self, "_host", None) is None:
+        if not getattr(self, "_copying", False):
             self.start_copy()
         if getattr(self, "_copy_stream", None) is None:
             return self.out[:self.size]
-        self._copy_stream.synchronize()
+        if os.environ.get("HYDAMD_DEBUG_D2H"):
+            import time
+            t0 = time.perf_counter()
+            self._copied.synchronize()
+            FrameAssembly._dbg.append((time.perf_counter() - t0,))
+        self._copied.synchronize()
+        self._copying = False
         return self._host[:self.size]
 
     def close(self):
         self.asm.close()
-        self.out = self._host = self._copy_stream = None  # device blocks torch handed out under a context's stream go back before that stream dies
+        self.out = self._host = self._copy_stream = self._copied = None  # device blocks torch handed out under a context's stream go back before that stream dies
 
 
 def enqueue_frame(engine, parts, capacity: int, group=None, to_rank=0, assembly: Optional["FrameAssembly"] = None,

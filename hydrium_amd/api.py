@@ -203,9 +203,12 @@ def tile_dims(width: int, height: int, shift_x: int, shift_y: int):
 
 def encode_image(lib: Library, img: np.ndarray, *, linear_light: int = 0, shift_x: int = -1, shift_y: int = -1,
                  out_buf_size: int = 1 << 20, layout: str = "packed", order=None, icc: Optional[bytes] = None,
-                 explicit_last: bool = False, out_buf=None, tile_pipeline: Optional[int] = None) -> bytes:
+                 explicit_last: bool = False, out_buf=None, tile_pipeline: Optional[int] = None, in_place: bool = False):
     """Encode a whole (H, W, 3) image the way the reference CLI does; returns the codestream.
-    ``tile_pipeline``: tile-mode frames in flight (this build only; None leaves the default, one frame per call)."""
+    ``tile_pipeline``: tile-mode frames in flight (this build only; None leaves the default, one frame per call).
+    ``in_place``: with an ``out_buf`` that took the whole file in one piece, return a memoryview of it instead of a bytes
+    copy — where a C caller finds its file when hyd_release_output_buffer has returned (a 12 MB bytes object costs
+    Python a millisecond)."""
     h, w, _ = img.shape
     src = img[::-1].copy() if layout == "flipped" else img
     tw, th = tile_dims(w, h, shift_x, shift_y)
@@ -230,8 +233,11 @@ def encode_image(lib: Library, img: np.ndarray, *, linear_light: int = 0, shift_
                 code, n = enc.release_output()
                 enc.check(code)
                 if n:
-                    chunks.append(C.string_at(buf, n))
+                    whole = in_place and out_buf is not None and not chunks and ret != HYD_NEED_MORE_OUTPUT and i == len(tiles) - 1
+                    chunks.append(n if whole else C.string_at(buf, n))  # (whole: nothing else will be written to buf)
                 enc.check(enc.provide_output(buf))
                 if ret != HYD_NEED_MORE_OUTPUT:
                     break
+    if len(chunks) == 1 and isinstance(chunks[0], int):
+        return memoryview(buf).cast("B")[:chunks[0]]
     return chunks[0] if len(chunks) == 1 else b"".join(chunks)

@@ -1,4 +1,8 @@
-s() { timeout 300 python bench.py --mode shard --steps 60 "$@" 2>gpurun_out/err.txt | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d.get('host_ms_per_frame'), d.get('assembled_frames_identical_to_host_assembly'))"; }
-for d in 4 6 8 10 12; do echo -n "depth $d: "; s --shard-depth $d; done
-echo -n "depth 8 form 5: "; s --shard-depth 8 --rans-waves 5
-echo -n "depth 8 pinned: "; s --shard-depth 8 --assemble device-pinned
+python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/bench.json
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench.json"))
+print(d["value"], d["timing"]["Mpixel/s_each_window"], d.get("value_by_the_method_of_rounds_1_to_3"))
+for k in ("one_frame_per_launch_group","hf_sections_only","finished_file_per_step","batch_4k_device","batch_4k","shard_16k","single_frame_form5","api_end_to_end"):
+    print(k, json.dumps(d["config"].get(k) if k in d.get("config",{}) else d.get(k))[:300])
+PY

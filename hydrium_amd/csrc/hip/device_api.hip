@@ -1601,7 +1601,8 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
             static const int lds = getenv("HYDAMD_DEBUG_SLEEP_LDS") ? atoi(getenv("HYDAMD_DEBUG_SLEEP_LDS")) : 0;
             if (lds > 65536)
                 (void)hipFuncSetAttribute((const void *)k_sleep_probe, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipLaunchKernelGGL(k_sleep_probe, dim3(wgs > 0 ? wgs * count : 1), dim3(64), (size_t)lds, ctx->stream, 250000ull);
+            static const unsigned long long ticks = getenv("HYDAMD_DEBUG_SLEEP_US") ? 100ull * strtoull(getenv("HYDAMD_DEBUG_SLEEP_US"), nullptr, 10) : 250000ull;
+            hipLaunchKernelGGL(k_sleep_probe, dim3(wgs > 0 ? wgs * count : 1), dim3(64), (size_t)lds, ctx->stream, ticks);
         } else if (debug_skip() & 2) {
         } else if (lanes) {
             HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, ctx->sym_count + g0, ctx->tables + first,

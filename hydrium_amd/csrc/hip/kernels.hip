@@ -530,6 +530,8 @@ __device__ __forceinline__ void store_record(void *tok, uint32_t at, uint32_t to
 
 #ifdef HYDK_K1_WAVES_EXACT /* register allocation padded so that exactly this many wavefronts fit a SIMD (occupancy experiments) */
 #define HYDK_K1_OCCUPANCY __attribute__((amdgpu_waves_per_eu(HYDK_K1_WAVES_EXACT, HYDK_K1_WAVES_EXACT))) __launch_bounds__(kThreads)
+#elif defined(HYDK_K1_NUM_VGPR) /* a register budget below what four wavefronts per SIMD allow: room beside them for another kernel's wavefront */
+#define HYDK_K1_OCCUPANCY __attribute__((amdgpu_num_vgpr(HYDK_K1_NUM_VGPR))) __launch_bounds__(kThreads, HYDK_K1_WAVES)
 #else
 #define HYDK_K1_OCCUPANCY __launch_bounds__(kThreads, HYDK_K1_WAVES)
 #endif

@@ -1,8 +1,5 @@
-python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/bench.json
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/bench.json"))
-print(d["value"], d["timing"]["Mpixel/s_each_window"], d.get("value_by_the_method_of_rounds_1_to_3"))
-for k in ("one_frame_per_launch_group","hf_sections_only","finished_file_per_step","batch_4k_device","batch_4k","shard_16k","single_frame_form5","api_end_to_end"):
-    print(k, json.dumps(d["config"].get(k) if k in d.get("config",{}) else d.get(k))[:300])
-PY
+pp() { GPU_MAX_HW_QUEUES=22 timeout 300 python scripts/pipe_probe.py --reps 1 --frames 512 --streams 16 --batch 2 --rans 6 "$@" 2>&1 | grep -E "SUSTAINED" | cut -c60-400; }
+for us in 2500 5000; do for lds in 0 24000 45000 64000 92000; do
+echo -n "sleep $us us, $lds B: "; HYDAMD_DEBUG_SKIP=16 HYDAMD_DEBUG_SLEEP_US=$us HYDAMD_DEBUG_SLEEP_LDS=$lds pp
+done; done
+echo -n "real chains: "; pp

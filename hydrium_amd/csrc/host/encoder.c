@@ -493,13 +493,13 @@ static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
 static ParkedCtx g_pool[CTX_POOL_MAX];
 static unsigned long g_stamp;
 
-/* HYDAMD_CONTEXT_CACHE: how many idle contexts may stay parked (default 8, 0 = none): one per
+/* HYDAMD_CONTEXT_CACHE: how many idle contexts may stay parked (default 16, at most 32, 0 = none): one per
  * thread that encodes images back to back is what a batch job wants, one per frame in flight a tile-mode encoder */
 static int ctx_pool_size(void) {
     static int n = -1;
     if (n < 0) {
         const char *v = getenv("HYDAMD_CONTEXT_CACHE");
-        n = v && *v ? atoi(v) : CTX_POOL_MAX;
+        n = v && *v ? atoi(v) : 16;
         if (n < 0)
             n = 0;
         if (n > CTX_POOL_MAX)

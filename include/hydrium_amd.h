@@ -375,7 +375,7 @@ HYDAMD_EXPORT int hydamd_frame_from_streams(const HYDImageMetadata *md, int writ
 HYDAMD_EXPORT void hydamd_free(void *p);
 
 /* hyd_encoder_destroy parks its device context (device memory, pinned staging, streams) for the next
- * encoder of the same shape instead of freeing it — up to HYDAMD_CONTEXT_CACHE contexts (default 8) and
+ * encoder of the same shape instead of freeing it — up to HYDAMD_CONTEXT_CACHE contexts (default 16, at most 32) and
  * HYDAMD_CONTEXT_CACHE_MB megabytes (default 8192) per process.  This releases whatever is parked, and the spare
  * frame buffers hydamd_free may have kept. */
 HYDAMD_EXPORT void hydamd_trim_cache(void);

@@ -58,7 +58,7 @@ def _run(case, devices, extra_env=None, reference=True, **kw):
 
     if reference:
         assert reference_expected()
-    env = dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="20", HYDAMD_DEVICES=devices, HYDAMD_TRACE="1")
+    env = dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="22", HYDAMD_DEVICES=devices, HYDAMD_TRACE="1")
     env.pop("HYDAMD_DEVICE", None)
     env.update(extra_env or {})
     r = subprocess.run([sys.executable, "-c", _ENCODE, json.dumps(dict(case=list(case), reference=reference, **kw))],

@@ -519,3 +519,39 @@ def test_c5_batch_of_4k_frames_on_four_threads_matches_the_reference(lib):
         ref = refprobe.reference_library(optimised=True)
         for k in range(8):
             assert got[k] == hashlib.md5(api.encode_image(ref, imgs[k])).hexdigest(), f"frame {k}"
+
+
+_THREADS = r"""
+import hashlib, threading
+from hydrium_amd import api, synth
+from oracle import refprobe
+imgs = [synth.make_image("photo", 2300, 2100, 8, seed=s) for s in range(3)] + [synth.make_image("photo", 1000, 4100, 16, seed=9).view("uint16")]
+lib = api.Library()
+got = {}
+def work(t):
+    for k in range(6):
+        i = (t + k) % len(imgs)
+        got[(t, k)] = (i, api.encode_image(lib, imgs[i]))
+ts = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+[t.start() for t in ts]; [t.join() for t in ts]
+import os
+assert refprobe.available() or os.environ.get("HYDAMD_ALLOW_ORACLE_ANCHOR") == "1", "oracle/_ref is absent"
+ref = refprobe.reference_library(optimised=True) if refprobe.available() else lib
+want = [api.encode_image(ref, im) for im in imgs]
+assert all(data == want[i] for i, data in got.values())
+print("ok", len(got))
+"""
+
+
+@pytest.mark.parametrize("copy_streams", ["0", "1", "4"])
+def test_upload_streams_shared_by_the_contexts_of_a_device(copy_streams):
+    """round 4: the uploads of all contexts of a device go through HYDAMD_COPY_STREAMS shared streams (0 = a stream per
+    context, as before).  Six encoder threads, six frames each of mixed shapes and sample types, every file against
+    the reference — one shared stream is the hard case: every context's uploads and fences interleave on it."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, HYDAMD_COPY_STREAMS=copy_streams, GPU_MAX_HW_QUEUES="22",
+               PYTHONPATH=os.path.dirname(os.path.dirname(__file__)))
+    r = subprocess.run([sys.executable, "-c", _THREADS], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "ok 36" in r.stdout, r.stdout + r.stderr

@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
             o.x = f ? (f << 20) - 1u : 0xFFFFFFFFu;
             o.y = (&tab->magic[0][0])[at];
             o.z = 0u - f;
-            o.w = (uint32_t)c * HYDK_ANS_SLOTS + (fbv >> 16);
+            o.w = ((uint32_t)c * HYDK_ANS_SLOTS + (fbv >> 16)) << (PACK ? 0 : 1); /* plain table: a byte offset */
             s_ops[i] = o;
         }
     }
@@ -1627,14 +1627,14 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     for (int q = 0; q < 4; q++)
         nx[q] = rj >= 0 ? tok[rj * 4 + q] : uint4{0, 0, 0, 0};
 
-#define HYDK_LANE_SLOT(ei) \
-    (PACK ? (uint32_t)s_lo[ei] | (__builtin_amdgcn_ubfe((uint32_t)s_hi[(ei) >> 1], ((ei) & 1u) << 2, 4u) << 8) : (uint32_t)s_inv[ei])
+/* slot of (symbol, remainder r): o.w is the list's first index (packed planes) or byte offset (plain u16 table) */
+#define HYDK_LANE_SLOT(base, r)                                                                                        \
+    (PACK ? (uint32_t)s_lo[(base) + (r)] | (__builtin_amdgcn_ubfe((uint32_t)s_hi[((base) + (r)) >> 1], (((base) + (r)) & 1u) << 2, 4u) << 8) \
+          : (uint32_t) * (const uint16_t *)((const unsigned char *)s_inv + ((base) + 2u * (r))))
 /* one symbol: record `rec` (position `pos` of the round, walked from 15 down to 0); PRED: the step
  * only counts if VALID (first round of a lane) */
-#define HYDK_LANE_STEP(rec, pos, PRED, VALID)                                                                    \
+#define HYDK_LANE_STEP(o, pos, PRED, VALID)                                                                      \
     do {                                                                                                         \
-        /* the record's symbol is the row of s_ops; beyond the stream's end: stale bytes */                     \
-        const uint4 o = s_ops[(PRED) && !(VALID) ? 0u : (rec) & 0x7FFu]; /* (an LDS read past the table returns 0) */ \
         uint32_t x;                                                                                              \
         /* refill test, renormalised state, and the flag shifted into the round's flag word */                  \
         asm("v_cmp_gt_u32 vcc, %2, %3\n\t"                                                                       \
@@ -1650,46 +1650,55 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
         uint32_t q = __umulhi(x, o.y);                                                                           \
         /* q is floor(x / f) or one less: both candidate remainders, the smaller (unsigned) is x mod f */        \
         const uint32_t r0 = mad24(q, o.z, x);                                                                    \
-        const uint32_t r1 = r0 + o.z;                                                                            \
+        /* r1 = r0 - f; the addition's carry says r0 >= f, which is also what q lacks: one add-with-carry */    \
+        uint32_t r1, q1;                                                                                         \
+        asm("v_add_co_u32 %0, vcc, %2, %3\n\t"                                                                   \
+            "v_addc_co_u32 %1, vcc, 0, %4, vcc"                                                                  \
+            : "=&v"(r1), "=v"(q1)                                                                                \
+            : "v"(r0), "v"(o.z), "v"(q)                                                                          \
+            : "vcc");                                                                                            \
         const uint32_t r = min(r0, r1);                                                                          \
-        q += (int)r1 >= 0;                                                                                       \
-        const uint32_t ei = o.w + r;                                                                             \
-        const uint32_t nstate = (q << 12) | HYDK_LANE_SLOT(ei);                                                  \
+        const uint32_t nstate = (q1 << 12) | HYDK_LANE_SLOT(o.w, r);                                             \
         state = (PRED) && !(VALID) ? state : nstate;                                                             \
     } while (0)
 
-    for (int it = 0; it < rounds; it++) {
-        uint4 cur[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            cur[q] = nx[q];
-        const int rjn = rj - 1;
-        if (rjn >= 0) { /* the next round's line travels during this round's walk */
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                nx[q] = tok[rjn * 4 + q];
-        }
-        if (rj >= 0) {
-            uint32_t fl = 0;
-            uint32_t w16[8];
-            const uint32_t recs[16] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w,
-                                       cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w};
-            if (it == 0) {
-#pragma unroll
-                for (int pos = 15; pos >= 0; pos--)
-                    HYDK_LANE_STEP(recs[pos], pos, true, pos < first_count);
-            } else {
-#pragma unroll
-                for (int pos = 15; pos >= 0; pos--)
-                    HYDK_LANE_STEP(recs[pos], pos, false, true);
-            }
-            aux[rj * 2] = uint4{w16[0], w16[1], w16[2], w16[3]};
-            aux[rj * 2 + 1] = uint4{w16[4], w16[5], w16[6], w16[7]};
-            flags[rj] = (uint16_t)fl; /* bit (p mod 16): symbol p refills */
-            refills += (uint32_t)__popc(fl);
-        }
-        rj = rjn;
-    }
+/* one round = the 16 symbols of one 64-byte line of records.  The first round of a lane is the partial one (FIRST: only
+ * positions below first_count count); it is peeled out of the loop, so that the other rounds carry no selects */
+#define HYDK_LANE_ROUND(FIRST)                                                                                   \
+    do {                                                                                                         \
+        uint4 cur[4];                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) cur[q] = nx[q];                                            \
+        const int rjn = rj - 1;                                                                                  \
+        if (rjn >= 0) { /* the next round's line travels during this round's walk */                             \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) nx[q] = tok[rjn * 4 + q];                              \
+        }                                                                                                        \
+        if (rj >= 0) {                                                                                           \
+            uint32_t fl = 0;                                                                                     \
+            uint32_t w16[8];                                                                                     \
+            const uint32_t recs[16] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w, \
+                                       cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w}; \
+            /* the record's symbol is the row of s_ops (beyond the stream's end: stale bytes; an LDS read past the   \
+             * table returns 0).  All sixteen rows are requested before the walk: a row requested inside its step \
+             * returns behind the step's slot lookup and lengthens every wait */                                 \
+            uint4 ov[16];                                                                                        \
+            _Pragma("unroll") for (int pos = 15; pos >= 0; pos--)                                                \
+                ov[pos] = s_ops[(FIRST) && !(pos < first_count) ? 0u : recs[pos] & 0x7FFu];                      \
+            __builtin_amdgcn_sched_barrier(0); /* (the scheduler would sink the requests back into the steps) */ \
+            _Pragma("unroll") for (int pos = 15; pos >= 0; pos--)                                                \
+                HYDK_LANE_STEP(ov[pos], pos, FIRST, pos < first_count);                                          \
+            aux[rj * 2] = uint4{w16[0], w16[1], w16[2], w16[3]};                                                 \
+            aux[rj * 2 + 1] = uint4{w16[4], w16[5], w16[6], w16[7]};                                             \
+            flags[rj] = (uint16_t)fl; /* bit (p mod 16): symbol p refills */                                     \
+            refills += (uint32_t)__popc(fl);                                                                     \
+        }                                                                                                        \
+        rj = rjn;                                                                                                \
+    } while (0)
+
+    if (rounds > 0)
+        HYDK_LANE_ROUND(true);
+    for (int it = 1; it < rounds; it++)
+        HYDK_LANE_ROUND(false);
+#undef HYDK_LANE_ROUND
 #undef HYDK_LANE_STEP
 #undef HYDK_LANE_SLOT
     if (lane < ngroups) {

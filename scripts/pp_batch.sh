@@ -1,5 +1,4 @@
-pp() { GPU_MAX_HW_QUEUES=22 timeout 300 python scripts/pipe_probe.py --reps 1 --frames 512 --streams 16 --batch 2 --rans 6 "$@" 2>&1 | grep -E "SUSTAINED" | cut -c60-400; }
-for us in 2500 5000; do for lds in 0 24000 45000 64000 92000; do
-echo -n "sleep $us us, $lds B: "; HYDAMD_DEBUG_SKIP=16 HYDAMD_DEBUG_SLEEP_US=$us HYDAMD_DEBUG_SLEEP_LDS=$lds pp
-done; done
-echo -n "real chains: "; pp
+python -m pytest tests/test_gpu_device_parity.py tests/test_gpu_full_size.py -x -q -m gpu 2>&1 | grep -E "passed|failed"
+for f in 5 6; do echo "form $f alone:"; python scripts/one_frame.py 3 $f 2 times 2>&1 | grep -E "rans_encode"; done
+pp() { GPU_MAX_HW_QUEUES=22 timeout 300 python scripts/pipe_probe.py --reps 1 --frames 512 --streams 16 --batch 2 "$@" 2>&1 | grep -E "SUSTAINED" | cut -c60-400; }
+for r in 1 2; do for f in 5 6; do echo -n "form $f loop: "; pp --rans $f; done; done

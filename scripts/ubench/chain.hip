@@ -6,7 +6,7 @@
 #define CK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(err_)); exit(1);} } while (0)
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k(unsigned *out, long long *cyc, int iters, unsigned f, unsigned mg) {
+__global__ __launch_bounds__(64) void k(unsigned *out, long long *cyc, int iters, unsigned f, unsigned mg, int lanes = 64) {
     __shared__ unsigned short tab[8192];
     for (int i = threadIdx.x; i < 8192; i += 64) tab[i] = (unsigned short)((i * 2654435761u) >> 20);
     __syncthreads();
@@ -16,6 +16,7 @@ __global__ __launch_bounds__(64) void k(unsigned *out, long long *cyc, int iters
     const unsigned thr = (f << 20) - 1u;
     const int n2 = -2 * (int)f;
     long long t0 = __builtin_readcyclecounter();
+    if ((int)threadIdx.x < lanes) /* fewer active lanes: does a dependent instruction issue sooner? */
 #pragma unroll 8
     for (int i = 0; i < iters; i++) {
         if (MODE == 0 || MODE == 1) {
@@ -53,6 +54,12 @@ int main() {
 #define RUN(M) RUNG(M, 1) RUNG(M, 1024)
     RUN(0) RUN(1) RUN(2) RUN(3) RUN(4)
     RUNG(0, 4096) RUNG(0, 8192)
+    for (int lanes = 64; lanes >= 8; lanes >>= 1) {
+#define RUNL(M) { hipLaunchKernelGGL(k<M>, dim3(1), dim3(64), 0, 0, out, cyc, iters, 977u, 0xFFFFFFFFu / 977u, lanes); CK(hipDeviceSynchronize()); \
+    CK(hipEventRecord(e0)); hipLaunchKernelGGL(k<M>, dim3(1), dim3(64), 0, 0, out, cyc, iters, 977u, 0xFFFFFFFFu / 977u, lanes); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); \
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("lanes %2d  %-42s %7.2f ns/step\n", lanes, names[M], ms * 1e6 / iters); }
+        RUNL(0) RUNL(2) RUNL(3) RUNL(4)
+    }
     int clk = 0; CK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0));
     int wclk = 0; CK(hipDeviceGetAttribute(&wclk, hipDeviceAttributeWallClockRate, 0));
     printf("device clock %d kHz, wall clock (readcyclecounter) %d kHz\n", clk, wclk);

@@ -51,6 +51,9 @@ hipError_t launch_export(const HydkLfJob *d_jobs, const HydkTables *tabs, const 
 hipError_t launch_rans(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint32_t *bitbuf,
                        uint32_t bit_pitch_words, uint32_t *group_bits, int preset_bits, int num_slots, const uint32_t *status,
                        hipStream_t stream);
+hipError_t launch_rans_deferred(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint16_t *aux,
+                                uint16_t *flags, uint32_t aux_pitch, uint32_t *final_state, uint32_t *group_bits,
+                                int preset_bits, int num_slots, const uint32_t *status, hipStream_t stream);
 hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint16_t *aux,
                              uint16_t *flags, uint32_t aux_pitch, uint32_t *final_state, uint32_t *group_bits, int preset_bits,
                              int nclusters, int num_slots, const uint32_t *status, const uint32_t *lf_hist,
@@ -1559,6 +1562,11 @@ __global__ __launch_bounds__(64) void k_sleep_probe(unsigned long long ticks_100
         __builtin_amdgcn_s_sleep(127);
 }
 } /* namespace */
+/* HYDAMD_WAVE_FORM_EMITS=1: form 4 as until round 4, the chain kernel writing its own bits into the reversed buffers (A/B) */
+static bool wave_form_defers() {
+    static const bool v = !(getenv("HYDAMD_WAVE_FORM_EMITS") && atoi(getenv("HYDAMD_WAVE_FORM_EMITS")) != 0);
+    return v;
+}
 static int debug_skip() {
     static const int v = getenv("HYDAMD_DEBUG_SKIP") ? atoi(getenv("HYDAMD_DEBUG_SKIP")) : 0;
     return v;
@@ -1592,6 +1600,7 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
         for (int i = first; i < first + count; i++)
             any_float = any_float || ctx->h_jobs[i].fmt == HYDK_FMT_F32;
         const bool lanes = ctx->rans_lanes && !any_float;
+        bool emits = lanes; /* the slots' bits are written by k_rans_emit (else: by the chain kernel itself + k_pack_sections) */
         if (with_lf_codes && !lanes)
             return fail(ctx, ST_INTERNAL_ERROR, "LF code construction can only ride with the lane-form entropy stage");
         (void)lanes;
@@ -1612,6 +1621,13 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
                                                  with_lf_codes ? ctx->lf_hist + (size_t)first * HYDK_LF_CODES : nullptr,
                                                  ctx->lf_streams + first, ctx->lf_work + (size_t)first * hydk::lf_work_bytes(),
                                                  ctx->rans_lanes == 2, ctx->stream));
+        } else if (!any_float && wave_form_defers()) {
+            /* wave per group, bits written by k_rans_emit as for the lane form (round 4: the walk no longer stops after
+             * every 64 symbols to scan, pack and store their bits itself) */
+            HIP_TRY(ctx, hydk::launch_rans_deferred(jobs, ctx->sym_count + g0, ctx->tables + first, ctx->rans_aux + g0 * ctx->tok_cap,
+                                                    ctx->rans_flags + g0 * (ctx->tok_cap / 16), ctx->tok_cap, ctx->rans_final + g0,
+                                                    ctx->group_bits + g0, ctx->preset_bits, count, ctx->status, ctx->stream));
+            emits = true;
         } else {
             const int st = ensure_bitbuf(ctx);
             if (st != ST_OK)
@@ -1621,7 +1637,7 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
                                            ctx->group_bits + g0, ctx->preset_bits, count, ctx->status, ctx->stream));
         }
         for (int i = first; i < first + count; i++)
-            ctx->slot_lanes[i] = lanes;
+            ctx->slot_lanes[i] = emits;
     }
     return ST_OK;
 }

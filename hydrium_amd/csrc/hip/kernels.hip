@@ -1333,9 +1333,8 @@ __device__ __forceinline__ uint32_t mad24(uint32_t b, uint32_t c, uint32_t a) {
 
 /* one step of the recurrence; the symbol's operands {-2f, floor(2^32/f), table address, threshold}
  * were staged in LDS by the lane that owns it and arrive by one broadcast ds_read_b128 */
-#define HYDK_RANS_STEP(src)                                                                   \
+#define HYDK_RANS_STEP(o)                                                                     \
     do {                                                                                      \
-        const uint4 o = ops[(src)];                                                           \
         /* lane 0 <- state, lane l <- trail[l-1]: the states file past, newest in lane 0 */   \
         trail = (uint32_t)__builtin_amdgcn_update_dpp((int)state, (int)trail, 0x138, 0xF, 0xF, false); \
         const uint32_t x = rans_renorm(state, o.w);                                           \
@@ -1348,17 +1347,18 @@ __device__ __forceinline__ uint32_t mad24(uint32_t b, uint32_t c, uint32_t a) {
         state = (q << 12) + ent;                                                              \
     } while (0)
 
-template <int WAVES> /* groups (= waves) per workgroup */
+template <int WAVES, bool DEFER> /* groups (= waves) per workgroup; DEFER: the bits are written by k_rans_emit */
 __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
                                                             const HydkTables *tabs, uint32_t *bitbuf_all,
                                                             uint32_t bit_pitch_words, uint32_t *group_bits_all,
-                                                            int preset_bits, const uint32_t *status) {
+                                                            int preset_bits, const uint32_t *status, uint16_t *aux_all,
+                                                            uint16_t *flags_all, uint32_t aux_pitch, uint32_t *final_state_all) {
     constexpr int kThreads = 64 * WAVES;                             /* shadows the file-level constant */
     constexpr int kBlocksPerLfg = HYDK_GROUPS_PER_LFG / WAVES;
     __shared__ uint16_t s_inv[kInvEntries];                          /* 144 KiB */
     __shared__ uint32_t s_fb[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
     __shared__ uint32_t s_magic[HYDK_MAX_CLUSTERS * HYDK_ALPHABET];
-    __shared__ uint32_t s_win[WAVES][kWinWords];
+    __shared__ uint32_t s_win[WAVES][DEFER ? 1 : kWinWords];           /* the bit writer's window (not with DEFER) */
     __shared__ uint4 s_ops[WAVES][64];                               /* per-symbol operands of the chunk being walked */
 
     HYDK_URGENT();
@@ -1447,13 +1447,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
         cur = newcur;
     };
 
-    uint2 rec_next = load_record(tok, n - 1 - lane, wide);
-    for (int hi_p = n - 1; hi_p >= 0; hi_p -= 64) {
+    /* chunks of 64 symbols aligned to the START of the token array: the chunk that holds the stream's end comes first
+     * and is the partial one (so that the refill flags of a chunk are whole 16-bit words of the flag array) */
+    uint16_t *aux = DEFER ? aux_all + G * aux_pitch : nullptr;
+    uint16_t *flags = DEFER ? flags_all + G * (aux_pitch / 16) : nullptr;
+    uint32_t refills = 0;
+    uint2 rec_next = load_record(tok, lane <= ((n - 1) & 63) ? n - 1 - lane : -1, wide);
+    for (int hi_p = n - 1; hi_p >= 0; hi_p = (hi_p & ~63) - 1) {
         /* lane l owns symbol p = hi_p - l; the walk visits lanes 0, 1, 2, ... */
+        const int cnt = (hi_p & 63) + 1;
         const int p = hi_p - lane;
-        const bool valid = p >= 0;
+        const bool valid = lane < cnt;
         const uint2 rec = rec_next;
-        rec_next = load_record(tok, p - 64, wide); /* the next chunk's records travel during this chunk's walk */
+        rec_next = load_record(tok, (hi_p & ~63) - 1 - lane, wide); /* the next chunk's records (a full chunk, or none) travel during this chunk's walk */
         const uint32_t lo = rec.x;
         const uint32_t e = ((lo >> 8) & 0xF) * HYDK_ALPHABET + (lo & 0xFF);
         const uint32_t fbv = s_fb[e];
@@ -1467,27 +1473,65 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
         op.w = thr;
         ops[lane] = op;
         __builtin_amdgcn_wave_barrier();
-        const int cnt = min(64, hi_p + 1);
         uint32_t trail = 0;
         if (cnt == 64) {
+            /* eight steps a block; the next block's operands are requested before this block's walk, so that no
+             * walk starts with an LDS round trip and no slot lookup waits behind operand reads */
+            uint4 nxt[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                nxt[u] = ops[u];
             for (int k = 0; k < 64; k += 8) {
+                uint4 blk[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++)
-                    HYDK_RANS_STEP(k + u);
+                    blk[u] = nxt[u];
+                if (k + 8 < 64) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        nxt[u] = ops[k + 8 + u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    HYDK_RANS_STEP(blk[u]);
             }
         } else {
-            for (int k = 0; k < cnt; k++)
-                HYDK_RANS_STEP(k);
+            for (int k = 0; k < cnt; k++) {
+                const uint4 o1 = ops[k];
+                HYDK_RANS_STEP(o1);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         /* the state seen by step j now sits in lane cnt-1-j; give it back to lane j */
         const uint32_t seen = (uint32_t)__shfl((int)trail, (cnt - 1 - lane) & 63);
-        /* refill p is written just before residue p (entropy.c:1134-1147), i.e. prepended after it */
-        const uint32_t rbits = valid ? (lo >> 16) & 0x3Fu : 0u;
         const bool refill = valid && seen > thr;
-        const unsigned long long residue = rec.y;
-        const unsigned long long val = refill ? (residue << 16) | (seen & 0xFFFFu) : residue;
-        emit(val, rbits + (refill ? 16u : 0u));
+        if (DEFER) {
+            /* the bit writer is another kernel (k_rans_emit, wave-parallel, as for the lane form): leave it the 16 bits
+             * each symbol's refill would send and one flag per symbol, in token order */
+            if (valid)
+                aux[p] = (uint16_t)seen;
+            const unsigned long long by_lane = __ballot(refill);
+            /* lane l holds symbol (p mod 64) = cnt - 1 - l */
+            const unsigned long long by_pos = __builtin_bitreverse64(by_lane) >> (64 - cnt);
+            if (lane < 4 && lane * 16 < cnt)
+                flags[(hi_p >> 6) * 4 + lane] = (uint16_t)(by_pos >> (16 * lane));
+            refills += (uint32_t)__popcll(by_lane);
+        } else {
+            /* refill p is written just before residue p (entropy.c:1134-1147), i.e. prepended after it */
+            const uint32_t rbits = valid ? (lo >> 16) & 0x3Fu : 0u;
+            const unsigned long long residue = rec.y;
+            const unsigned long long val = refill ? (residue << 16) | (seen & 0xFFFFu) : residue;
+            emit(val, rbits + (refill ? 16u : 0u));
+        }
+    }
+    if (DEFER) {
+        if (lane == 0) {
+            final_state_all[G] = state;
+            /* [preset id][final state][per symbol: refill word, residue bits] (encoder.c:945, entropy.c:1127-1147) */
+            group_bits_all[G] = (uint32_t)preset_bits + (n > 0 ? 32u : 0u) + 16u * refills + jobs[slot].rbits_total[g];
+        }
+        return;
     }
     /* [preset id][final state, low half first] precede everything (encoder.c:945, entropy.c:1127-1130) */
     {
@@ -2144,8 +2188,18 @@ hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t 
 hipError_t launch_rans(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint32_t *bitbuf,
                        uint32_t bit_pitch_words, uint32_t *group_bits, int preset_bits, int num_slots, const uint32_t *status,
                        hipStream_t stream) {
-    hipLaunchKernelGGL(k_rans_encode<4>, dim3(num_slots * 16), dim3(256), 0, stream, d_jobs, sym_count, tabs, bitbuf,
-                       bit_pitch_words, group_bits, preset_bits, status);
+    hipLaunchKernelGGL((k_rans_encode<4, false>), dim3(num_slots * 16), dim3(256), 0, stream, d_jobs, sym_count, tabs, bitbuf,
+                       bit_pitch_words, group_bits, preset_bits, status, (uint16_t *)nullptr, (uint16_t *)nullptr, 0u,
+                       (uint32_t *)nullptr);
+    return hipGetLastError();
+}
+
+/* the same walk leaving refill words and flags for k_rans_emit instead of writing bits itself (4-byte records only) */
+hipError_t launch_rans_deferred(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint16_t *aux,
+                                uint16_t *flags, uint32_t aux_pitch, uint32_t *final_state, uint32_t *group_bits,
+                                int preset_bits, int num_slots, const uint32_t *status, hipStream_t stream) {
+    hipLaunchKernelGGL((k_rans_encode<4, true>), dim3(num_slots * 16), dim3(256), 0, stream, d_jobs, sym_count, tabs,
+                       (uint32_t *)nullptr, 0u, group_bits, preset_bits, status, aux, flags, aux_pitch, final_state);
     return hipGetLastError();
 }
 

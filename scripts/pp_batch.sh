@@ -1,4 +1,4 @@
-python -m pytest tests/test_gpu_device_parity.py tests/test_gpu_full_size.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error" | tail -3
-echo "form 4, chain writes its own bits:"; HYDAMD_WAVE_FORM_EMITS=1 python scripts/one_frame.py 3 4 1 times 2>&1 | grep -E "rans_encode|pack_sections"
-echo "form 4, deferred emission:"; python scripts/one_frame.py 3 4 1 times 2>&1 | grep -E "rans_encode|pack_sections"
-python -m pytest tests/test_gpu_api_parity.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error" | tail -3
+for r in 1 2 3; do for f in 5 6; do
+echo -n "form $f: "; python bench.py --rans-waves $f --no-cpu-baseline --no-api 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['timing']['Mpixel/s_each_window'], 'batch_dev', d['batch_4k_device']['frames_per_s'], 'shard', d['shard_16k']['ms_per_step'], 'B1', d['one_frame_per_launch_group']['Mpixel/s'])"
+done; done

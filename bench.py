@@ -902,12 +902,12 @@ def main():
         kernels = {k: {"avg_ms": round(v[0] / max(v[1], 1), 4), "launches": v[1],
                        "algorithmic_GBs": round(bytes_in * groups_profiled / (v[0] / max(v[1], 1) * 1e-3) / 1e9, 1) if v[0] else None}
                    for k, v in kern.items()}
-        # dominant kernel = largest share of the timed interval's kernel time; its roofline figure uses
-        # the duration measured with the kernel running ALONE (single-frame leg of this same run, same
-        # form): per-launch durations inside the interval are co-residency figures (a launch there shares
-        # the GPU with the other streams' kernels and lasts several frame periods)
-        dom = max(kern, key=lambda k: kern[k][0])
+        # dominant kernel = the one that lasts longest with the GPU to itself (single-frame leg of this same run, the
+        # loop's form): the serial rANS chains.  Inside the interval per-launch durations are co-residency figures (a
+        # launch there shares the GPU with the other streams' kernels and lasts several frame periods), and by their sum
+        # the chains and the transform kernel trade places from run to run; roofline_transform_kernel is always K1's.
         alone = (lat5 or {}).get("kernel_avg_ms", {}) if args.rans_waves >= 5 else (lat or {}).get("kernel_avg_ms", {})
+        dom = max(alone, key=lambda k: alone[k]) if alone else max(kern, key=lambda k: kern[k][0])
         dom_ms = alone.get(dom) or kern[dom][0] / max(kern[dom][1], 1)
         achieved = bytes_in / (dom_ms * 1e-3) / 1e9
         k1_ms = alone.get("transform_tokenize")

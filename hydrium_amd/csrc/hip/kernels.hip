@@ -39,15 +39,17 @@ constexpr int kThreads = 256;
 /* Build-time variants of the transform kernel, for A/B measurements (scripts/k1_variants.py; results in
  * profiles/r04_k1_variants.txt and DESIGN.md 3, 9); the defaults are the product.
  *   HYDK_K1_GATHER     bit i set = LUT i of a pixel is a gather from the uploaded table instead of a register evaluation
- *                      (0-2 transfer curve of R, G, B; 3-5 bias curve of L, M, S): one bias gather takes 7 % off the kernel
- *                      alone and nothing off the pipelined loop, more gathers cost more than they save
+ *                      (0-2 transfer curve of R, G, B; 3-5 bias curve of L, M, S).  Default 0x10: the M channel's bias curve
+ *                      through the otherwise idle texture path — photo 0.467 -> 0.424 ms alone, smooth 0.423 -> 0.390,
+ *                      RGB8 photo 0.396 -> 0.375, the pipelined loop +0.7 % (146.7 -> 147.7 Gpixel/s); random-noise pixels,
+ *                      whose indices scatter over the whole 256 KB table, 1.04 -> 1.17.  More gathers cost more than they save.
  *   HYDK_K1_ILP        pixels of a row whose curves are evaluated in lock step (0: one value at a time, as until round 3)
  *   HYDK_K1_WAVELOCAL  a wavefront row-transforms exactly the eight blocks whose columns it transforms next, so no
  *                      workgroup barrier separates the two phases
  *   HYDK_K1_SKIP       timing-only builds that leave a stage out (wrong bytes): 1 token walk, 2 curves, 4 bitmaps, 8 column pass
  *   HYDK_K1_PADLDS / HYDK_K1_WAVES_EXACT   occupancy experiments: extra LDS per workgroup / exactly n wavefronts per SIMD */
 #ifndef HYDK_K1_GATHER
-#define HYDK_K1_GATHER 0
+#define HYDK_K1_GATHER 0x10
 #endif
 #ifndef HYDK_K1_WAVELOCAL
 #define HYDK_K1_WAVELOCAL 1

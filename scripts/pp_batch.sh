@@ -1,4 +1,9 @@
-for r in 1 2 3; do for f in 5 6; do
-echo -n "form $f: "; python bench.py --rans-waves $f --no-cpu-baseline --no-api 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['timing']['Mpixel/s_each_window'], 'batch_dev', d['batch_4k_device']['frames_per_s'], 'shard', d['shard_16k']['ms_per_step'], 'B1', d['one_frame_per_launch_group']['Mpixel/s'])"
-done; done
+python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc $?"; grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -3
+python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/bench.json
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench.json"))
+print(d["value"], d["timing"]["Mpixel/s_each_window"], d.get("value_by_the_method_of_rounds_1_to_3"), d["roofline"]["frac"], d["roofline"]["avg_launch_ms"])
+for k in ("one_frame_per_launch_group","hf_sections_only","finished_file_per_step","batch_4k_device","batch_4k","shard_16k","single_frame","single_frame_form5","api_end_to_end"):
+    print(k, json.dumps(d["config"].get(k) if k in d.get("config",{}) else d.get(k))[:300])
+PY

@@ -13,7 +13,7 @@ root=$PWD
 python bench.py > "$out/${tag}_bench_default.json" 2> "$out/bench_default.err"
 cd /tmp
 rm -rf /tmp/kt_single /tmp/kt_pipe /tmp/kt_shard /tmp/kt_api
-rocprofv3 --kernel-trace --stats -d /tmp/kt_single -o kt -- python "$root/scripts/one_frame.py" 5 6 2 > /tmp/kt_single.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kt_single -o kt -- python "$root/scripts/one_frame.py" 5 5 2 > /tmp/kt_single.log 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/kt_pipe -o kt -- python "$root/bench.py" --steps 256 --no-cpu-baseline --no-api --no-legs > /tmp/kt_pipe.log 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/kt_shard -o kt -- python "$root/bench.py" --mode shard --steps 30 > /tmp/kt_shard.log 2>&1
 rocprofv3 --kernel-trace --memory-copy-trace --stats -d /tmp/kt_api -o kt -- python "$root/scripts/api_frame_times.py" > /tmp/kt_api.log 2>&1
@@ -27,7 +27,6 @@ db=$(find /tmp/kt_api -name "*.db" | head -1)
 python scripts/api_tile_mode.py 4096 8 > "$out/${tag}_tile_mode_now.txt" 2>&1
 grep "^{" /tmp/kt_pipe.log | tail -1 > "$out/${tag}_bench_under_rocprof.json"
 grep "^{" /tmp/kt_shard.log | tail -1 > "$out/${tag}_shard_under_rocprof.json"
-bash scripts/collect_pmc.sh "$out/pmc" python scripts/one_frame.py 3 6 2 > /dev/null 2>&1
+bash scripts/collect_pmc.sh "$out/pmc" python scripts/one_frame.py 3 5 2 > /dev/null 2>&1
 cat "$out"/pmc/pmc_set*.txt > "$out/${tag}_pmc_8k_photo.txt"
-python scripts/probe_k1_phases.py --run > "$out/${tag}_k1_phases.txt" 2>&1
 ls -la "$out"

@@ -1,9 +1,10 @@
-python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc $?"; grep -E "passed|failed|error" gpurun_out/pytest_gpu.log | tail -3
-python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/bench.json
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/bench.json"))
-print(d["value"], d["timing"]["Mpixel/s_each_window"], d.get("value_by_the_method_of_rounds_1_to_3"), d["roofline"]["frac"], d["roofline"]["avg_launch_ms"])
-for k in ("one_frame_per_launch_group","hf_sections_only","finished_file_per_step","batch_4k_device","batch_4k","shard_16k","single_frame","single_frame_form5","api_end_to_end"):
-    print(k, json.dumps(d["config"].get(k) if k in d.get("config",{}) else d.get(k))[:300])
-PY
+export TMPDIR=/tmp; root=$PWD; out=gpurun_out/r04; mkdir -p $out
+cd /tmp; rm -rf /tmp/kt_single
+rocprofv3 --kernel-trace --stats -d /tmp/kt_single -o kt -- python "$root/scripts/one_frame.py" 5 5 2 > /tmp/kt_single.log 2>&1
+cd "$root"
+db=$(find /tmp/kt_single -name "*.db" | head -1); python scripts/rocpd_summary.py "$db" | grep -v "at::native" > "$out/r04_kernel_stats_single.txt" 2>&1
+rm -rf /tmp/kt_f4; cd /tmp; rocprofv3 --kernel-trace --stats -d /tmp/kt_f4 -o kt -- python "$root/scripts/one_frame.py" 5 4 1 > /tmp/kt_f4.log 2>&1; cd "$root"
+db=$(find /tmp/kt_f4 -name "*.db" | head -1); python scripts/rocpd_summary.py "$db" | grep -v "at::native" > "$out/r04_kernel_stats_single_form4.txt" 2>&1
+bash scripts/collect_pmc.sh "$out/pmc" python scripts/one_frame.py 3 5 2 > /dev/null 2>&1
+cat "$out"/pmc/pmc_set*.txt > "$out/r04_pmc_8k_photo.txt"
+head -12 $out/r04_kernel_stats_single.txt; head -8 $out/r04_kernel_stats_single_form4.txt

@@ -88,10 +88,12 @@ HYDAMD_EXPORT int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode);
  *       parallel kernel writes the bits straight into the payload; a fifteenth of the instructions and
  *       a sixty-fourth of the wavefronts of form 4 — best when many frames are in flight.  LF groups
  *       with float samples are still coded by form 4.
- *   6   form 5 with its coding tables packed (12-bit slots as a byte and a nibble plane, operands for the 40
- *       tokens an integer frame can hold): 62 KB of LDS per chain instead of 80, at three more dependent
- *       instructions a symbol.  Alone the chains take 11 % longer; with many frames in flight on one device
- *       the compute units that host a chain take a third transform workgroup and the loop gains 4 %.
+ *   6   form 5 with its coding tables packed (12-bit slots as a byte and a nibble plane): 62 KB of LDS per chain
+ *       instead of 80, at three more dependent instructions a symbol (2.66 against 2.27 ms alone).  For devices so
+ *       crowded that the chains' LDS is what keeps transform workgroups off a compute unit; on an MI355X with the
+ *       streams laid out as INTEGRATION.md section 3 says it equals form 5 in a pipelined loop and loses elsewhere.
+ * Integer frames: forms 4-6 all leave the bits to a second, wave-parallel kernel (k_rans_emit); float frames are
+ * coded by form 4's self-emitting variant.
  * Round 1's row forms 1-3 are gone: asking for one of them (here or through HYDAMD_RANS_WAVES) selects
  * form 5, which replaced them, and says so once on stderr. */
 HYDAMD_EXPORT int hydamd_set_rans_waves(HydAmdContext *ctx, int waves);

@@ -573,6 +573,8 @@ __global__ __launch_bounds__(256) void k_asm_copy(Scratch S, uint8_t *__restrict
 
 } // namespace
 
+extern "C" void hydamd_host_copy(void *dst, const void *src, size_t n); /* device_api.hip */
+
 struct HydkAsm {
     int device = 0;
     char error[256] = "";
@@ -586,7 +588,10 @@ struct HydkAsm {
     size_t own_cap = 0;
     uint8_t *last_out = nullptr;  /* where the last run wrote */
     hipStream_t last_stream = nullptr; /* ... and the stream it ran in */
+    uint64_t last_cap = 0;        /* ... and how large that buffer is */
     bool ran = false;
+    uint8_t *bounce = nullptr;    /* pinned: hydk_asm_read lands frames here (DMA engines), then copies to the caller's memory */
+    size_t bounce_cap = 0;
 };
 
 namespace {
@@ -622,6 +627,8 @@ void hydk_asm_destroy(HydkAsm *a) {
             (void)hipFree(p);
     if (a->h_result)
         (void)hipHostFree(a->h_result);
+    if (a->bounce)
+        (void)hipHostFree(a->bounce);
     delete a;
 }
 
@@ -727,6 +734,7 @@ int hydk_asm_run(HydkAsm *a, const void *const *blobs, const uint64_t *blob_caps
     if ((uintptr_t)out & 3u)
         return afail(a, ST_API_ERROR, "output buffer must be 4-byte aligned");
     a->last_out = (uint8_t *)out;
+    a->last_cap = out_cap;
     a->last_stream = st;
     a->ran = true;
     BlobArgs args;
@@ -756,14 +764,34 @@ int hydk_asm_result(HydkAsm *a, uint64_t *size, uint32_t *err) {
     return ST_OK;
 }
 
-/* after the stream has been synchronised: the frame's bytes, copied out of device memory */
+/* after the stream has been synchronised: the frame's bytes, copied out of device memory.  `dst` is ordinary (pageable)
+ * memory as a rule: a plain hipMemcpy into it is staged by the runtime through shader copies in 3 MB pieces (an 8K frame's
+ * 12 MB: 0.6 ms, and a length that is not a multiple of four takes the same path whatever the destination).  So: one DMA
+ * of the length rounded up to 256 bytes into a pinned buffer of the assembler's (56 GB/s), then the staging threads' memcpy */
 int hydk_asm_read(HydkAsm *a, uint8_t *dst, size_t capacity) {
     if (!a || !dst || !a->last_out)
         return afail(a, ST_API_ERROR, "nothing to read");
     if (a->h_result[1] || !a->h_result[0] || a->h_result[0] > capacity)
         return afail(a, ST_API_ERROR, "no finished frame of that size");
     ASM_TRY(a, hipSetDevice(a->device));
-    ASM_TRY(a, hipMemcpy(dst, a->last_out, (size_t)a->h_result[0], hipMemcpyDeviceToHost));
+    const size_t n = (size_t)a->h_result[0];
+    const size_t padded = (n + 255) & ~(size_t)255;
+    if (n < ((size_t)1 << 20) || padded > a->last_cap) { /* small, or no room to round up: the runtime's own path */
+        ASM_TRY(a, hipMemcpy(dst, a->last_out, n, hipMemcpyDeviceToHost));
+        return ST_OK;
+    }
+    if (padded > a->bounce_cap) {
+        if (a->bounce)
+            (void)hipHostFree(a->bounce);
+        a->bounce = nullptr;
+        a->bounce_cap = 0;
+        const size_t want = padded + (padded >> 2);
+        ASM_TRY(a, hipHostMalloc((void **)&a->bounce, want, hipHostMallocDefault));
+        a->bounce_cap = want;
+    }
+    ASM_TRY(a, hipMemcpyAsync(a->bounce, a->last_out, padded, hipMemcpyDeviceToHost, a->last_stream));
+    ASM_TRY(a, hipStreamSynchronize(a->last_stream));
+    hydamd_host_copy(dst, a->bounce, n);
     return ST_OK;
 }
 

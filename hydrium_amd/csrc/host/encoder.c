@@ -461,7 +461,7 @@ static void drain(HYDEncoder *e) {
     if (n > e->out_len - e->out_pos)
         n = e->out_len - e->out_pos;
     if (n) {
-        memcpy(e->out + e->out_pos, e->stream.data + e->stream_pos, n);
+        hydamd_host_copy(e->out + e->out_pos, e->stream.data + e->stream_pos, n);
         e->out_pos += n;
         e->stream_pos += n;
     }

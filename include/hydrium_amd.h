@@ -55,6 +55,9 @@ enum { HYDAMD_K_TRANSFORM = 0, HYDAMD_K_TABLES = 1, HYDAMD_K_RANS = 2, HYDAMD_K_
 /* Number of usable HIP devices (0 when there is none; never fails). */
 HYDAMD_EXPORT int hydamd_device_count(void);
 
+/* memcpy on the library's staging threads (HYDAMD_STAGE_THREADS) for moves of several megabytes; plain memcpy below 4 MB */
+HYDAMD_EXPORT void hydamd_host_copy(void *dst, const void *src, size_t n);
+
 /*
  * Create a context on `device` with room for `max_lf_groups` LF groups in flight (one frame's
  * worth: every LF group of a one-frame image, or 1 for tile mode).  `linear_light` selects the

@@ -1595,7 +1595,7 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
     {
         ScopedTimer timer(ctx, HYDAMD_K_TABLES);
         /* the LF code construction's passengers ride in the chain kernel's launch (2.5 ms long anyway).  HYDAMD_LF_CODES_RIDE=tables
-         * puts them into this launch instead, where they do not ask for the chain kernel's 92 KB of LDS: measured equal in the
+         * puts them into this launch instead, where they do not ask for the chain kernel's 80 KB of LDS: measured equal in the
          * pipelined loop (143.5 against 143.3 Gpixel/s) and 0.13 ms worse for one frame alone (the table kernel then lasts
          * 0.20 instead of 0.07 ms in front of the chains), so it stays an A/B switch */
         if (!(debug_skip() & 1)) {

@@ -1302,15 +1302,26 @@ constexpr int kWinWords = 100; /* 64 symbols x 46 bits = 92 words + alignment sl
 __device__ __forceinline__ uint2 load_record(const void *tok, int p, bool wide) {
     uint2 r = {0u, 0u};
     if (p >= 0) {
+        /* device memory, said so: a flat load counts against the LDS counter too, and every slot lookup of the walk
+         * would wait for the records that are meant to travel during it */
         if (wide) {
-            r = ((const uint2 *)tok)[p];
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v = HYDK_GLOBAL(const u32x2, tok)[p];
+            r = uint2{v.x, v.y};
         } else {
-            const uint32_t v = ((const uint32_t *)tok)[p];
+            const uint32_t v = HYDK_GLOBAL(const uint32_t, tok)[p];
             r.x = HYDK_REC32_TO_LO(v);
             r.y = v >> 16;
         }
     }
     return r;
+}
+/* four 4-byte records, 16-byte aligned, as a GLOBAL load (the token arrays' address comes out of the job descriptor,
+ * generic to the compiler: a flat load, which every LDS wait of a walk would then wait for as well) */
+typedef uint32_t hydk_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_records4(const void *tok, int i) {
+    const hydk_u32x4 v = HYDK_GLOBAL(const hydk_u32x4, tok)[i];
+    return uint4{v.x, v.y, v.z, v.w};
 }
 constexpr int kInvEntries = HYDK_MAX_CLUSTERS * 2 * HYDK_ANS_SLOTS;
 
@@ -1531,7 +1542,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
         if (lane == 0) {
             final_state_all[G] = state;
             /* [preset id][final state][per symbol: refill word, residue bits] (encoder.c:945, entropy.c:1127-1147) */
-            group_bits_all[G] = (uint32_t)preset_bits + (n > 0 ? 32u : 0u) + 16u * refills + jobs[slot].rbits_total[g];
+            group_bits_all[G] = (uint32_t)preset_bits + (n > 0 ? 32u : 0u) + 16u * refills + HYDK_GLOBAL(const uint32_t, jobs[slot].rbits_total)[g];
         }
         return;
     }
@@ -1654,7 +1665,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + lane;
     const int n = lane < ngroups ? (int)sym_count_all[G] : 0;
     /* 4-byte records, 4 per uint4 (tok_cap is a multiple of 16: rounds never straddle a group's array) */
-    const uint4 *tok = (const uint4 *)((const char *)jobs[slot].tokens + (size_t)lane * jobs[slot].tok_cap * jobs[slot].rec_bytes);
+    const void *tok = (const char *)jobs[slot].tokens + (size_t)lane * jobs[slot].tok_cap * jobs[slot].rec_bytes;
     uint4 *aux = (uint4 *)(aux_all + G * aux_pitch); /* u16 per symbol, 8 per uint4 */
     uint16_t *flags = flags_all + G * (aux_pitch / 16);
     uint32_t refills = 0;
@@ -1671,7 +1682,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     uint4 nx[4];
 #pragma unroll
     for (int q = 0; q < 4; q++)
-        nx[q] = rj >= 0 ? tok[rj * 4 + q] : uint4{0, 0, 0, 0};
+        nx[q] = rj >= 0 ? load_records4(tok, rj * 4 + q) : uint4{0, 0, 0, 0};
 
 /* slot of (symbol, remainder r): o.w is the list's first index (packed planes) or byte offset (plain u16 table) */
 #define HYDK_LANE_SLOT(base, r)                                                                                        \
@@ -1716,7 +1727,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
         _Pragma("unroll") for (int q = 0; q < 4; q++) cur[q] = nx[q];                                            \
         const int rjn = rj - 1;                                                                                  \
         if (rjn >= 0) { /* the next round's line travels during this round's walk */                             \
-            _Pragma("unroll") for (int q = 0; q < 4; q++) nx[q] = tok[rjn * 4 + q];                              \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) nx[q] = load_records4(tok, rjn * 4 + q);               \
         }                                                                                                        \
         if (rj >= 0) {                                                                                           \
             uint32_t fl = 0;                                                                                     \
@@ -1750,7 +1761,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     if (lane < ngroups) {
         final_state_all[G] = state;
         /* [preset id][final state][per symbol: refill word, residue bits] (encoder.c:945, entropy.c:1127-1147) */
-        group_bits_all[G] = (uint32_t)preset_bits + (n > 0 ? 32u : 0u) + 16u * refills + jobs[slot].rbits_total[lane];
+        group_bits_all[G] = (uint32_t)preset_bits + (n > 0 ? 32u : 0u) + 16u * refills + HYDK_GLOBAL(const uint32_t, jobs[slot].rbits_total)[lane];
     } else {
         group_bits_all[G] = 0;
     }
@@ -1781,7 +1792,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
     const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + g;
     if (g >= ngroups || (*status & HYDK_STATUS_OVERFLOW))
         return;
-    const uint4 *tok = (const uint4 *)((const char *)jobs[slot].tokens + (size_t)g * jobs[slot].tok_cap * jobs[slot].rec_bytes);
+    const void *tok = (const char *)jobs[slot].tokens + (size_t)g * jobs[slot].tok_cap * jobs[slot].rec_bytes;
     const uint4 *aux = (const uint4 *)(aux_all + G * aux_pitch);
     const uint16_t *flags = flags_all + G * (aux_pitch / 16);
     uint32_t *W = (uint32_t *)payload; /* 256-byte aligned allocation */
@@ -1854,8 +1865,8 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
     auto fetch = [&](int batch) {
         const int p0 = batch * kEmitBatch + kEmitPer * lane;
         if (batch >= 0 && p0 < n) { /* the arrays are padded to a multiple of 16 symbols: whole octets are readable */
-            rec_n[0] = tok[p0 >> 2];
-            rec_n[1] = tok[(p0 >> 2) + 1];
+            rec_n[0] = load_records4(tok, p0 >> 2);
+            rec_n[1] = load_records4(tok, (p0 >> 2) + 1);
             a_n = aux[p0 >> 3];
             fl_n = flags[p0 >> 4];
         }

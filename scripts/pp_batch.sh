@@ -1,5 +1,5 @@
-FUZZ_BUDGET_S=500 python scripts/fuzz_api_parity.py 20000 99001 2>&1 | tail -2
-FUZZ_BUDGET_S=400 python scripts/fuzz_api_parity.py 600 31337 large 2>&1 | tail -2
-HYDAMD_TILE_PIPELINE=8 FUZZ_BUDGET_S=250 python scripts/fuzz_api_parity.py 5000 555 2>&1 | tail -2
-HYDAMD_RANS_WAVES=5 FUZZ_BUDGET_S=200 python scripts/fuzz_api_parity.py 5000 808 2>&1 | tail -2
-HYDAMD_RANS_WAVES=6 FUZZ_BUDGET_S=200 python scripts/fuzz_api_parity.py 5000 909 2>&1 | tail -2
+b() { timeout 300 python bench.py --mode batch --frames 512 "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['frames_per_s'], d['frames_per_s_each_round'])"; }
+export HYDAMD_CONTEXT_CACHE=32 HYDAMD_RANS_WAVES=5
+for lf in 1 2; do for t in 10 14 18; do
+echo -n "form 5, LF coder mode $lf threads $t: "; HYDAMD_LF_CODER=$lf b --threads $t
+done; done

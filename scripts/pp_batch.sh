@@ -1,5 +1,4 @@
-b() { timeout 300 python bench.py --mode batch --frames 512 "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['frames_per_s'], d['frames_per_s_each_round'])"; }
-export HYDAMD_CONTEXT_CACHE=32 HYDAMD_RANS_WAVES=5
-for lf in 1 2; do for t in 10 14 18; do
-echo -n "form 5, LF coder mode $lf threads $t: "; HYDAMD_LF_CODER=$lf b --threads $t
-done; done
+for cs in 2 4 8; do for st in 2 4 8 16; do echo -n "copy streams $cs stage threads $st: "; HYDAMD_COPY_STREAMS=$cs HYDAMD_STAGE_THREADS=$st python scripts/batch_client.py 10 2>&1 | tail -1 | cut -c1-70; done; done
+echo -n "eager off: "; HYDAMD_EAGER=0 python scripts/batch_client.py 10 2>&1 | tail -1 | cut -c1-70
+echo -n "lf 0: "; HYDAMD_LF_CODER=0 python scripts/batch_client.py 10 2>&1 | tail -1 | cut -c1-70
+echo -n "host assembly: "; HYDAMD_HOST_ASSEMBLY=1 python scripts/batch_client.py 10 2>&1 | tail -1 | cut -c1-70

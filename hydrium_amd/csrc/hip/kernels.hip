@@ -489,6 +489,9 @@ extern "C" __attribute__((visibility("default"))) int hydamd_debug_phase_ticks(u
  * already late (its stream holds nothing else): those kernels raise their wavefronts' issue priority so
  * that, sharing a SIMD with other frames' transform waves, they run as fast as they do alone. */
 #define HYDK_URGENT() __builtin_amdgcn_s_setprio(3)
+#ifndef HYDK_LANES_PRIO
+#define HYDK_LANES_PRIO 3 /* issue priority of the lane-form chains' wavefronts (A/B: a chain wave takes ~40 % of its SIMD's VALU issue) */
+#endif
 
 /* inclusive prefix sums in registers (DPP), no LDS round trips */
 #define HYDK_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xF, false))
@@ -1615,7 +1618,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     __shared__ uint8_t s_hi[PACK ? kInvEntries / 4 : 16];             /* slot >> 8, two per byte: 18 KiB */
     __shared__ uint16_t s_inv[PACK ? 8 : kInvEntries / 2];            /* or the plain inverse slot table, 72 KiB */
     __shared__ uint4 s_ops[HYDK_MAX_CLUSTERS * kLaneTokens];          /* 5.6 KiB */
-    HYDK_URGENT();
+    __builtin_amdgcn_s_setprio(HYDK_LANES_PRIO);
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= num_slots) {
         /* passengers: workgroup num_slots + s builds the prefix code of LF group s's coefficient stream

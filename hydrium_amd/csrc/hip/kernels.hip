@@ -1744,21 +1744,44 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
             _Pragma("unroll") for (int pos = 15; pos >= 0; pos--)                                                \
                 ov[pos] = s_ops[(FIRST) && !(pos < first_count) ? 0u : recs[pos] & 0x7FFu];                      \
             __builtin_amdgcn_sched_barrier(0); /* (the scheduler would sink the requests back into the steps) */ \
-            _Pragma("unroll") for (int pos = 15; pos >= 0; pos--)                                                \
+            _Pragma("unroll") for (int pos = 15; pos >= 8; pos--)                                                \
                 HYDK_LANE_STEP(ov[pos], pos, FIRST, pos < first_count);                                          \
-            aux[rj * 2] = uint4{w16[0], w16[1], w16[2], w16[3]};                                                 \
-            aux[rj * 2 + 1] = uint4{w16[4], w16[5], w16[6], w16[7]};                                             \
-            flags[rj] = (uint16_t)fl; /* bit (p mod 16): symbol p refills */                                     \
+            /* the PREVIOUS round's refill words and flags are stored here, in the middle of the walk: vmcnt counts \
+             * stores too, and stored at a round's end they were the youngest memory operations when the next round \
+             * took its records — that wait was a wait for the stores' round trip */                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            if (prj >= 0) {                                                                                      \
+                aux[prj * 2] = uint4{pw[0], pw[1], pw[2], pw[3]};                                                \
+                aux[prj * 2 + 1] = uint4{pw[4], pw[5], pw[6], pw[7]};                                            \
+                flags[prj] = (uint16_t)pfl; /* bit (p mod 16): symbol p refills */                               \
+            }                                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            _Pragma("unroll") for (int pos = 7; pos >= 0; pos--)                                                 \
+                HYDK_LANE_STEP(ov[pos], pos, FIRST, pos < first_count);                                          \
+            _Pragma("unroll") for (int q = 0; q < 8; q++) pw[q] = w16[q];                                        \
+            pfl = fl;                                                                                            \
             refills += (uint32_t)__popc(fl);                                                                     \
+        } else if (prj >= 0) { /* this lane's last round */                                                      \
+            aux[prj * 2] = uint4{pw[0], pw[1], pw[2], pw[3]};                                                    \
+            aux[prj * 2 + 1] = uint4{pw[4], pw[5], pw[6], pw[7]};                                                \
+            flags[prj] = (uint16_t)pfl;                                                                          \
         }                                                                                                        \
+        prj = rj; /* (negative: nothing to store) */                                                             \
         rj = rjn;                                                                                                \
     } while (0)
 
+    uint32_t pw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pfl = 0;
+    int prj = -1; /* the round whose results are still in registers */
     if (rounds > 0)
         HYDK_LANE_ROUND(true);
     for (int it = 1; it < rounds; it++)
         HYDK_LANE_ROUND(false);
 #undef HYDK_LANE_ROUND
+    if (prj >= 0) {
+        aux[prj * 2] = uint4{pw[0], pw[1], pw[2], pw[3]};
+        aux[prj * 2 + 1] = uint4{pw[4], pw[5], pw[6], pw[7]};
+        flags[prj] = (uint16_t)pfl;
+    }
 #undef HYDK_LANE_STEP
 #undef HYDK_LANE_SLOT
     if (lane < ngroups) {

@@ -92,7 +92,7 @@ HYDAMD_EXPORT int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode);
  *       a sixty-fourth of the wavefronts of form 4 — best when many frames are in flight.  LF groups
  *       with float samples are still coded by form 4.
  *   6   form 5 with its coding tables packed (12-bit slots as a byte and a nibble plane): 62 KB of LDS per chain
- *       instead of 80, at three more dependent instructions a symbol (2.66 against 2.27 ms alone).  For devices so
+ *       instead of 80, at three more dependent instructions a symbol (2.26 against 2.07 ms alone).  For devices so
  *       crowded that the chains' LDS is what keeps transform workgroups off a compute unit; on an MI355X with the
  *       streams laid out as INTEGRATION.md section 3 says it equals form 5 in a pipelined loop and loses elsewhere.
  * Integer frames: forms 4-6 all leave the bits to a second, wave-parallel kernel (k_rans_emit); float frames are

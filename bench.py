@@ -57,11 +57,12 @@ def parse():
     ap.add_argument("--depth", type=int, default=16, choices=(8, 16))
     ap.add_argument("--kind", default="photo")
     ap.add_argument("--streams", type=int, default=16, help="contexts (one HIP stream each), frames-per-launch-group frames in flight on each")
-    ap.add_argument("--rans-waves", type=int, default=5, choices=(4, 5, 6),
-                    help="entropy-stage form, see hydamd_set_rans_waves: 5 = one lane per group, a wavefront per LF group "
-                         "(throughput; default); 6 = the same with packed tables (62 KB of LDS per chain, not 80; chains 17 %% slower "
-                         "alone; +4 %% in the loop before the stream clean-up of round 4, equal since: 147.4 against 148.4 Gpixel/s, "
-                         "4K batch 4 050 against 4 500 frames/s); 4 = one wave per group (lowest single-frame latency)")
+    ap.add_argument("--rans-waves", type=int, default=6, choices=(4, 5, 6),
+                    help="entropy-stage form of the frame loop and the shard leg, see hydamd_set_rans_waves: 5 = one lane per group, a "
+                         "wavefront per LF group; 6 = the same with packed tables (62 KB of LDS per chain, not 80; chains 2.26 against 2.07 ms "
+                         "alone); 4 = one wave per group (lowest single-frame latency).  Last A/B, three alternating full runs: loop "
+                         "151.0 (form 6) against 148.8 Gpixel/s, shard 1.97 against 2.03 ms; the 4K batch, where the chain's own duration "
+                         "counts, 4 467 against 4 731 frames/s — that leg always runs form 5")
     ap.add_argument("--lf-coder", default="on", choices=("on", "off"),
                     help="code the LF coefficient streams on the GPU inside the timed loop (default) or leave them out")
     ap.add_argument("--collective", default="gather", choices=("gather", "all-gather"),
@@ -371,7 +372,7 @@ def batch_device_leg(args, frames, contexts=16, rounds=4):
     S = max(1, min(contexts, len(mine) or 1))
     ctxs = [device.DeviceContext(local, 4, 0) for _ in range(S)]
     for c in ctxs:
-        c.set_rans_waves(args.rans_waves)
+        c.set_rans_waves(5)  # 4K frames: four chains per frame, their own duration counts (form 6: -6 %)
         c.set_lf_coder(2)
     want = {}
     for k in range(distinct):  # reference digests: one context, one frame at a time

@@ -1842,15 +1842,20 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
             W[d] = v;
     };
     /* eight (value, bit count) per lane, in stream order by (lane, index); written in front of what is there */
-    auto emit = [&](const uint32_t (&val)[kEmitPer], const uint32_t (&nb)[kEmitPer]) {
+    /* `before_stores` runs between the window's assembly and its stores: the place to take delivery of loads that were
+     * requested earlier — vmcnt counts stores too, so a wait for loads placed BEHIND the stores waits for the stores' round
+     * trip as well (this kernel runs one wavefront per SIMD: nothing hides it) */
+    auto emit = [&](const uint32_t (&val)[kEmitPer], const uint32_t (&nb)[kEmitPer], auto &&before_stores) {
         uint32_t mine = 0;
 #pragma unroll
         for (int j = 0; j < kEmitPer; j++)
             mine += nb[j];
         const uint32_t inc = scan64_inclusive(mine);
         const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
-        if (!total)
+        if (!total) {
+            before_stores();
             return;
+        }
         const uint32_t newcur = cur - total;
         const uint32_t wlo = newcur >> 5, whi = (cur - 1u) >> 5;
         const uint32_t nwords = whi - wlo + 1u;
@@ -1876,6 +1881,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
             pos += nb[j];
         }
         __builtin_amdgcn_wave_barrier();
+        before_stores();
         const bool low_partial = (newcur & 31u) != 0;
         for (uint32_t i = lane + (low_partial ? 1u : 0u); i < nwords; i += 64)
             put(wlo + i, win[i]);
@@ -1884,7 +1890,8 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
         cur = newcur;
     };
 
-    /* the next batch's records, refill words and flags travel while this one is being written */
+    /* the next batch's records, refill words and flags travel while this one's window is being assembled, and are taken
+     * delivery of (`take`) before this one's stores */
     uint4 rec_n[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     uint4 a_n = {0, 0, 0, 0};
     uint32_t fl_n = 0;
@@ -1898,13 +1905,31 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
         }
     };
     const int batches = (n + kEmitBatch - 1) / kEmitBatch;
+    uint32_t rc[kEmitPer] = {0, 0, 0, 0, 0, 0, 0, 0}, ac[4] = {0, 0, 0, 0}, flc = 0; /* the batch in hand */
+    auto take = [&] {
+        const uint32_t r[kEmitPer] = {rec_n[0].x, rec_n[0].y, rec_n[0].z, rec_n[0].w, rec_n[1].x, rec_n[1].y, rec_n[1].z, rec_n[1].w};
+        const uint32_t a[4] = {a_n.x, a_n.y, a_n.z, a_n.w};
+#pragma unroll
+        for (int j = 0; j < kEmitPer; j++) {
+            rc[j] = r[j];
+            asm volatile("" : "+v"(rc[j])); /* here, not where the compiler would first need it */
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            ac[j] = a[j];
+            asm volatile("" : "+v"(ac[j]));
+        }
+        flc = fl_n;
+        asm volatile("" : "+v"(flc));
+    };
     fetch(batches - 1);
+    take();
     for (int b = batches - 1; b >= 0; b--) {
         const int p0 = b * kEmitBatch + kEmitPer * lane;
-        const uint32_t recs[kEmitPer] = {rec_n[0].x, rec_n[0].y, rec_n[0].z, rec_n[0].w, rec_n[1].x, rec_n[1].y, rec_n[1].z, rec_n[1].w};
-        const uint32_t aw[kEmitPer] = {a_n.x & 0xFFFFu, a_n.x >> 16, a_n.y & 0xFFFFu, a_n.y >> 16,
-                                       a_n.z & 0xFFFFu, a_n.z >> 16, a_n.w & 0xFFFFu, a_n.w >> 16};
-        const uint32_t flq = fl_n >> (p0 & 15);
+        const uint32_t recs[kEmitPer] = {rc[0], rc[1], rc[2], rc[3], rc[4], rc[5], rc[6], rc[7]};
+        const uint32_t aw[kEmitPer] = {ac[0] & 0xFFFFu, ac[0] >> 16, ac[1] & 0xFFFFu, ac[1] >> 16,
+                                       ac[2] & 0xFFFFu, ac[2] >> 16, ac[3] & 0xFFFFu, ac[3] >> 16};
+        const uint32_t flq = flc >> (p0 & 15);
         fetch(b - 1);
         uint32_t val[kEmitPer], nb[kEmitPer];
 #pragma unroll
@@ -1916,7 +1941,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
             val[j] = refill ? (residue << 16) | aw[j] : residue;
             nb[j] = valid ? rbits + (refill ? 16u : 0u) : 0u;
         }
-        emit(val, nb);
+        emit(val, nb, take);
     }
     {
         /* [preset id][final state, low half first] precede everything (encoder.c:945, entropy.c:1127-1130) */
@@ -1929,7 +1954,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
                 nb[1] = 32;
             }
         }
-        emit(val, nb);
+        emit(val, nb, [] {});
     }
     if (lane == 0 && (cur & 31u))
         put(cur >> 5, carry);

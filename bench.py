@@ -351,11 +351,13 @@ def run_shard(args):
         emit(out)
 
 
-def batch_device_leg(args, frames, contexts=16, rounds=4):
+def batch_device_leg(args, frames, contexts=16, rounds=4, per_group=8):
     """BASELINE configs[4] WITHOUT PCIe: the batch of independent 3840x2160 RGB8 frames already resident in HBM
-    ("synthetic RGB tiles"), frame i on GPU i mod N, each rank's frames round-robined over `contexts` device contexts
-    (hydamd_encode_image: one call per frame), every frame's finished sections left in HBM.  After the clock stops the
-    sections of every frame are hashed and compared with a one-context, one-frame-at-a-time run of the same pictures."""
+    ("synthetic RGB tiles"), frame i on GPU i mod N, each rank's frames dealt to `contexts` device contexts `per_group`
+    at a time (hydamd_encode_image_batch: four 4K frames = sixteen LF groups = one launch group, the shape of an 8K
+    frame; per_group 1 = hydamd_encode_image, one call and one launch group per frame), every frame's finished sections
+    left in HBM.  After the clock stops the sections every context holds are compared, byte for byte, with those of the
+    same pictures coded one frame at a time on one context."""
     import torch
     import torch.distributed as dist
 
@@ -370,56 +372,72 @@ def batch_device_leg(args, frames, contexts=16, rounds=4):
     imgs = [synth.make_image("photo", w, h, 8, seed=1234 + k, device=torch.device("cuda", local)) for k in range(distinct)]
     mine = list(range(rank, frames, world))
     S = max(1, min(contexts, len(mine) or 1))
-    ctxs = [device.DeviceContext(local, 4, 0) for _ in range(S)]
+    ctxs = [device.DeviceContext(local, 4 * per_group, 0) for _ in range(S)]
     for c in ctxs:
-        c.set_rans_waves(5)  # 4K frames: four chains per frame, their own duration counts (form 6: -6 %)
+        c.set_rans_waves(5)
         c.set_lf_coder(2)
     want = {}
-    for k in range(distinct):  # reference digests: one context, one frame at a time
+    for k in range(distinct):  # reference sections: one context, one frame at a time
         ctxs[0].encode_image_tensor(imgs[k])
         ctxs[0].sync()
-        want[k] = hashlib.md5(ctxs[0].read_payload()).hexdigest()
-    for c in ctxs:  # every context's buffers touched once
-        c.encode_image_tensor(imgs[0])
-    for c in ctxs:
-        c.sync()
-    dts = []
-    last = {}
-    for _ in range(rounds):
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i, f in enumerate(mine):
-            ctxs[i % S].encode_image_tensor(imgs[f % distinct])
-            last[i % S] = f
+        want[k] = bytes(ctxs[0].read_payload())
+
+    def run(G):
+        # several frames per launch group: the loop's regime, form 6 (+1.5 %); a frame per group: four chains per launch,
+        # their own duration counts, form 5 (+6 %)
+        for c in ctxs:
+            c.set_rans_waves(args.rans_waves if G > 1 and args.rans_waves >= 5 else 5)
+        groups = [mine[i:i + G] for i in range(0, len(mine), G)]
+        for c in ctxs:  # every context's buffers touched once
+            c.encode_image_batch([imgs[0]] * G) if G > 1 else c.encode_image_tensor(imgs[0])
         for c in ctxs:
             c.sync()
-        torch.cuda.synchronize()
+        dts, last = [], {}
+        for _ in range(rounds):
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i, grp in enumerate(groups):
+                if G > 1 and len(grp) == G:
+                    ctxs[i % S].encode_image_batch([imgs[f % distinct] for f in grp])
+                    last[i % S] = grp
+                else:
+                    for f in grp:
+                        ctxs[i % S].encode_image_tensor(imgs[f % distinct])
+                        last[i % S] = [f]
+            for c in ctxs:
+                c.sync()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            dts.append(time.perf_counter() - t0)
+        ok = all(bytes(ctxs[k].read_payload()) == b"".join(want[f % distinct] for f in grp) for k, grp in last.items())
         if use_dist:
-            dist.barrier()
-        dts.append(time.perf_counter() - t0)
-    ok = all(hashlib.md5(ctxs[k].read_payload()).hexdigest() == want[f % distinct] for k, f in last.items())
+            tt = torch.tensor(dts, dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = [float(x) for x in tt.tolist()]
+        timed = sorted(dts[1:])
+        return timed[len(timed) // 2], dts, ok
+
+    dt, dts, ok = run(per_group)
+    dt1, dts1, ok1 = run(1) if per_group > 1 else (dt, dts, ok)
     for c in ctxs:
         c.close()
-    if use_dist:
-        tt = torch.tensor(dts, dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dts = [float(x) for x in tt.tolist()]
-    timed = sorted(dts[1:])
-    dt = timed[len(timed) // 2]
     if rank != 0:
         return None
     return {"value": round(frames * w * h / dt / 1e6, 1), "unit": "Mpixel/s", "frames_per_s": round(frames / dt, 1),
             "ms_per_step": round(dt / frames * 1e3, 4), "n_gpus": world, "steps": frames, "scaling": "strong",
             "frames_per_s_each_round": [round(frames / x, 1) for x in dts[1:]],
+            "frames_per_s_one_frame_per_launch_group": round(frames / dt1, 1),
             "frac_of_hbm_read_roofline": round(frames * w * h * 3 / dt / (HBM_PEAK_GBS * 1e9), 5),
             "config": {"workload": f"{frames} independent {w}x{h} RGB8 'photo' frames (BASELINE configs[4]) resident in HBM, "
-                                   f"round-robined over {S} device contexts per GPU, frame i on GPU i mod {world}; sections + coded LF streams "
+                                   f"dealt to {S} device contexts per GPU {per_group} at a time (one hydamd_encode_image_batch call = one "
+                                   f"launch group of {4 * per_group} LF groups), frame i on GPU i mod {world}; sections + coded LF streams "
                                    "of every frame left in HBM (no PCIe in the timed region: the host-pointer form is batch_4k); wall clock "
                                    "around the whole batch, fill and drain included",
-                       "contexts_per_gpu": S},
-            "sections_identical_to_single_context_run": ok}
+                       "contexts_per_gpu": S, "frames_per_launch_group": per_group},
+            "sections_identical_to_single_context_run": bool(ok and ok1)}
 
 
 def batch_leg(args, frames, threads, rounds=4):
@@ -1066,7 +1084,7 @@ def main():
             keep = ("value", "unit", "ms_per_step", "frames_per_s", "n_gpus", "steps", "scaling", "config", "frame_bytes", "frame_md5",
                     "frames_checked", "assembled_frames_identical_to_host_assembly", "host_ms_per_frame", "frac_of_hbm_read_roofline",
                     "frame0_identical_to_reference", "threads_agree_with_single_thread_run", "frames_per_s_each_round", "leg_wall_s", "error",
-                    "sections_identical_to_single_context_run")
+                    "sections_identical_to_single_context_run", "frames_per_s_one_frame_per_launch_group")
             out[name] = {k: r[k] for k in keep if k in r}
         if world == 1 and not args.no_api:
             # API end-to-end through the drop-in hyd_send_tile (host pixels: includes PCIe, read-back, assembly)

@@ -57,7 +57,7 @@ hipError_t launch_rans_deferred(const HydkLfJob *d_jobs, const uint32_t *sym_cou
 hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint16_t *aux,
                              uint16_t *flags, uint32_t aux_pitch, uint32_t *final_state, uint32_t *group_bits, int preset_bits,
                              int nclusters, int num_slots, const uint32_t *status, const uint32_t *lf_hist,
-                             HydkLfStream *lf_streams, void *lf_work, bool packed_tables, hipStream_t stream);
+                             HydkLfStream *lf_streams, void *lf_work, hipStream_t stream);
 hipError_t launch_lf_front(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, void *work, int num_slots,
                            hipStream_t stream);
 hipError_t launch_lf_back(const HydkLfJob *d_jobs, const unsigned long long *recs, HydkLfStream *streams, uint32_t *bits,
@@ -133,6 +133,8 @@ struct HydAmdContext {
     int preset_bits = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t chain_stream = nullptr;        /* HYDAMD_CHAIN_CUS: the device's shared stream (restricted to the chains' compute units) this context's chains run in */
+    hipEvent_t chain_go = nullptr, chain_done = nullptr;
     char error[256] = "";
 
     /* device memory */
@@ -398,6 +400,50 @@ constexpr int kMaxSharedCopyStreams = 8;
 static std::mutex g_copy_lock;
 static hipStream_t g_copy_streams[HYDAMD_MAX_PEERS * 2][kMaxSharedCopyStreams];
 static unsigned g_copy_next[HYDAMD_MAX_PEERS * 2];
+
+/* HYDAMD_CHAIN_CUS=R (experiment, VERDICT r4 task 1b): the lane-form chains run on R compute units of their own — the device's
+ * HYDAMD_CHAIN_STREAMS (default 4) shared streams are created with a CU mask of R units (mask bits are dealt to the XCDs in
+ * turn: the low R bits are R / 8 units of every XCD), every context's own stream with the complement — so that a chain
+ * never shares a compute unit's LDS pipeline and issue ports with transform workgroups, and never takes a transform
+ * workgroup's place. */
+static int chain_cus() {
+    static const int v = [] {
+        const char *e = getenv("HYDAMD_CHAIN_CUS");
+        const int n = e && *e ? atoi(e) : 0;
+        return n < 0 ? 0 : n > 128 ? 128 : n;
+    }();
+    return v;
+}
+static hipStream_t g_chain_streams[HYDAMD_MAX_PEERS * 2][kMaxSharedCopyStreams];
+static unsigned g_chain_next[HYDAMD_MAX_PEERS * 2];
+static hipError_t create_masked_stream(hipStream_t *out, int device, int first_cu, int end_cu) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess)
+        return e;
+    uint32_t mask[16] = {0};
+    const int total = prop.multiProcessorCount > 512 ? 512 : prop.multiProcessorCount;
+    for (int cu = first_cu; cu < end_cu && cu < total; cu++)
+        mask[cu >> 5] |= 1u << (cu & 31);
+    return hipExtStreamCreateWithCUMask(out, (uint32_t)((total + 31) / 32), mask);
+}
+static int acquire_chain_stream(HydAmdContext *ctx) {
+    if (!chain_cus() || ctx->device < 0 || ctx->device >= HYDAMD_MAX_PEERS * 2)
+        return ST_OK;
+    static const int shared = [] {
+        const char *v = getenv("HYDAMD_CHAIN_STREAMS");
+        const int n = v && *v ? atoi(v) : 4;
+        return n < 1 ? 1 : n > kMaxSharedCopyStreams ? kMaxSharedCopyStreams : n;
+    }();
+    std::lock_guard<std::mutex> hold(g_copy_lock);
+    const unsigned k = g_chain_next[ctx->device]++ % (unsigned)shared;
+    if (!g_chain_streams[ctx->device][k])
+        HIP_TRY(ctx, create_masked_stream(&g_chain_streams[ctx->device][k], ctx->device, 0, chain_cus()));
+    ctx->chain_stream = g_chain_streams[ctx->device][k];
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chain_go, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chain_done, hipEventDisableTiming));
+    return ST_OK;
+}
 
 int acquire_copy_stream(HydAmdContext *ctx) {
     static const int shared = [] {
@@ -708,6 +754,10 @@ void hydamd_destroy(HydAmdContext *ctx) {
         (void)hipHostFree(ctx->h_total_pinned);
     if (ctx->h_status_pinned)
         (void)hipHostFree(ctx->h_status_pinned);
+    if (ctx->chain_go)
+        (void)hipEventDestroy(ctx->chain_go);
+    if (ctx->chain_done)
+        (void)hipEventDestroy(ctx->chain_done);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -814,7 +864,14 @@ static int acquire_shared_luts(HydAmdContext *ctx) {
 static int create_impl(HydAmdContext *ctx, int debug_planes) {
     const size_t slots = (size_t)ctx->max_slots, G = HYDK_GROUPS_PER_LFG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    if (chain_cus()) {
+        HIP_TRY(ctx, create_masked_stream(&ctx->own_stream, ctx->device, chain_cus(), 1 << 20));
+        const int st = acquire_chain_stream(ctx);
+        if (st != ST_OK)
+            return st;
+    } else {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    }
     ctx->stream = ctx->own_stream;
     if (const char *env = getenv("HYDAMD_TOKEN_CAP")) { /* records per group before the overflow path kicks in (tests) */
         const long v = atol(env);
@@ -1630,13 +1687,23 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
             hipLaunchKernelGGL(k_sleep_probe, dim3(wgs > 0 ? wgs * count : 1), dim3(64), (size_t)lds, ctx->stream, ticks);
         } else if (debug_skip() & 2) {
         } else if (lanes) {
+            hipStream_t chains = ctx->stream;
+            if (ctx->chain_stream) { /* the chains' own compute units: behind the table kernel, in front of the section scan */
+                HIP_TRY(ctx, hipEventRecord(ctx->chain_go, ctx->stream));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->chain_stream, ctx->chain_go, 0));
+                chains = ctx->chain_stream;
+            }
             HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, ctx->sym_count + g0, ctx->tables + first,
                                                  ctx->rans_aux + g0 * ctx->tok_cap, ctx->rans_flags + g0 * (ctx->tok_cap / 16),
                                                  ctx->tok_cap, ctx->rans_final + g0, ctx->group_bits + g0, ctx->preset_bits,
                                                  ctx->nclusters, count, ctx->status,
                                                  with_lf_codes ? ctx->lf_hist + (size_t)first * HYDK_LF_CODES : nullptr,
                                                  ctx->lf_streams + first, ctx->lf_work + (size_t)first * hydk::lf_work_bytes(),
-                                                 ctx->rans_lanes == 2, ctx->stream));
+                                                 chains));
+            if (ctx->chain_stream) {
+                HIP_TRY(ctx, hipEventRecord(ctx->chain_done, ctx->chain_stream));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->chain_done, 0));
+            }
         } else if (!any_float && wave_form_defers()) {
             /* wave per group, bits written by k_rans_emit as for the lane form (round 4: the walk no longer stops after
              * every 64 symbols to scan, pack and store their bits itself) */

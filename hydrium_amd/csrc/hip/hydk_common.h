@@ -40,15 +40,18 @@
  *   lo: bits 0-7 token, 8-11 preset-local cluster, 16-21 residue bit count;  hi: residue bits. */
 #define HYDK_REC_LO(token, cluster, rbits) ((uint32_t)(token) | ((uint32_t)(cluster) << 8) | ((uint32_t)(rbits) << 16))
 /* Integer sample formats bound every quantised coefficient below 2^13 (K1), so their record fits 4 bytes:
- *   bits 0-10 symbol = preset-local cluster * HYDK_REC32_TOKENS + token (what the transform kernel's histogram and
- *   the lane-form chain's operand table are indexed by), 11-15 residue bit count, 16-31 residue bits.
+ *   bits 0-3 residue bit count (at most 12), 4-14 symbol = preset-local cluster * HYDK_REC32_TOKENS + token (what the
+ *   transform kernel's histogram is indexed by; `record & 0x7FF0` IS the byte offset of the symbol's 16-byte row in the
+ *   lane-form chain's operand table: one instruction, where a shift and a mask were two of a step's sixteen), 16-31 residue bits.
  * HYDK_REC32_TO_LO turns one back into the lo word of the 8-byte form (symbol / 40 by multiplication: exact below 2^11,
  * asserted in kernels.hip). */
 #define HYDK_REC32_TOKENS 40u /* every token of an integer frame is below 36 */
-#define HYDK_REC32(symbol, rbits, residue) ((uint32_t)(symbol) | ((uint32_t)(rbits) << 11) | ((uint32_t)(residue) << 16))
-#define HYDK_REC32_CLUSTER(r) ((((r) & 0x7FFu) * 1639u) >> 16)
+#define HYDK_REC32(symbol, rbits, residue) ((uint32_t)(rbits) | ((uint32_t)(symbol) << 4) | ((uint32_t)(residue) << 16))
+#define HYDK_REC32_SYMBOL(r) (((r) >> 4) & 0x7FFu)
+#define HYDK_REC32_RBITS(r) ((r) & 0xFu)
+#define HYDK_REC32_CLUSTER(r) ((HYDK_REC32_SYMBOL(r) * 1639u) >> 16)
 #define HYDK_REC32_TO_LO(r) \
-    ((((r) & 0x7FFu) - HYDK_REC32_CLUSTER(r) * HYDK_REC32_TOKENS) | (HYDK_REC32_CLUSTER(r) << 8) | ((((r) >> 11) & 0x1Fu) << 16))
+    ((HYDK_REC32_SYMBOL(r) - HYDK_REC32_CLUSTER(r) * HYDK_REC32_TOKENS) | (HYDK_REC32_CLUSTER(r) << 8) | (HYDK_REC32_RBITS(r) << 16))
 
 /* Per-LF-group ANS coding tables produced by the table kernel, consumed by the rANS kernel. */
 typedef struct HydkTables {

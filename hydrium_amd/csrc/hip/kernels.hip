@@ -521,7 +521,7 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
 
 /* Token records.  Integer input: |quantised coefficient| <= 0.42 * 1969 * 5 < 2^13 (XYB is bounded by the
  * bias LUT's range and the scaled DCT has unit gain), so token < 36, residue < 2^13 and one record fits
- * 32 bits: symbol | residue bit count << 11 | residue << 16, symbol = cluster * 40 + token — the histogram bin,
+ * 32 bits: residue bit count | symbol << 4 | residue << 16 (hydk_common.h), symbol = cluster * 40 + token — the histogram bin,
  * which the caller has at hand.  Float input has no such bound and keeps the 8-byte record:
  * lo = token | cluster << 8 | bit count << 16, hi = residue. */
 template <int FMT>
@@ -1347,6 +1347,22 @@ __device__ __forceinline__ uint32_t mad24(uint32_t b, uint32_t c, uint32_t a) {
     return r;
 }
 
+__device__ __forceinline__ uint64_t mad_u64_u32(uint32_t a, uint32_t b, uint64_t c) {
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return d;
+}
+__device__ __forceinline__ uint64_t mul_u64_u32(uint32_t a, uint32_t b) {
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b) : "vcc");
+    return d;
+}
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 /* one step of the recurrence; the symbol's operands {-2f, floor(2^32/f), table address, threshold}
  * were staged in LDS by the lane that owns it and arrive by one broadcast ds_read_b128 */
 #define HYDK_RANS_STEP(o)                                                                     \
@@ -1588,44 +1604,79 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
 
 constexpr bool rec32_cluster_is_exact() {
     for (uint32_t s = 0; s < 2048u; s++)
-        if (HYDK_REC32_CLUSTER(s) != s / HYDK_REC32_TOKENS)
+        if (HYDK_REC32_CLUSTER(s << 4) != s / HYDK_REC32_TOKENS)
             return false;
     return true;
 }
 static_assert(rec32_cluster_is_exact(), "HYDK_REC32_CLUSTER: symbol / 40 by multiplication");
 constexpr int kLaneTokens = (int)HYDK_REC32_TOKENS; /* integer formats: the record's symbol is cluster * 40 + token */
 
+/* The step, and what bounds it (round 5; profiles/r05_chain_anatomy.txt).  With x the renormalised state, f the symbol's
+ * frequency:  q = mulhi(x, floor(2^32 / f))  (floor(x / f) or one less),  r0 = x - q f in [0, 2f),  fix = r0 >= f,
+ *   state' = ((q + fix) << 12) | slot(symbol, r0 - fix f)                                   (entropy.c:1092-1119)
+ * A wavefront that has its SIMD to itself issues one instruction every ~6.7 cycles whether or not it depends on the one
+ * before (scripts/ubench/valu_rate: 2.8 ns per instruction at one wave per SIMD; 9.5 cycles when dependent): the walk's
+ * time is its INSTRUCTION COUNT times that, plus whatever of the slot lookup's ~64 cycles of LDS latency no instruction
+ * covers.  (Measured both ways: a step cut to four dependent instructions between lookups by forming 64-bit partial
+ * products ahead — 27 instructions — ran 8 % faster than round 4's 16 instructions in one dependent chain; the same
+ * idea in the wave-per-group form, 9 -> 19 instructions, ran 30 % SLOWER.)  So the step below is the short one, with the
+ * instructions that do not need the slot placed behind the lookup's request:
+ *   - the refill test state' > (f' << 20) - 1 looks at bits 20.. of state' only: A = (q + fix) << 12 decides it, and
+ *     with it x' = (A >> 16) or (A | slot) = B | (slot & mask): quotient repair, A, test, B, mask and the flag go first;
+ *   - so do putting the previous state together (A | slot of the step before) and filing its low half;
+ *   - a record's bits 4-14 are its operand row's byte offset (hydk_common.h): one instruction per row request.
+ * A step is 17 instructions, 7 of them between the slot's arrival and the next request.  One asm statement per step:
+ * the compiler pads every asm statement's edges with s_nop (it cannot see inside), three or four per step before. */
 struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs besides the state */
     uint32_t thr;   /* (f << 20) - 1: renormalise when state > thr (entropy.c:1092) */
     uint32_t magic; /* floor(2^32 / f) */
     uint32_t negf;  /* -f */
-    uint32_t tab2;  /* index of the symbol's slot list in the slot planes: cluster * 4096 + base */
+    uint32_t tab;   /* LDS byte address of the symbol's slot list (u16 per remainder) */
 };
 
-template <bool PACK>
+/* request of the slot of (symbol with operands mg / nf / tab, renormalised state x) */
+#define HYDK_LANE_ASM_CORE                                                                                       \
+    "v_mul_hi_u32 %[q], %[x], %[mg]\n\t"                                                                         \
+    "v_mad_i32_i24 %[t0], %[q], %[nf], %[x]\n\t" /* r0 = x - q f */                                              \
+    "v_add_co_u32 %[t1], vcc, %[t0], %[nf]\n\t"  /* r0 - f; carry: r0 >= f, the quotient is one short */          \
+    "v_min_u32 %[t0], %[t0], %[t1]\n\t"          /* x mod f */                                                    \
+    "v_lshl_add_u32 %[t1], %[t0], 1, %[tab]\n\t"                                                                 \
+    "ds_read_u16 %[sln], %[t1]\n\t"
+/* behind the request: the repaired quotient, the new state without its slot, the NEXT symbol's refill test on it */
+#define HYDK_LANE_ASM_SHADOW                                                                                     \
+    "v_addc_co_u32 %[q], vcc, 0, %[q], vcc\n\t"                                                                  \
+    "v_lshlrev_b32 %[A], 12, %[q]\n\t"                                                                           \
+    "v_cmp_gt_u32 vcc, %[A], %[thrn]\n\t"                                                                        \
+    "v_cndmask_b32_sdwa %[B], %[A], %[A], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
+    "v_cndmask_b32_e64 %[sm], %[k0fff], 0, vcc\n\t"                                                              \
+    "v_addc_co_u32 %[fl], vcc, %[fl], %[fl], vcc\n\t"                                                            \
+    "s_waitcnt lgkmcnt(0)"
+#define HYDK_LANE_ASM_SDWA_SELECT "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+
+template <int NC> /* NC: clusters per preset of the frame's clustering scheme (9 / 3 / 2 / 1): the tables' size in LDS */
 __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
                                                    const HydkTables *tabs, uint16_t *aux_all, uint16_t *flags_all,
                                                    uint32_t aux_pitch /* symbols per group in aux / flags */,
-                                                   uint32_t *final_state_all, uint32_t *group_bits_all, int nclusters,
+                                                   uint32_t *final_state_all, uint32_t *group_bits_all,
                                                    int preset_bits, const uint32_t *status, int num_slots,
                                                    const uint32_t *lf_hist, HydkLfStream *lf_streams, void *lf_work) {
     /* The workgroup HOLDS its LDS for the whole walk, and in the pipelined loop that (times the walk's duration, which
-     * doubles beside other frames' transform workgroups) is most of what the chains cost the kernels around them
-     * (profiles/r04_pipeline_bounds.txt).  PACK (form 6): the 12-bit slots as a byte plane and a nibble plane — both
-     * reads leave together, one LDS latency, three more dependent instructions a step: 62 KB instead of 80, so a
-     * compute unit that hosts a chain takes three transform workgroups, not two; the chain alone is 11 % slower. */
-    __shared__ uint8_t s_lo[PACK ? kInvEntries / 2 : 16];             /* slot & 255: 36 KiB */
-    __shared__ uint8_t s_hi[PACK ? kInvEntries / 4 : 16];             /* slot >> 8, two per byte: 18 KiB */
-    __shared__ uint16_t s_inv[PACK ? 8 : kInvEntries / 2];            /* or the plain inverse slot table, 72 KiB */
-    __shared__ uint4 s_ops[HYDK_MAX_CLUSTERS * kLaneTokens];          /* 5.6 KiB */
+     * more than doubles beside other frames' transform workgroups) is what the chains cost the kernels around them
+     * (profiles/r04_pipeline_bounds.txt, r05_pipeline_bounds.txt).  The tables are sized by the frame's clustering scheme
+     * (a 16384^2 frame has 3 clusters per preset: 26 KB, not 80). */
+    constexpr int kOpsBytes = NC * kLaneTokens * (int)sizeof(uint4);
+    constexpr int kTabBytes = 2 * NC * HYDK_ANS_SLOTS;
+    constexpr int kLdsBytes = kOpsBytes + kTabBytes > (int)sizeof(LfHuffScratch) ? kOpsBytes + kTabBytes : (int)sizeof(LfHuffScratch);
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[kLdsBytes];
+    uint4 *const s_ops = (uint4 *)s_mem;
+    unsigned char *const s_tab = s_mem + kOpsBytes; /* uint16_t[NC * 4096] */
     __builtin_amdgcn_s_setprio(HYDK_LANES_PRIO);
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= num_slots) {
         /* passengers: workgroup num_slots + s builds the prefix code of LF group s's coefficient stream
          * (lf_coder.hip; 200 us of serial work on one wavefront, like the chains and independent of them) */
-        __shared__ LfHuffScratch s_huff;
         const int s = (int)blockIdx.x - num_slots;
-        lf_huffman_wave(lf_hist + (size_t)s * HYDK_LF_CODES, ((LfWork *)lf_work)[s].codes, lf_streams + s, s_huff, lane);
+        lf_huffman_wave(lf_hist + (size_t)s * HYDK_LF_CODES, ((LfWork *)lf_work)[s].codes, lf_streams + s, *(LfHuffScratch *)s_mem, lane);
         return;
     }
     const int slot = blockIdx.x;
@@ -1633,34 +1684,20 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     const HydkTables *tab = tabs + slot;
     if (*status & HYDK_STATUS_OVERFLOW)
         return; /* the transform stage ran out of token space: the host reruns the frame */
+    typedef __attribute__((address_space(3))) const uint16_t LdsU16;
     {
         const uint4 *src = (const uint4 *)&tab->inv1[0][0];
-        for (int i = lane; i < nclusters * HYDK_ANS_SLOTS / 8 && !PACK; i += 64)
-            ((uint4 *)s_inv)[i] = src[i];
-        for (int i = lane; i < nclusters * HYDK_ANS_SLOTS / 8 && PACK; i += 64) { /* eight slots a turn */
-            const uint4 v = src[i];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            uint32_t lo[2], hi = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t pair = (w[k] & 0xFFu) | ((w[k] >> 8) & 0xFF00u);
-                if (k & 1)
-                    lo[k >> 1] |= pair << 16;
-                else
-                    lo[k >> 1] = pair;
-                hi |= (((w[k] >> 8) & 0xFu) | ((w[k] >> 20) & 0xF0u)) << (8 * k);
-            }
-            ((uint2 *)s_lo)[i] = uint2{lo[0], lo[1]};
-            ((uint32_t *)s_hi)[i] = hi;
-        }
-        for (int i = lane; i < nclusters * kLaneTokens; i += 64) {
+        for (int i = lane; i < NC * HYDK_ANS_SLOTS / 8; i += 64)
+            ((uint4 *)s_tab)[i] = src[i];
+        const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_tab;
+        for (int i = lane; i < NC * kLaneTokens; i += 64) {
             const int c = i / kLaneTokens, at = c * HYDK_ALPHABET + i % kLaneTokens;
             const uint32_t fbv = (&tab->fb[0][0])[at], f = fbv & 0xFFFFu;
             uint4 o;
             o.x = f ? (f << 20) - 1u : 0xFFFFFFFFu;
             o.y = (&tab->magic[0][0])[at];
             o.z = 0u - f;
-            o.w = ((uint32_t)c * HYDK_ANS_SLOTS + (fbv >> 16)) << (PACK ? 0 : 1); /* plain table: a byte offset */
+            o.w = tab_lds + 2u * ((uint32_t)c * HYDK_ANS_SLOTS + (fbv >> 16));
             s_ops[i] = o;
         }
     }
@@ -1680,50 +1717,105 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     rounds = __builtin_amdgcn_readfirstlane(rounds);
     const int first_count = n - 16 * rj; /* symbols in the lane's first (partial) round: 1..16 */
 
-    uint32_t state;
+    uint32_t state, k0fff, ksel;
     asm volatile("v_mov_b32 %0, 0x130000" : "=v"(state));
+    asm volatile("v_mov_b32 %0, 0xfff" : "=v"(k0fff));       /* constants the walk wants in vector registers */
+    asm volatile("v_mov_b32 %0, 0x05040100" : "=v"(ksel));   /* v_perm_b32: {low half of source 0, low half of source 1} */
     uint4 nx[4];
 #pragma unroll
     for (int q = 0; q < 4; q++)
         nx[q] = rj >= 0 ? load_records4(tok, rj * 4 + q) : uint4{0, 0, 0, 0};
 
-/* slot of (symbol, remainder r): o.w is the list's first index (packed planes) or byte offset (plain u16 table) */
-#define HYDK_LANE_SLOT(base, r)                                                                                        \
-    (PACK ? (uint32_t)s_lo[(base) + (r)] | (__builtin_amdgcn_ubfe((uint32_t)s_hi[((base) + (r)) >> 1], (((base) + (r)) & 1u) << 2, 4u) << 8) \
-          : (uint32_t) * (const uint16_t *)((const unsigned char *)s_inv + ((base) + 2u * (r))))
-/* one symbol: record `rec` (position `pos` of the round, walked from 15 down to 0); PRED: the step
- * only counts if VALID (first round of a lane) */
-#define HYDK_LANE_STEP(o, pos, PRED, VALID)                                                                      \
+/* one symbol the plain way (the first, partial round of a lane): the step only counts if VALID */
+#define HYDK_LANE_STEP_COLD(o, pos, VALID)                                                                       \
     do {                                                                                                         \
         uint32_t x;                                                                                              \
-        /* refill test, renormalised state, and the flag shifted into the round's flag word */                  \
+        const uint32_t thr = (VALID) ? o.x : 0xFFFFFFFFu;                                                        \
         asm("v_cmp_gt_u32 vcc, %2, %3\n\t"                                                                       \
-            "v_cndmask_b32_sdwa %0, %2, %2, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
+            "v_cndmask_b32_sdwa %0, %2, %2, vcc " HYDK_LANE_ASM_SDWA_SELECT "\n\t"                               \
             "v_addc_co_u32 %1, vcc, %1, %1, vcc"                                                                 \
             : "=&v"(x), "+v"(fl)                                                                                 \
-            : "v"(state), "v"((PRED) && !(VALID) ? 0xFFFFFFFFu : o.x)                                            \
+            : "v"(state), "v"(thr)                                                                               \
             : "vcc");                                                                                            \
         if ((pos) & 1) /* the walk goes down: the odd position of a pair comes first */                          \
             w16[(pos) >> 1] = state << 16;                                                                       \
         else                                                                                                     \
             w16[(pos) >> 1] |= state & 0xFFFFu;                                                                  \
         uint32_t q = __umulhi(x, o.y);                                                                           \
-        /* q is floor(x / f) or one less: both candidate remainders, the smaller (unsigned) is x mod f */        \
         const uint32_t r0 = mad24(q, o.z, x);                                                                    \
-        /* r1 = r0 - f; the addition's carry says r0 >= f, which is also what q lacks: one add-with-carry */    \
         uint32_t r1, q1;                                                                                         \
         asm("v_add_co_u32 %0, vcc, %2, %3\n\t"                                                                   \
             "v_addc_co_u32 %1, vcc, 0, %4, vcc"                                                                  \
             : "=&v"(r1), "=v"(q1)                                                                                \
             : "v"(r0), "v"(o.z), "v"(q)                                                                          \
             : "vcc");                                                                                            \
-        const uint32_t r = min(r0, r1);                                                                          \
-        const uint32_t nstate = (q1 << 12) | HYDK_LANE_SLOT(o.w, r);                                             \
-        state = (PRED) && !(VALID) ? state : nstate;                                                             \
+        const uint32_t nstate = (q1 << 12) | (uint32_t) * (LdsU16 *)(uintptr_t)(o.w + 2u * min(r0, r1));        \
+        state = (VALID) ? nstate : state;                                                                        \
+    } while (0)
+
+/* a round's first symbol (position 15): the state arrives in one piece */
+#define HYDK_LANE_STEP_HEAD(o, on)                                                                               \
+    do {                                                                                                         \
+        uint32_t x, q, t0, t1, sln;                                                                              \
+        asm volatile("v_cmp_gt_u32 vcc, %[st], %[thr]\n\t"                                                       \
+                     "v_cndmask_b32_sdwa %[x], %[st], %[st], vcc " HYDK_LANE_ASM_SDWA_SELECT "\n\t"              \
+                     "v_addc_co_u32 %[fl], vcc, %[fl], %[fl], vcc\n\t" HYDK_LANE_ASM_CORE HYDK_LANE_ASM_SHADOW   \
+                     : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [A] "=&v"(A), \
+                       [B] "=&v"(B), [sm] "=&v"(sm), [fl] "+v"(fl)                                               \
+                     : [st] "v"(state), [thr] "v"(o.x), [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w), [thrn] "v"(on.x), \
+                       [k0fff] "v"(k0fff)                                                                        \
+                     : "vcc");                                                                                   \
+        so = state; /* position 15 is odd: filed together with position 14's */                                  \
+        sl = sln;                                                                                                \
+    } while (0)
+/* a symbol in the middle of a round: (A, sl) = the state it meets, in two pieces; B, sm = the renormalised state's */
+#define HYDK_LANE_STEP_BODY(o, on, pos)                                                                          \
+    do {                                                                                                         \
+        uint32_t x, q, t0, t1, sln, st, An, Bn, smn;                                                             \
+        if ((pos) & 1) {                                                                                         \
+            asm volatile("v_and_or_b32 %[x], %[sl], %[smi], %[Bi]\n\t" HYDK_LANE_ASM_CORE                        \
+                         "v_or_b32 %[st], %[Ai], %[sl]\n\t" HYDK_LANE_ASM_SHADOW                                 \
+                         : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
+                           [A] "=&v"(An), [B] "=&v"(Bn), [sm] "=&v"(smn), [fl] "+v"(fl)                          \
+                         : [sl] "v"(sl), [smi] "v"(sm), [Bi] "v"(B), [Ai] "v"(A), [mg] "v"(o.y), [nf] "v"(o.z),   \
+                           [tab] "v"(o.w), [thrn] "v"(on.x), [k0fff] "v"(k0fff)                                  \
+                         : "vcc");                                                                               \
+            so = st;                                                                                             \
+        } else {                                                                                                 \
+            asm volatile("v_and_or_b32 %[x], %[sl], %[smi], %[Bi]\n\t" HYDK_LANE_ASM_CORE                        \
+                         "v_or_b32 %[st], %[Ai], %[sl]\n\t"                                                      \
+                         "v_perm_b32 %[w], %[so], %[st], %[ksel]\n\t" HYDK_LANE_ASM_SHADOW                       \
+                         : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
+                           [w] "=&v"(w16[(pos) >> 1]), [A] "=&v"(An), [B] "=&v"(Bn), [sm] "=&v"(smn), [fl] "+v"(fl) \
+                         : [sl] "v"(sl), [smi] "v"(sm), [Bi] "v"(B), [Ai] "v"(A), [so] "v"(so), [ksel] "v"(ksel), \
+                           [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w), [thrn] "v"(on.x), [k0fff] "v"(k0fff)    \
+                         : "vcc");                                                                               \
+        }                                                                                                        \
+        A = An;                                                                                                  \
+        B = Bn;                                                                                                  \
+        sm = smn;                                                                                                \
+        sl = sln;                                                                                                \
+    } while (0)
+/* a round's last symbol (position 0): the round ends with the state in one piece */
+#define HYDK_LANE_STEP_TAIL(o)                                                                                   \
+    do {                                                                                                         \
+        uint32_t x, q, t0, t1, sln, st, An;                                                                      \
+        asm volatile("v_and_or_b32 %[x], %[sl], %[smi], %[Bi]\n\t" HYDK_LANE_ASM_CORE                            \
+                     "v_or_b32 %[st], %[Ai], %[sl]\n\t"                                                          \
+                     "v_perm_b32 %[w], %[so], %[st], %[ksel]\n\t"                                                \
+                     "v_addc_co_u32 %[q], vcc, 0, %[q], vcc\n\t"                                                 \
+                     "v_lshlrev_b32 %[A], 12, %[q]\n\t"                                                          \
+                     "s_waitcnt lgkmcnt(0)\n\t"                                                                  \
+                     "v_or_b32 %[state], %[A], %[sln]"                                                           \
+                     : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
+                       [w] "=&v"(w16[0]), [A] "=&v"(An), [state] "=&v"(state)                                    \
+                     : [sl] "v"(sl), [smi] "v"(sm), [Bi] "v"(B), [Ai] "v"(A), [so] "v"(so), [ksel] "v"(ksel),     \
+                       [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w)                                              \
+                     : "vcc");                                                                                   \
     } while (0)
 
 /* one round = the 16 symbols of one 64-byte line of records.  The first round of a lane is the partial one (FIRST: only
- * positions below first_count count); it is peeled out of the loop, so that the other rounds carry no selects */
+ * positions below first_count count); it is peeled out of the loop and walks the plain way */
 #define HYDK_LANE_ROUND(FIRST)                                                                                   \
     do {                                                                                                         \
         uint4 cur[4];                                                                                            \
@@ -1737,15 +1829,22 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
             uint32_t w16[8];                                                                                     \
             const uint32_t recs[16] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w, \
                                        cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w}; \
-            /* the record's symbol is the row of s_ops (beyond the stream's end: stale bytes; an LDS read past the   \
-             * table returns 0).  All sixteen rows are requested before the walk: a row requested inside its step \
-             * returns behind the step's slot lookup and lengthens every wait */                                 \
+            /* bits 4-14 of a record are its operand row's byte offset (beyond the stream's end: stale bytes; an LDS \
+             * read past the table returns 0).  All sixteen rows are requested before the walk: a row requested  \
+             * inside its step returns behind the step's slot lookup and lengthens every wait */                 \
             uint4 ov[16];                                                                                        \
             _Pragma("unroll") for (int pos = 15; pos >= 0; pos--)                                                \
-                ov[pos] = s_ops[(FIRST) && !(pos < first_count) ? 0u : recs[pos] & 0x7FFu];                      \
+                ov[pos] = *(const uint4 *)(s_mem + ((FIRST) && !(pos < first_count) ? 0u : recs[pos] & 0x7FF0u)); \
             __builtin_amdgcn_sched_barrier(0); /* (the scheduler would sink the requests back into the steps) */ \
-            _Pragma("unroll") for (int pos = 15; pos >= 8; pos--)                                                \
-                HYDK_LANE_STEP(ov[pos], pos, FIRST, pos < first_count);                                          \
+            uint32_t A = 0, B = 0, sm = 0, sl = 0, so = 0; /* the walk's state between two steps of a round */   \
+            if (FIRST) {                                                                                         \
+                _Pragma("unroll") for (int pos = 15; pos >= 8; pos--)                                            \
+                    HYDK_LANE_STEP_COLD(ov[pos], pos, pos < first_count);                                        \
+            } else {                                                                                             \
+                HYDK_LANE_STEP_HEAD(ov[15], ov[14]);                                                             \
+                _Pragma("unroll") for (int pos = 14; pos >= 8; pos--)                                            \
+                    HYDK_LANE_STEP_BODY(ov[pos], ov[pos - 1], pos);                                              \
+            }                                                                                                    \
             /* the PREVIOUS round's refill words and flags are stored here, in the middle of the walk: vmcnt counts \
              * stores too, and stored at a round's end they were the youngest memory operations when the next round \
              * took its records — that wait was a wait for the stores' round trip */                             \
@@ -1756,8 +1855,14 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
                 flags[prj] = (uint16_t)pfl; /* bit (p mod 16): symbol p refills */                               \
             }                                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
-            _Pragma("unroll") for (int pos = 7; pos >= 0; pos--)                                                 \
-                HYDK_LANE_STEP(ov[pos], pos, FIRST, pos < first_count);                                          \
+            if (FIRST) {                                                                                         \
+                _Pragma("unroll") for (int pos = 7; pos >= 0; pos--)                                             \
+                    HYDK_LANE_STEP_COLD(ov[pos], pos, pos < first_count);                                        \
+            } else {                                                                                             \
+                _Pragma("unroll") for (int pos = 7; pos >= 1; pos--)                                             \
+                    HYDK_LANE_STEP_BODY(ov[pos], ov[pos - 1], pos);                                              \
+                HYDK_LANE_STEP_TAIL(ov[0]);                                                                      \
+            }                                                                                                    \
             _Pragma("unroll") for (int q = 0; q < 8; q++) pw[q] = w16[q];                                        \
             pfl = fl;                                                                                            \
             refills += (uint32_t)__popc(fl);                                                                     \
@@ -1782,8 +1887,10 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
         aux[prj * 2 + 1] = uint4{pw[4], pw[5], pw[6], pw[7]};
         flags[prj] = (uint16_t)pfl;
     }
-#undef HYDK_LANE_STEP
-#undef HYDK_LANE_SLOT
+#undef HYDK_LANE_STEP_TAIL
+#undef HYDK_LANE_STEP_BODY
+#undef HYDK_LANE_STEP_HEAD
+#undef HYDK_LANE_STEP_COLD
     if (lane < ngroups) {
         final_state_all[G] = state;
         /* [preset id][final state][per symbol: refill word, residue bits] (encoder.c:945, entropy.c:1127-1147) */
@@ -1936,7 +2043,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
         for (int j = 0; j < kEmitPer; j++) {
             const bool valid = p0 + j < n;
             const bool refill = valid && ((flq >> j) & 1u);
-            const uint32_t rbits = (recs[j] >> 11) & 0x1Fu, residue = recs[j] >> 16;
+            const uint32_t rbits = HYDK_REC32_RBITS(recs[j]), residue = recs[j] >> 16;
             /* refill p is written just before residue p (entropy.c:1134-1147): at most 16 + 16 bits for integer input */
             val[j] = refill ? (residue << 16) | aw[j] : residue;
             nb[j] = valid ? rbits + (refill ? 16u : 0u) : 0u;
@@ -2271,14 +2378,23 @@ hipError_t launch_rans_deferred(const HydkLfJob *d_jobs, const uint32_t *sym_cou
 hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count, const HydkTables *tabs, uint16_t *aux,
                              uint16_t *flags, uint32_t aux_pitch, uint32_t *final_state, uint32_t *group_bits, int preset_bits,
                              int nclusters, int num_slots, const uint32_t *status, const uint32_t *lf_hist,
-                             HydkLfStream *lf_streams, void *lf_work, bool packed_tables, hipStream_t stream) {
+                             HydkLfStream *lf_streams, void *lf_work, hipStream_t stream) {
     const dim3 grid(lf_hist ? 2 * num_slots : num_slots);
-    if (packed_tables)
-        hipLaunchKernelGGL(k_rans_lanes<true>, grid, dim3(64), 0, stream, d_jobs, sym_count, tabs, aux, flags, aux_pitch,
-                           final_state, group_bits, nclusters, preset_bits, status, num_slots, lf_hist, lf_streams, lf_work);
+#define HYDK_LAUNCH_LANES(NC)                                                                                                  \
+    hipLaunchKernelGGL(k_rans_lanes<NC>, grid, dim3(64), 0, stream, d_jobs, sym_count, tabs, aux, flags, aux_pitch, final_state, \
+                       group_bits, preset_bits, status, num_slots, lf_hist, lf_streams, lf_work)
+    /* the tables in LDS are sized by the clustering scheme (encoder.c:862-901: 9 / 3 / 2 / 1 clusters per preset) */
+    if (nclusters == 9)
+        HYDK_LAUNCH_LANES(9);
+    else if (nclusters == 3)
+        HYDK_LAUNCH_LANES(3);
+    else if (nclusters == 2)
+        HYDK_LAUNCH_LANES(2);
+    else if (nclusters == 1)
+        HYDK_LAUNCH_LANES(1);
     else
-        hipLaunchKernelGGL(k_rans_lanes<false>, grid, dim3(64), 0, stream, d_jobs, sym_count, tabs, aux, flags, aux_pitch,
-                           final_state, group_bits, nclusters, preset_bits, status, num_slots, lf_hist, lf_streams, lf_work);
+        return hipErrorInvalidValue;
+#undef HYDK_LAUNCH_LANES
     return hipGetLastError();
 }
 

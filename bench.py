@@ -57,12 +57,12 @@ def parse():
     ap.add_argument("--depth", type=int, default=16, choices=(8, 16))
     ap.add_argument("--kind", default="photo")
     ap.add_argument("--streams", type=int, default=16, help="contexts (one HIP stream each), frames-per-launch-group frames in flight on each")
-    ap.add_argument("--rans-waves", type=int, default=6, choices=(4, 5, 6),
+    ap.add_argument("--rans-waves", type=int, default=5, choices=(4, 5, 6),
                     help="entropy-stage form of the frame loop and the shard leg, see hydamd_set_rans_waves: 5 = one lane per group, a "
-                         "wavefront per LF group; 6 = the same with packed tables (62 KB of LDS per chain, not 80; chains 2.26 against 2.07 ms "
-                         "alone); 4 = one wave per group (lowest single-frame latency).  Last A/B, three alternating full runs: loop "
-                         "151.0 (form 6) against 148.8 Gpixel/s, shard 1.97 against 2.03 ms; the 4K batch, where the chain's own duration "
-                         "counts, 4 467 against 4 731 frames/s — that leg always runs form 5")
+                         "wavefront per LF group (tables in LDS sized by the clustering scheme since round 5); 4 = one wave per group "
+                         "(lowest single-frame latency); 6 = rounds 3-4's packed-table variant of 5, now another name of 5")
+    ap.add_argument("--no-content", action="store_true",
+                    help="frame mode: leave out the rows for SURVEY 8(d)'s other two synthetic inputs (smooth, noise)")
     ap.add_argument("--lf-coder", default="on", choices=("on", "off"),
                     help="code the LF coefficient streams on the GPU inside the timed loop (default) or leave them out")
     ap.add_argument("--collective", default="gather", choices=("gather", "all-gather"),
@@ -542,6 +542,168 @@ def run_batch(args):
         emit(out)
 
 
+def loop_rate(ctxs, groups, ext, W, H, FPL, prime_groups, timed_groups):
+    """the frame loop of `main`, stripped: contexts take launch groups in turn; HIP events at the end of every group's stream;
+    -> sustained Mpixel/s over `timed_groups` groups per stream behind `prime_groups` of priming"""
+    import torch
+
+    S = len(ctxs)
+    evs = []
+    n = (prime_groups + timed_groups + 1) * S
+    for i in range(n):
+        k = i % S
+        ctxs[k].encode_image_batch(groups[k]) if FPL > 1 else ctxs[k].encode_image_tensor(groups[k][0])
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(ext[k])
+        evs.append(e)
+    for c in ctxs:
+        c.sync()
+    torch.cuda.synchronize()
+    done = [evs[0].elapsed_time(e) for e in evs]
+    a, b = prime_groups * S, (prime_groups + timed_groups) * S
+    t0, t1 = sum(done[a - S:a]) / S, sum(done[b - S:b]) / S
+    return W * H * FPL * timed_groups * S / ((t1 - t0) * 1e-3) / 1e6
+
+
+def content_row(args, kind, local):
+    """SURVEY 8(d) / BASELINE.md 3 name three synthetic inputs: 'photo' is the contract line; this is the same set of figures
+    for one of the other two (8192x8192 RGB16): the pipelined loop's sustained rate, one frame alone, the drop-in API end to
+    end, each beside the CPU reference on one core over the same frame, with the byte-equality verdict."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from hydrium_amd import api, device, synth
+    from oracle import refprobe
+
+    W = H = args.size
+    S, FPL = max(1, args.streams), max(1, args.frames_per_launch)
+    lfg = (-(-W // 2048)) * (-(-H // 2048))
+    dev = torch.device("cuda", local)
+    img = synth.make_image(kind, W, H, args.depth, device=dev)
+    torch.cuda.synchronize()
+    row = {"kind": kind}
+    ctxs = [device.DeviceContext(local, lfg * FPL, 0) for _ in range(S)]
+    try:
+        ext = [torch.cuda.ExternalStream(c.get_stream()) for c in ctxs]
+        groups = [[img] * FPL for _ in ctxs]
+        for c in ctxs:
+            c.set_rans_waves(args.rans_waves)
+            c.set_lf_coder(2)
+            c.encode_image_batch([img] * FPL) if FPL > 1 else c.encode_image_tensor(img)
+        for c in ctxs:
+            c.sync()  # (a frame that outgrows the default buffers — noise: 2.9 symbols per pixel — is rerun in here, once)
+        row["overflow_reruns_first_frame"] = int(sum(c.overflow_reruns() for c in ctxs))
+        rate = loop_rate(ctxs, groups, ext, W, H, FPL, 4, 6)
+        row["Mpixel/s"] = round(rate, 1)
+        row["ms_per_frame_in_the_loop"] = round(W * H / rate / 1e3, 4)
+        row["symbols_per_pixel"] = round(sum(int(ctxs[0].read_symbol_counts(s).sum()) for s in range(lfg)) / (W * H), 4)
+        row["section_bytes"] = ctxs[0].payload_size() // FPL
+        c0 = ctxs[0]
+        for form, key in ((max(5, args.rans_waves), "lane_form"), (4, "wave_form")):
+            c0.set_rans_waves(form)
+            c0.set_lf_coder(2 if form >= 5 else 1)
+            c0.encode_image_tensor(img)
+            c0.sync()
+            c0.profile(True)
+            t = time.perf_counter()
+            for _ in range(3):
+                c0.encode_image_tensor(img)
+                c0.sync()
+            t = (time.perf_counter() - t) / 3
+            k = {n_: round(ms / max(n, 1), 4) for n_, (ms, n) in c0.profile_read().items()}
+            c0.profile(False)
+            row["single_frame_" + key] = {"ms_per_frame": round(t * 1e3, 4), "transform_ms": k.get("transform_tokenize"), "chains_ms": k.get("rans_encode")}
+    finally:
+        for c in ctxs:
+            c.close()
+    arr = img.cpu().numpy()
+    host = np.ascontiguousarray(arr.view(np.uint16) if args.depth == 16 else arr)
+    del img
+    torch.cuda.empty_cache()
+    lib = api.Library()
+    big = (ctypes.c_uint8 * (256 << 20))()  # noise compresses to ~2 bytes per pixel
+    api.encode_image(lib, host, out_buf=big)
+    times = []
+    for _ in range(3):
+        t = time.perf_counter()
+        data = api.encode_image(lib, host, out_buf=big, in_place=True)
+        times.append(time.perf_counter() - t)
+    data = bytes(data)
+    row["api_end_to_end"] = {"ms": round(sorted(times)[1] * 1e3, 1), "bytes": len(data), "md5": hashlib.md5(data).hexdigest()}
+    if refprobe.available() and not args.no_cpu_baseline:
+        t = time.perf_counter()
+        ref = api.encode_image(refprobe.reference_library(), host, out_buf_size=64 << 20)
+        t = time.perf_counter() - t
+        row["cpu_baseline"] = {"value": round(W * H / t / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "reference",
+                               "sample": f"the whole frame once through hyd_send_tile ({t:.1f} s of CPU work)", "bytes": len(ref)}
+        row["api_end_to_end"]["identical_to_cpu_reference"] = ref == data
+    trim = getattr(lib.dll, "hydamd_trim_cache", None)
+    if trim is not None:
+        trim.restype = None
+        trim()
+    return row
+
+
+_MULTI_DEVICE_CLIENT = r"""
+import ctypes, hashlib, json, sys, time
+import numpy as np
+import torch
+from hydrium_amd import api, synth
+size, verify = int(sys.argv[1]), int(sys.argv[2])
+t = synth.make_image("photo", size, size, 8, device="cuda")
+torch.cuda.synchronize()
+img = np.ascontiguousarray(t.cpu().numpy())
+del t
+torch.cuda.empty_cache()
+lib = api.Library()
+buf = (ctypes.c_uint8 * (96 << 20))()
+t0 = time.perf_counter()
+api.encode_image(lib, img, out_buf=buf)
+first = time.perf_counter() - t0
+times = []
+for _ in range(5):
+    t0 = time.perf_counter()
+    data = api.encode_image(lib, img, out_buf=buf, in_place=True)
+    times.append(time.perf_counter() - t0)
+data = bytes(data)
+print("RESULT " + json.dumps({"ms": round(sorted(times)[2] * 1e3, 2), "ms_each": [round(x * 1e3, 2) for x in times],
+                              "first_call_ms": round(first * 1e3, 1), "bytes": len(data), "md5": hashlib.md5(data).hexdigest()}))
+"""
+
+
+def api_multi_device_leg(ndev, size=16384):
+    """The multi-device tile scheduler INSIDE the C library (csrc/host/encoder.c finish_frame_multi): one process, one
+    encoder, `hyd_send_tile` from host memory, the frame's LF groups dealt to every device of HYDAMD_DEVICES, the frame
+    assembled on the first one from peer reads.  On a box with ONE GPU the list names it four times (four contexts, every
+    cross-context step taken, only the xGMI hop missing).  A process of its own: the device list is read once per process,
+    and this one's API legs are pinned to its own GPU.  A second run with HYDAMD_VERIFY_PEERS=1 checks every shard's view
+    on both sides of the peer read."""
+    import subprocess
+
+    devices = ",".join(str(d) for d in range(ndev)) if ndev > 1 else "0,0,0,0"
+    out = {"devices": devices, "aliased": ndev <= 1,
+           "workload": f"one {size}x{size} RGB8 'photo' frame (BASELINE configs[3]) from host memory through hyd_send_tile, one-frame mode; "
+                       "PCIe, peer reads, assembly on the first device and read-back inclusive; median of 5 frames after the first"}
+    for verify in (0, 1):
+        env = dict(os.environ, PYTHONPATH=ROOT, HYDAMD_DEVICES=devices, HYDAMD_VERIFY_PEERS=str(verify))
+        for k in ("HYDAMD_DEVICE", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, "-c", _MULTI_DEVICE_CLIENT, str(size), str(verify)], capture_output=True, text=True, env=env, timeout=600)
+        line = next((l for l in r.stdout.splitlines() if l.startswith("RESULT ")), None)
+        if r.returncode or not line:
+            out["error" if not verify else "verify_error"] = (r.stderr or r.stdout)[-400:]
+            break
+        res = json.loads(line[7:])
+        if not verify:
+            out.update(res)
+            out["Mpixel/s"] = round(size * size / res["ms"] / 1e3, 1)
+        else:
+            out["with_peer_views_verified"] = {"ms": res["ms"], "same_file": res["md5"] == out.get("md5")}
+    return out
+
+
 def main():
     args = parse()
     if args.mode == "shard":
@@ -581,10 +743,16 @@ def main():
     gx = sharding.slab_grid(world)[0]
     img = synth.make_image(args.kind, W, H, args.depth, x0=(rank % gx) * W, y0=(rank // gx) * H,
                            device=torch.device("cuda", local))
-    torch.cuda.synchronize()
     lfg = (-(-W // 2048)) * (-(-H // 2048))
     ctxs = [device.DeviceContext(local, lfg * FPL, 0) for _ in range(max(1, args.streams))]
-    group = [img] * FPL
+    # every frame a context holds is a picture of its own — windows of the synthetic image stacked below the ranks' slabs,
+    # 0.4 GB each of 288 — so that no cache can serve one context's pixels to another (round 4 coded one tensor everywhere).
+    # Context 0's first frame is `img`, the picture the single-frame, API and CPU legs code.
+    gy = -(-world // gx)
+    pictures = [[img if (k, f) == (0, 0) else
+                 synth.make_image(args.kind, W, H, args.depth, x0=(rank % gx) * W, y0=((1 + k * FPL + f) * gy + rank // gx) * H,
+                                  device=torch.device("cuda", local)) for f in range(FPL)] for k in range(len(ctxs))]
+    torch.cuda.synchronize()
     for c in ctxs:
         c.set_rans_waves(args.rans_waves)
         # throughput loop: the LF coder runs at the end of each context's own stream (mode 2), so that
@@ -617,16 +785,16 @@ def main():
         ctx = ctxs[k]
         if not exchange:
             if FPL > 1:
-                ctx.encode_image_batch(group)
+                ctx.encode_image_batch(pictures[k])
             else:
-                ctx.encode_image_tensor(img)
+                ctx.encode_image_tensor(pictures[k][0])
             return ctx
         j = k // per
         half = (i // len(ctxs)) & 1
         with torch.cuda.stream(ext[k]):
             if xstate["work"][j][half] is not None:
                 xstate["work"][j][half].wait()  # device-side: this stream waits until the gather that last read this buffer is done
-            ctx.encode_image_tensor(img)
+            ctx.encode_image_tensor(pictures[k][0])
             t_b = time.perf_counter()
             ctx.export_frame(lfg, xstate["big"][j][half][k % per])
             xt[1] += time.perf_counter() - t_b
@@ -658,8 +826,8 @@ def main():
 
     # initialisation, not measurement: every context codes one frame once so that its freshly
     # allocated buffers have been touched before anything is timed; then the W warm-up steps
-    for c in ctxs:
-        step_init = c.encode_image_batch(group) if FPL > 1 else c.encode_image_tensor(img)
+    for k, c in enumerate(ctxs):
+        step_init = c.encode_image_batch(pictures[k]) if FPL > 1 else c.encode_image_tensor(pictures[k][0])
     for c in ctxs:
         c.sync()
     if exchange:
@@ -810,8 +978,14 @@ def main():
         with device.DeviceContext(local, lfg, 0) as v, device.Assembler(local) as asm:
             v.set_rans_waves(args.rans_waves)
             v.set_lf_coder(2)
+            alone = []
+            for k in range(len(ctxs)):  # every picture coded alone, in the order `held` lists them; `img` (context 0, frame 0) last
+                for f in range(FPL):
+                    if (k, f) != (0, 0):
+                        v.encode_image_tensor(pictures[k][f])
+                        alone.append(frame_digests(v, 1)[0])
             v.encode_image_tensor(img)
-            alone = frame_digests(v, 1)[0]
+            alone.insert(0, frame_digests(v, 1)[0])
             asm.plan(md, [list(range(lfg))])
             out_buf = torch.empty(v.blob_bound(lfg) + (1 << 20), dtype=torch.uint8, device=img.device)
             vs = torch.cuda.ExternalStream(v.get_stream())
@@ -822,9 +996,9 @@ def main():
             file_md5 = hashlib.md5(out_buf[:asm.result()].cpu().numpy()).hexdigest()
             del out_buf
         timed_files = {"contexts": len(ctxs), "frames_per_launch_group": FPL, "frames_hashed": len(held),
-                       "all_identical": len(set(held)) == 1,
-                       "sections_and_lf_streams_equal_the_frame_coded_alone": set(held) == {alone},
-                       "md5": file_md5, "md5_is": "the frame coded alone, exported and assembled on the device"}
+                       "distinct_pictures": len(set(alone)),
+                       "sections_and_lf_streams_equal_the_frame_coded_alone": held == alone,
+                       "md5": file_md5, "md5_is": "context 0's first picture coded alone, exported and assembled on the device"}
 
     # single-frame latency leg: one stream, one wave per group (the lowest-latency entropy form),
     # each frame synchronised before the next starts; kernels run alone, so these are also the
@@ -882,7 +1056,7 @@ def main():
     # the same loop with ONE frame per launch group (what rounds 1-3 timed)
     one_per_group = None
     if world == 1 and FPL > 1 and not args.no_legs:
-        r1 = timed_run(8 * S, lambda i: ctxs[i % S].encode_image_tensor(img))
+        r1 = timed_run(8 * S, lambda i: ctxs[i % S].encode_image_tensor(pictures[i % S][0]))
         one_per_group = {"Mpixel/s": round(W * H * 8 * S / r1["dt"] / 1e6, 1), "ms_per_step": round(r1["dt"] / (8 * S) * 1e3, 4), "frames": 8 * S,
                          "note": "same loop, contexts and timing, hydamd_encode_image: every frame a launch group of its own"}
 
@@ -900,7 +1074,7 @@ def main():
         def step_file(i):
             k = i % S
             with torch.cuda.stream(ext[k]):
-                ctxs[k].encode_image_tensor(img)
+                ctxs[k].encode_image_tensor(pictures[k][0])
                 ptr, n = ctxs[k].export_frame_owned(lfg)  # a view: records only, the sections stay in the context's buffers
                 asms[k].run([ptr], [n], outs_w[k].data_ptr(), outs_w[k].numel(), ext[k].cuda_stream)
 
@@ -969,7 +1143,7 @@ def main():
             "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / K * 1e3, 4),
-            "value_is": "the SUSTAINED rate: median of three consecutive 512-frame windows of one continuous run behind 0.2 s of priming "
+            "value_is": "the SUSTAINED rate: median of three consecutive windows (timing.timed_frames frames each) of one continuous run behind ten launch groups per stream of priming "
                         "(it equals the barrier-to-barrier rate of the whole run, timing.Mpixel/s_wall, within a few per cent)",
             "value_by_the_method_of_rounds_1_to_3": round(world * W * H * 2 * S * FPL / burst["dt"] / 1e6, 1),
             "value_by_the_method_of_rounds_1_to_3_is": "a short event window right behind a short priming phase, from an idle GPU (BENCH_r03: 136 941 by this "
@@ -1021,7 +1195,7 @@ def main():
                          if exchange else None),
             "timed_contexts_as_files": timed_files,
             "single_frame": lat,
-            "single_frame_form5": lat5,  # the loop's own lane-per-group form (5, or 6 = packed tables), un-overlapped
+            "single_frame_form5": lat5,  # the loop's own lane-per-group form, un-overlapped
             "hf_sections_only": hf_only,
             "one_frame_per_launch_group": one_per_group,
             "finished_file_per_step": whole_file,
@@ -1048,6 +1222,9 @@ def main():
     for c in ctxs:
         c.close()
     del img
+    pictures = None
+    gc.collect()
+    torch.cuda.empty_cache()
 
     # ---- the other two BASELINE workloads, a few hundred milliseconds each, in the same line: configs[3] (one 16K frame
     # sharded over the GPUs, assembled on the device) and configs[4] (a batch of 4K frames through the drop-in API) ----
@@ -1114,6 +1291,22 @@ def main():
                 timed_files["identical_to_api_file"] = timed_files["md5"] == out["api_end_to_end"]["md5"]
             if whole_file:
                 whole_file["identical_to_api_file"] = whole_file["md5"] == out["api_end_to_end"]["md5"]
+        if world == 1 and not args.no_content and not args.no_legs and not args.no_api:
+            # SURVEY 8(d)'s other two synthetic inputs, each with its own CPU baseline and byte-equality verdict
+            out["content"] = {}
+            for kind in ("smooth", "noise"):
+                try:
+                    out["content"][kind] = content_row(args, kind, local)
+                except Exception as exc:
+                    out["content"][kind] = {"error": f"{type(exc).__name__}: {exc}"}
+        if not args.no_legs and not args.no_api:
+            # the C library's own multi-device scheduler, over every GPU of the job (one GPU: an aliased list), once, on rank 0
+            try:
+                out["api_multi_device"] = api_multi_device_leg(world)
+                if "shard_16k" in out and "frame_md5" in out["shard_16k"] and "md5" in out["api_multi_device"]:
+                    out["api_multi_device"]["same_file_as_shard_16k"] = out["api_multi_device"]["md5"] == out["shard_16k"]["frame_md5"]
+            except Exception as exc:
+                out["api_multi_device"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_img)
             if "api_end_to_end" in out and "md5" in out["cpu_baseline"]:

@@ -228,6 +228,8 @@ def encode_image(lib: Library, img: np.ndarray, *, linear_light: int = 0, shift_
             if explicit_last or order is not None:
                 is_last = 1 if i == len(tiles) - 1 else 0
             ret = enc.check(enc.send_tile(src, tx, ty, tw, th, is_last, layout))
+            if in_place and out_buf is not None and (shift_x < 0 or shift_y < 0) and i != len(tiles) - 1:
+                continue  # one-frame mode: nothing but the file header exists before the final tile; it waits in `buf`
             while True:
                 ret = enc.check(enc.flush())
                 code, n = enc.release_output()

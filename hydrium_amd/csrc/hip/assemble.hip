@@ -587,7 +587,8 @@ struct HydkAsm {
     uint8_t *own_out = nullptr;   /* output buffer for callers that bring none (hydk_asm_run with out == NULL) */
     size_t own_cap = 0;
     uint8_t *last_out = nullptr;  /* where the last run wrote */
-    hipStream_t last_stream = nullptr; /* ... and the stream it ran in */
+    hipStream_t last_stream = nullptr; /* ... and the stream it ran in (the caller's: it must outlive hydk_asm_read of that run) */
+    hipEvent_t done = nullptr;    /* the assembler's own: recorded behind every run; what a plan change and a run in another stream wait for */
     uint64_t last_cap = 0;        /* ... and how large that buffer is */
     bool ran = false;
     uint8_t *bounce = nullptr;    /* pinned: hydk_asm_read lands frames here (DMA engines), then copies to the caller's memory */
@@ -629,6 +630,8 @@ void hydk_asm_destroy(HydkAsm *a) {
         (void)hipHostFree(a->h_result);
     if (a->bounce)
         (void)hipHostFree(a->bounce);
+    if (a->done)
+        (void)hipEventDestroy(a->done);
     delete a;
 }
 
@@ -655,6 +658,7 @@ static int asm_alloc(HydkAsm *a) {
     ASM_TRY(a, hipMalloc(&a->S.result, 2 * sizeof(uint64_t)));
     ASM_TRY(a, hipHostMalloc((void **)&a->h_result, 2 * sizeof(uint64_t), hipHostMallocDefault));
     a->h_result[0] = a->h_result[1] = 0;
+    ASM_TRY(a, hipEventCreateWithFlags(&a->done, hipEventDisableTiming));
     return ST_OK;
 }
 
@@ -687,10 +691,12 @@ int hydk_asm_set_plan(HydkAsm *a, const void *plan, size_t bytes) {
         hp->toc_n != 2 + hp->num_slots + hp->frame_groups || hp->ntails > HYDK_ASM_MAX_TAILS)
         return afail(a, ST_API_ERROR, "inconsistent plan");
     ASM_TRY(a, hipSetDevice(a->device));
-    /* an earlier frame may still be reading the old plan: wait for ITS stream only (a device-wide wait would stall every
-     * other encoder thread's frames in a batch of differently shaped images) */
+    /* an earlier frame may still be reading the old plan: wait for IT only (a device-wide wait would stall every other
+     * encoder thread's frames in a batch of differently shaped images) — by the assembler's own event, not by the caller's
+     * stream handle, which may be gone by now; runs in different streams are chained behind each other (hydk_asm_run), so
+     * the last run's event covers them all */
     if (a->ran)
-        ASM_TRY(a, hipStreamSynchronize(a->last_stream));
+        ASM_TRY(a, hipEventSynchronize(a->done));
     if (bytes > a->plan_cap) {
         if (a->plan)
             (void)hipFree(a->plan);
@@ -733,6 +739,8 @@ int hydk_asm_run(HydkAsm *a, const void *const *blobs, const uint64_t *blob_caps
     /* k_asm_copy moves whole 32-bit words of the output and 16-byte-aligned records of the blobs */
     if ((uintptr_t)out & 3u)
         return afail(a, ST_API_ERROR, "output buffer must be 4-byte aligned");
+    if (a->ran && st != a->last_stream) /* the runs share the assembler's scratch arrays: one behind the other */
+        ASM_TRY(a, hipStreamWaitEvent(st, a->done, 0));
     a->last_out = (uint8_t *)out;
     a->last_cap = out_cap;
     a->last_stream = st;
@@ -751,6 +759,7 @@ int hydk_asm_run(HydkAsm *a, const void *const *blobs, const uint64_t *blob_caps
                        a->h_result);
     hipLaunchKernelGGL(k_asm_copy, dim3(kCopyBlocks), dim3(256), 0, st, a->S, (uint8_t *)out);
     ASM_TRY(a, hipGetLastError());
+    ASM_TRY(a, hipEventRecord(a->done, st));
     return ST_OK;
 }
 

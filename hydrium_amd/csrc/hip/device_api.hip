@@ -117,8 +117,10 @@ struct HydAmdContext {
     int linear_light = 0;
     int use_luts = 2;               /* XYB mode: 0 registers + fast reciprocal, 1 registers + IEEE division, 2 LUT gathers */
     int best_register_mode = 2;     /* best mode that passed the bit-exactness self-test */
+    int curve_gathers = 0;          /* hydamd_set_curve_gathers: 0 by the last frame's density, 1 always (round 4), 2 never */
+    uint64_t published_pixels = 0;  /* pixels of the frame whose section total k_publish wrote last */
     int register_luts_ok = 0;
-    int rans_lanes = 0;             /* entropy-stage form: 0 wave per group (form 4), 1 lane per group (form 5; float frames still take form 4), 2 the same with packed tables (form 6) */
+    int rans_lanes = 0;             /* entropy-stage form: 0 wave per group (form 4), non-zero lane per group (form 5, also what 6 asks for; float frames still take form 4) */
     uint32_t tok_cap = HYDK_DEFAULT_TOKEN_CAP; /* token records per group the arrays below hold */
     uint32_t rec_bytes = 4;         /* their record size: 4 until a float LF group is recorded, then 8 */
     uint32_t bit_pitch_words = 0;   /* words per group in bitbuf (0: not allocated yet) */
@@ -133,8 +135,6 @@ struct HydAmdContext {
     int preset_bits = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipStream_t chain_stream = nullptr;        /* HYDAMD_CHAIN_CUS: the device's shared stream (restricted to the chains' compute units) this context's chains run in */
-    hipEvent_t chain_go = nullptr, chain_done = nullptr;
     char error[256] = "";
 
     /* device memory */
@@ -218,6 +218,7 @@ struct HydAmdContext {
     /* several contexts (devices) working on one frame: hydamd_wait_for, hydamd_alphabet_floor_from_peers */
     hipEvent_t peer_event = nullptr; /* "everything enqueued so far on this context's stream" */
     uint32_t *peer_floor = nullptr;  /* [1] the floor k_floor_from_peers leaves for the table kernel */
+    unsigned long long *verify_sums = nullptr; /* [HYDAMD_MAX_PEERS] checksums of frame views (hydamd_verify_enqueue) */
 
     /* the drop-in API's frame assembly on the device (hydamd_export_frame_owned, hydamd_context_assembler) */
     void *own_blob = nullptr;
@@ -400,50 +401,6 @@ constexpr int kMaxSharedCopyStreams = 8;
 static std::mutex g_copy_lock;
 static hipStream_t g_copy_streams[HYDAMD_MAX_PEERS * 2][kMaxSharedCopyStreams];
 static unsigned g_copy_next[HYDAMD_MAX_PEERS * 2];
-
-/* HYDAMD_CHAIN_CUS=R (experiment, VERDICT r4 task 1b): the lane-form chains run on R compute units of their own — the device's
- * HYDAMD_CHAIN_STREAMS (default 4) shared streams are created with a CU mask of R units (mask bits are dealt to the XCDs in
- * turn: the low R bits are R / 8 units of every XCD), every context's own stream with the complement — so that a chain
- * never shares a compute unit's LDS pipeline and issue ports with transform workgroups, and never takes a transform
- * workgroup's place. */
-static int chain_cus() {
-    static const int v = [] {
-        const char *e = getenv("HYDAMD_CHAIN_CUS");
-        const int n = e && *e ? atoi(e) : 0;
-        return n < 0 ? 0 : n > 128 ? 128 : n;
-    }();
-    return v;
-}
-static hipStream_t g_chain_streams[HYDAMD_MAX_PEERS * 2][kMaxSharedCopyStreams];
-static unsigned g_chain_next[HYDAMD_MAX_PEERS * 2];
-static hipError_t create_masked_stream(hipStream_t *out, int device, int first_cu, int end_cu) {
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, device);
-    if (e != hipSuccess)
-        return e;
-    uint32_t mask[16] = {0};
-    const int total = prop.multiProcessorCount > 512 ? 512 : prop.multiProcessorCount;
-    for (int cu = first_cu; cu < end_cu && cu < total; cu++)
-        mask[cu >> 5] |= 1u << (cu & 31);
-    return hipExtStreamCreateWithCUMask(out, (uint32_t)((total + 31) / 32), mask);
-}
-static int acquire_chain_stream(HydAmdContext *ctx) {
-    if (!chain_cus() || ctx->device < 0 || ctx->device >= HYDAMD_MAX_PEERS * 2)
-        return ST_OK;
-    static const int shared = [] {
-        const char *v = getenv("HYDAMD_CHAIN_STREAMS");
-        const int n = v && *v ? atoi(v) : 4;
-        return n < 1 ? 1 : n > kMaxSharedCopyStreams ? kMaxSharedCopyStreams : n;
-    }();
-    std::lock_guard<std::mutex> hold(g_copy_lock);
-    const unsigned k = g_chain_next[ctx->device]++ % (unsigned)shared;
-    if (!g_chain_streams[ctx->device][k])
-        HIP_TRY(ctx, create_masked_stream(&g_chain_streams[ctx->device][k], ctx->device, 0, chain_cus()));
-    ctx->chain_stream = g_chain_streams[ctx->device][k];
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chain_go, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chain_done, hipEventDisableTiming));
-    return ST_OK;
-}
 
 int acquire_copy_stream(HydAmdContext *ctx) {
     static const int shared = [] {
@@ -726,6 +683,8 @@ void hydamd_destroy(HydAmdContext *ctx) {
         (void)hipEventDestroy(ctx->peer_event);
     if (ctx->peer_floor)
         (void)hipFree(ctx->peer_floor);
+    if (ctx->verify_sums)
+        (void)hipFree(ctx->verify_sums);
     if (ctx->h_lf_total_pinned)
         (void)hipHostFree(ctx->h_lf_total_pinned);
     void *lfdev[] = {ctx->lf_recs, ctx->lf_codes, ctx->lf_work, ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total};
@@ -754,10 +713,6 @@ void hydamd_destroy(HydAmdContext *ctx) {
         (void)hipHostFree(ctx->h_total_pinned);
     if (ctx->h_status_pinned)
         (void)hipHostFree(ctx->h_status_pinned);
-    if (ctx->chain_go)
-        (void)hipEventDestroy(ctx->chain_go);
-    if (ctx->chain_done)
-        (void)hipEventDestroy(ctx->chain_done);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -828,6 +783,24 @@ static int acquire_shared_luts(HydAmdContext *ctx) {
             return ST_OK;
         }
     SharedLuts l = {ctx->device, ctx->linear_light, nullptr, nullptr, nullptr, 2};
+    uint32_t *mism = nullptr;
+    struct Guard { /* an error part of the way through hands back what was allocated so far */
+        SharedLuts *l;
+        uint32_t **mism;
+        bool keep = false;
+        ~Guard() {
+            if (*mism)
+                (void)hipFree(*mism);
+            if (!keep) {
+                if (l->in_lut8)
+                    (void)hipFree(l->in_lut8);
+                if (l->in_lut16)
+                    (void)hipFree(l->in_lut16);
+                if (l->bias_lut)
+                    (void)hipFree(l->bias_lut);
+            }
+        }
+    } guard{&l, &mism};
     HIP_TRY(ctx, hipMalloc(&l.in_lut8, 256 * sizeof(uint16_t)));
     HIP_TRY(ctx, hipMalloc(&l.in_lut16, 65536 * sizeof(uint16_t)));
     HIP_TRY(ctx, hipMalloc(&l.bias_lut, 65536 * sizeof(float)));
@@ -841,7 +814,6 @@ static int acquire_shared_luts(HydAmdContext *ctx) {
     HIP_TRY(ctx, hipMemcpy(l.in_lut8, l8.data(), 256 * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(l.in_lut16, l16.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(l.bias_lut, bias.data(), 65536 * sizeof(float), hipMemcpyHostToDevice));
-    uint32_t *mism = nullptr;
     HIP_TRY(ctx, hipMalloc(&mism, sizeof(uint32_t)));
     for (int mode = 0; mode < 2 && l.best_register_mode == 2; mode++) {
         uint32_t h_mism = 1;
@@ -852,7 +824,7 @@ static int acquire_shared_luts(HydAmdContext *ctx) {
         if (h_mism == 0)
             l.best_register_mode = mode;
     }
-    (void)hipFree(mism);
+    guard.keep = true;
     g_luts.push_back(l);
     ctx->in_lut8 = l.in_lut8;
     ctx->in_lut16 = l.in_lut16;
@@ -864,14 +836,7 @@ static int acquire_shared_luts(HydAmdContext *ctx) {
 static int create_impl(HydAmdContext *ctx, int debug_planes) {
     const size_t slots = (size_t)ctx->max_slots, G = HYDK_GROUPS_PER_LFG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (chain_cus()) {
-        HIP_TRY(ctx, create_masked_stream(&ctx->own_stream, ctx->device, chain_cus(), 1 << 20));
-        const int st = acquire_chain_stream(ctx);
-        if (st != ST_OK)
-            return st;
-    } else {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
-    }
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     if (const char *env = getenv("HYDAMD_TOKEN_CAP")) { /* records per group before the overflow path kicks in (tests) */
         const long v = atol(env);
@@ -965,6 +930,9 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
         else if (w >= 1 && w <= 3)
             ctx->rans_lanes = retired_rans_form(w);
     }
+    if (const char *env = getenv("HYDAMD_CURVE_GATHERS")) /* A/B: 1 always, 2 never */
+        if (atoi(env) >= 0 && atoi(env) <= 2)
+            ctx->curve_gathers = atoi(env);
     if (const char *env = getenv("HYDAMD_LF_CODER")) /* 0: leave the LF ints to the host coder (A/B measurements) */
         ctx->lf_on_device = atoi(env) == 2 ? 2 : atoi(env) != 0;
     if (const char *env = getenv("HYDAMD_XYB_MODE")) { /* 0 / 1 / 2, never faster than what was proven exact */
@@ -1037,6 +1005,15 @@ int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode) {
     return ST_OK;
 }
 
+int hydamd_set_curve_gathers(HydAmdContext *ctx, int mode) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (mode < 0 || mode > 2)
+        return fail(ctx, ST_API_ERROR, "curve gathers: 0 by content, 1 always, 2 never");
+    ctx->curve_gathers = mode;
+    return ST_OK;
+}
+
 int hydamd_set_rans_waves(HydAmdContext *ctx, int waves) {
     if (!ctx)
         return ST_API_ERROR;
@@ -1045,7 +1022,7 @@ int hydamd_set_rans_waves(HydAmdContext *ctx, int waves) {
         return ST_OK;
     }
     if (waves < 4 || waves > 6)
-        return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group), 5 (lane per group) or 6 (lane per group, packed tables)");
+        return fail(ctx, ST_API_ERROR, "entropy-stage form must be 4 (wave per group) or 5 (lane per group; 6 is accepted as a synonym)");
     ctx->rans_lanes = waves - 4;
     return ST_OK;
 }
@@ -1249,7 +1226,20 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
     ctx->accum_stale = false;
     HIP_TRY(ctx, hipEventRecord(ctx->jobs_uploaded[ctx->jobs_idx], ctx->stream));
     ScopedTimer timer(ctx, HYDAMD_K_TRANSFORM);
-    HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs + first, count, mask, ctx->use_luts, ctx->status, ctx->stream));
+    /* One of a pixel's six curves comes from the uploaded table through the texture path (HYDK_K1_GATHER: photo -9 %,
+     * smooth -8 %) — unless the picture's pixels scatter over the whole table, where every lane's gather is its own L2
+     * miss (random noise +12 %).  No one tells the encoder what it is about to see; what it has is the frame this context
+     * published last (HF section bytes in pinned memory, possibly a frame behind, no wait): above 0.75 bytes per pixel —
+     * photographic content has 0.15, noise 2 — the next transform kernels evaluate all six curves in registers (modes 3, 4). */
+    int xmode = ctx->use_luts;
+    if (xmode < 2) {
+        bool dense = ctx->curve_gathers == 2;
+        if (ctx->curve_gathers == 0 && ctx->published_pixels)
+            dense = (double)*ctx->h_total_pinned > 0.75 * (double)ctx->published_pixels;
+        if (dense)
+            xmode += 3;
+    }
+    HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs + first, count, mask, xmode, ctx->status, ctx->stream));
     return ST_OK;
 }
 
@@ -1493,7 +1483,10 @@ int hydamd_wait_for(HydAmdContext *ctx, HydAmdContext *peer) {
         return ST_OK;
     HIP_TRY(peer, hipSetDevice(peer->device));
     if (!peer->peer_event)
-        HIP_TRY(peer, hipEventCreateWithFlags(&peer->peer_event, hipEventDisableTiming));
+        /* what the waiting device reads is this device's memory, over xGMI: the record must release to SYSTEM scope (the
+         * runtime's default for an event is device scope; this device's L2 slices are written back either way, its
+         * memory-side cache is coherent for the fabric — the flag makes the intent explicit and costs nothing measurable) */
+        HIP_TRY(peer, hipEventCreateWithFlags(&peer->peer_event, hipEventDisableTiming | hipEventReleaseToSystem));
     HIP_TRY(peer, hipEventRecord(peer->peer_event, peer->stream));
     const int st = enable_peer_reads(ctx, peer->device);
     if (st != ST_OK)
@@ -1553,6 +1546,102 @@ int hydamd_alphabet_floor_from_peers(HydAmdContext *ctx, int npeers, HydAmdConte
     hipLaunchKernelGGL(k_floor_from_peers, dim3(1), dim3(64), 0, ctx->stream, a, ctx->peer_floor);
     HIP_TRY(ctx, hipGetLastError());
     ctx->alpha_floor_dev = ctx->peer_floor;
+    return ST_OK;
+}
+
+/* Can every device of the list read every other one's memory?  hyd_send_tile asks BEFORE it deals a frame out to several
+ * devices (a frame that cannot be assembled from peer reads stays on one device).  HYDAMD_TEST_NO_P2P=1 answers "no" for
+ * any list of two or more entries — how the tests reach the fallback on a box with one GPU. */
+int hydamd_peers_reachable(const int *devices, int n) {
+    if (!devices || n < 1)
+        return 0;
+    if (n == 1)
+        return 1;
+    if (const char *e = getenv("HYDAMD_TEST_NO_P2P"))
+        if (*e && *e != '0')
+            return 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    for (int i = 0; i < n; i++) {
+        if (devices[i] < 0 || devices[i] >= count)
+            return 0;
+        for (int j = 0; j < n; j++) {
+            if (devices[i] == devices[j])
+                continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) {
+                (void)hipGetLastError();
+                return 0;
+            }
+        }
+    }
+    return 1;
+}
+
+/* HYDAMD_VERIFY_PEERS: a checksum of everything an exported view of `owner`'s frame names — the view's header and slot
+ * records, the packed LF streams, the HF sections — computed by a kernel in `reader`'s stream (reader == owner: on the
+ * owning device; else: through peer reads, behind hydamd_wait_for(reader, owner)).  Both sides run the same kernel on the
+ * same addresses, so the two sums differ exactly when the reading device saw other bytes than the owner wrote (a stale
+ * line of remote memory in its L2, a release that did not reach the fabric). */
+namespace {
+__device__ __forceinline__ unsigned long long mix_words(const uint8_t *p, unsigned long long bytes, unsigned long long salt) {
+    const unsigned long long words = bytes >> 3;
+    const unsigned long long *w = (const unsigned long long *)p;
+    unsigned long long s = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (unsigned long long)gridDim.x * blockDim.x)
+        s += (w[i] ^ salt) * (2ull * i + 1ull);
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 7ull))
+        s += ((unsigned long long)p[(words << 3) + threadIdx.x] + 1ull) * (salt | 1ull) * (threadIdx.x + 3ull);
+    return s;
+}
+__global__ __launch_bounds__(256) void k_view_checksum(const uint8_t *view, unsigned long long view_bytes, const uint8_t *lf,
+                                                       const unsigned long long *lf_total, const uint8_t *hf,
+                                                       const uint64_t *hf_total, unsigned long long *out) {
+    unsigned long long s = mix_words(view, view_bytes, 0x9E3779B97F4A7C15ull);
+    s += mix_words(lf, *lf_total, 0xC2B2AE3D27D4EB4Full);
+    s += mix_words(hf, (unsigned long long)*hf_total, 0x165667B19E3779F9ull);
+#pragma unroll
+    for (int d = 32; d; d >>= 1)
+        s += (unsigned long long)__shfl_xor((long long)s, d);
+    if ((threadIdx.x & 63) == 0)
+        atomicAdd(out, s);
+}
+} /* namespace */
+
+int hydamd_verify_enqueue(HydAmdContext *reader, HydAmdContext *owner, int num_slots, int index) {
+    if (!reader || !owner || index < 0 || index >= HYDAMD_MAX_PEERS)
+        return ST_API_ERROR;
+    if (!owner->own_blob || num_slots < 1 || num_slots > owner->max_slots)
+        return fail(reader, ST_API_ERROR, "verification needs the owner's frame exported as a view first");
+    if (reader != owner) {
+        const int st = enable_peer_reads(reader, owner->device);
+        if (st != ST_OK)
+            return st;
+    }
+    HIP_TRY(reader, hipSetDevice(reader->device));
+    if (!reader->verify_sums)
+        HIP_TRY(reader, hipMalloc(&reader->verify_sums, HYDAMD_MAX_PEERS * sizeof(unsigned long long)));
+    HIP_TRY(reader, hipMemsetAsync(reader->verify_sums + index, 0, sizeof(unsigned long long), reader->stream));
+    const size_t view_bytes = sizeof(HydAmdBlobHeader) + (size_t)num_slots * sizeof(HydAmdBlobSlot);
+    hipLaunchKernelGGL(k_view_checksum, dim3(64), dim3(256), 0, reader->stream, (const uint8_t *)owner->own_blob,
+                       (unsigned long long)view_bytes, (const uint8_t *)owner->lf_packed, owner->lf_total,
+                       (const uint8_t *)owner->payload, owner->total, reader->verify_sums + index);
+    HIP_TRY(reader, hipGetLastError());
+    return ST_OK;
+}
+
+int hydamd_verify_read(HydAmdContext *reader, int index, unsigned long long *sum) {
+    if (!reader || !sum || index < 0 || index >= HYDAMD_MAX_PEERS || !reader->verify_sums)
+        return ST_API_ERROR;
+    HIP_TRY(reader, hipSetDevice(reader->device));
+    HIP_TRY(reader, hipStreamSynchronize(reader->stream));
+    HIP_TRY(reader, hipMemcpy(sum, reader->verify_sums + index, sizeof(*sum), hipMemcpyDeviceToHost));
+    if (const char *e = getenv("HYDAMD_TEST_CORRUPT_PEER_VIEW")) /* test hook: the sum of view `index` as a faulty link would leave it */
+        if (*e && atoi(e) == index)
+            *sum ^= 1ull;
     return ST_OK;
 }
 
@@ -1687,23 +1776,13 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
             hipLaunchKernelGGL(k_sleep_probe, dim3(wgs > 0 ? wgs * count : 1), dim3(64), (size_t)lds, ctx->stream, ticks);
         } else if (debug_skip() & 2) {
         } else if (lanes) {
-            hipStream_t chains = ctx->stream;
-            if (ctx->chain_stream) { /* the chains' own compute units: behind the table kernel, in front of the section scan */
-                HIP_TRY(ctx, hipEventRecord(ctx->chain_go, ctx->stream));
-                HIP_TRY(ctx, hipStreamWaitEvent(ctx->chain_stream, ctx->chain_go, 0));
-                chains = ctx->chain_stream;
-            }
             HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, ctx->sym_count + g0, ctx->tables + first,
                                                  ctx->rans_aux + g0 * ctx->tok_cap, ctx->rans_flags + g0 * (ctx->tok_cap / 16),
                                                  ctx->tok_cap, ctx->rans_final + g0, ctx->group_bits + g0, ctx->preset_bits,
                                                  ctx->nclusters, count, ctx->status,
                                                  with_lf_codes ? ctx->lf_hist + (size_t)first * HYDK_LF_CODES : nullptr,
                                                  ctx->lf_streams + first, ctx->lf_work + (size_t)first * hydk::lf_work_bytes(),
-                                                 chains));
-            if (ctx->chain_stream) {
-                HIP_TRY(ctx, hipEventRecord(ctx->chain_done, ctx->chain_stream));
-                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->chain_done, 0));
-            }
+                                                 ctx->stream));
         } else if (!any_float && wave_form_defers()) {
             /* wave per group, bits written by k_rans_emit as for the lane form (round 4: the walk no longer stops after
              * every 64 symbols to scan, pack and store their bits itself) */
@@ -1798,6 +1877,12 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
             return st;
     }
     /* one single-wave kernel writes the frame's totals and status straight into pinned host memory */
+    {
+        uint64_t px = 0;
+        for (int i = 0; i < num_slots; i++)
+            px += (uint64_t)ctx->h_jobs[i].width * (uint64_t)ctx->h_jobs[i].height;
+        ctx->published_pixels = px;
+    }
     HIP_TRY(ctx, hydk::launch_publish(ctx->total, ctx->h_total_pinned, ctx->lf_total_unpublished ? ctx->lf_total : nullptr,
                                       ctx->h_lf_total_pinned, ctx->status, ctx->h_status_pinned, ctx->stream));
     if (ctx->lf_total_unpublished) /* hydamd_sync_lf waits for this event and then reads the LF total */
@@ -2075,12 +2160,20 @@ int hydamd_debug_shader_clock_mhz(HydAmdContext *ctx, double *mhz) {
     if (!ctx || !mhz)
         return ST_API_ERROR;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    static hipStream_t side = nullptr;
-    static unsigned long long *h = nullptr;
-    if (!side) {
+    /* on the context's own device and stream-independent: a side stream and a pinned pair per device, made under a lock
+     * (one process may drive several devices from several threads) */
+    static std::mutex lock;
+    static hipStream_t sides[HYDAMD_MAX_PEERS * 2];
+    static unsigned long long *pinned[HYDAMD_MAX_PEERS * 2];
+    if (ctx->device < 0 || ctx->device >= HYDAMD_MAX_PEERS * 2)
+        return fail(ctx, ST_API_ERROR, "device index out of range");
+    std::lock_guard<std::mutex> hold(lock);
+    hipStream_t &side = sides[ctx->device];
+    unsigned long long *&h = pinned[ctx->device];
+    if (!side)
         HIP_TRY(ctx, hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    if (!h)
         HIP_TRY(ctx, hipHostMalloc((void **)&h, 2 * sizeof(unsigned long long), hipHostMallocDefault));
-    }
     hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, side, h);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(side));

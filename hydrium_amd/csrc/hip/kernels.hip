@@ -170,6 +170,12 @@ __device__ __forceinline__ uint32_t to_u16(float x) { /* format.c:33-36 */
  *   1  registers, IEEE division as the compiler expands it
  *   2  gathers from the uploaded LUTs */
 constexpr int kXybFastRcp = 0, kXybIeeeDiv = 1, kXybGather = 2;
+/* 3, 4: modes 0 and 1 with EVERY curve evaluated in registers — no HYDK_K1_GATHER gathers.  Chosen per frame by the host
+ * (device_api.hip transform_range) for content whose pixels scatter over the whole bias table, where a gather is an L2
+ * miss per lane (random noise: 1.04 ms against 1.17 with the M-channel gather) */
+constexpr int kXybFastRcpRegs = 3, kXybIeeeDivRegs = 4;
+constexpr int xyb_arith(int xm) { return xm == kXybFastRcpRegs ? kXybFastRcp : xm == kXybIeeeDivRegs ? kXybIeeeDiv : xm; }
+constexpr int xyb_gmask(int xm) { return xm == kXybFastRcpRegs || xm == kXybIeeeDivRegs ? 0 : HYDK_K1_GATHER; }
 
 /* the 65536-entry LUTs of format.c:58-83, evaluated in registers.  The clamp of f32_to_u16 (format.c:33-36)
  * never acts on these inputs — the curve maps [0, 1] into [0, 1) — so it is left out; like every other
@@ -195,7 +201,7 @@ __device__ __forceinline__ uint32_t input_lut16_eval_as(uint32_t i) {
 __device__ __forceinline__ uint32_t div3(uint32_t u) { return __umulhi(u, 0x55555556u); }
 template <int XMODE>
 __device__ __forceinline__ float bias_lut_eval(uint32_t i) {
-    if (XMODE == kXybIeeeDiv)
+    if (xyb_arith(XMODE) == kXybIeeeDiv)
         return bias_curve((float)i * kUnit16);
     /* same operations as bias_curve (format.c:21-31) with 1.0f / z computed as v_rcp_f32 plus one
      * fused Newton step: explicit fmaf() is a fused operation regardless of the contraction setting,
@@ -267,7 +273,7 @@ __device__ __forceinline__ void input_lut16_eval_n(const uint32_t (&i)[N], uint3
 
 template <int XMODE, int N>
 __device__ __forceinline__ void bias_lut_eval_n(const uint32_t (&i)[N], float (&o)[N]) {
-    if (XMODE == kXybIeeeDiv) {
+    if (xyb_arith(XMODE) == kXybIeeeDiv) {
 #pragma unroll
         for (int k = 0; k < N; k++)
             o[k] = bias_curve((float)i[k] * kUnit16);
@@ -352,9 +358,9 @@ __device__ __forceinline__ void lms_mix_u16(uint32_t r, uint32_t g, uint32_t b, 
         s = bias_lut[is];
     } else {
         const auto *gl = HYDK_GLOBAL(const float, bias_lut);
-        l = (HYDK_K1_GATHER & 8) ? gl[il] : bias_lut_eval<XMODE>(il);
-        m = (HYDK_K1_GATHER & 16) ? gl[im] : bias_lut_eval<XMODE>(im);
-        s = (HYDK_K1_GATHER & 32) ? gl[is] : bias_lut_eval<XMODE>(is);
+        l = (xyb_gmask(XMODE) & 8) ? gl[il] : bias_lut_eval<XMODE>(il);
+        m = (xyb_gmask(XMODE) & 16) ? gl[im] : bias_lut_eval<XMODE>(im);
+        s = (xyb_gmask(XMODE) & 32) ? gl[is] : bias_lut_eval<XMODE>(is);
     }
     Y = (l + m) * 0.5f;
     X = Y - m;
@@ -546,7 +552,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
     constexpr bool LUTS = XMODE == kXybGather;
     constexpr int kWords = FMT == HYDK_FMT_U8 ? 6 : 12; /* dwords holding 8 packed RGB pixels */
     const HydkLfJob job = jobs[blockIdx.x >> 6];
-    if (job.fmt != FMT || (FMT != HYDK_FMT_F32 && job.use_luts != XMODE))
+    if (job.fmt != FMT || (FMT != HYDK_FMT_F32 && job.use_luts != xyb_arith(XMODE)))
         return; /* another template instance of this launch round owns this LF group */
     if ((int)(blockIdx.x & 63) >= job.gcols * job.grows)
         return;
@@ -716,7 +722,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                             }
                             /* which of the 3 * P bias values come from the uploaded table through the (otherwise idle)
                              * texture path: HYDK_K1_GATHER bits 3-5 */
-                            constexpr auto gathered = [](int k) constexpr { return ((HYDK_K1_GATHER >> 3) >> (k % 3) & 1) != 0; };
+                            constexpr auto gathered = [](int k) constexpr { return ((xyb_gmask(XMODE) >> 3) >> (k % 3) & 1) != 0; };
                             constexpr int NG = [&]() constexpr { int n = 0; for (int k = 0; k < 3 * P; k++) n += gathered(k); return n; }();
                             if (NG == 0)
                                 bias_lut_eval_n<XMODE, 3 * P>(idx, bia);
@@ -762,7 +768,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                                 rgb[ch] = s_lut8[(w[si >> 2] >> (8 * (si & 3))) & 0xFF];
                             else {
                                 const uint32_t v = (w[si >> 1] >> (16 * (si & 1))) & 0xFFFF;
-                                rgb[ch] = LUTS ? (uint32_t)job.in_lut16[v] : (HYDK_K1_GATHER >> ch & 1) ? (uint32_t)HYDK_GLOBAL(const uint16_t, job.in_lut16)[v] : input_lut16_eval_as<CURVE>(v);
+                                rgb[ch] = LUTS ? (uint32_t)job.in_lut16[v] : (xyb_gmask(XMODE) >> ch & 1) ? (uint32_t)HYDK_GLOBAL(const uint16_t, job.in_lut16)[v] : input_lut16_eval_as<CURVE>(v);
                             }
                         }
                         if (HYDK_K1_SKIP & 2) { /* timing only: no transfer or bias curves */
@@ -2294,24 +2300,26 @@ hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt
                             hipStream_t stream) {
     const dim3 grid(num_slots * HYDK_GROUPS_PER_LFG), block(kThreads);
 #define HYDK_LAUNCH_K1(FMT, XM) hipLaunchKernelGGL((k_transform_tokenize<FMT, XM>), grid, block, 0, stream, d_jobs, status)
-    if (fmt_mask & (1u << HYDK_FMT_U8)) {
-        if (xmode == kXybFastRcp)
-            HYDK_LAUNCH_K1(HYDK_FMT_U8, kXybFastRcp);
-        else if (xmode == kXybIeeeDiv)
-            HYDK_LAUNCH_K1(HYDK_FMT_U8, kXybIeeeDiv);
-        else
-            HYDK_LAUNCH_K1(HYDK_FMT_U8, kXybGather);
-    }
-    if (fmt_mask & (1u << HYDK_FMT_U16)) {
-        if (xmode == kXybFastRcp)
-            HYDK_LAUNCH_K1(HYDK_FMT_U16, kXybFastRcp);
-        else if (xmode == kXybIeeeDiv)
-            HYDK_LAUNCH_K1(HYDK_FMT_U16, kXybIeeeDiv);
-        else
-            HYDK_LAUNCH_K1(HYDK_FMT_U16, kXybGather);
-    }
+#define HYDK_LAUNCH_K1_MODES(FMT)              \
+    do {                                       \
+        if (xmode == kXybFastRcp)              \
+            HYDK_LAUNCH_K1(FMT, kXybFastRcp);  \
+        else if (xmode == kXybIeeeDiv)         \
+            HYDK_LAUNCH_K1(FMT, kXybIeeeDiv);  \
+        else if (xmode == kXybFastRcpRegs)     \
+            HYDK_LAUNCH_K1(FMT, kXybFastRcpRegs); \
+        else if (xmode == kXybIeeeDivRegs)     \
+            HYDK_LAUNCH_K1(FMT, kXybIeeeDivRegs); \
+        else                                   \
+            HYDK_LAUNCH_K1(FMT, kXybGather);   \
+    } while (0)
+    if (fmt_mask & (1u << HYDK_FMT_U8))
+        HYDK_LAUNCH_K1_MODES(HYDK_FMT_U8);
+    if (fmt_mask & (1u << HYDK_FMT_U16))
+        HYDK_LAUNCH_K1_MODES(HYDK_FMT_U16);
     if (fmt_mask & (1u << HYDK_FMT_F32))
         HYDK_LAUNCH_K1(HYDK_FMT_F32, kXybIeeeDiv);
+#undef HYDK_LAUNCH_K1_MODES
 #undef HYDK_LAUNCH_K1
     return hipGetLastError();
 }

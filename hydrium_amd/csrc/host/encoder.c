@@ -121,6 +121,7 @@ struct HYDEncoder {
     int pipe_request; /* hydamd_set_tile_pipeline: frames in flight this encoder asks for; 0 = HYDAMD_TILE_PIPELINE, else 1 */
     struct PendingTile *cur_pend; /* the ring entry the running call works for (device errors are recorded there) */
     size_t tile_seq;
+    char verify_msg[128]; /* HYDAMD_VERIFY_PEERS: the error text that names the device pair */
 };
 
 #define FAIL(enc, code, msg) ((enc)->error = (msg), (code))
@@ -1082,6 +1083,17 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
 
 /* ---- one frame on several devices (SURVEY 8(e) behind the C boundary) ----
  * hands the shards' contexts back; e->dev was only an alias of one of them */
+/* HYDAMD_VERIFY_PEERS=1: every sharded frame's peer reads are checked (hydamd_verify_enqueue): the owning device and the
+ * assembling device sum every shard's view; a difference fails the frame with the device pair named */
+static int verify_peers_on(void) {
+    static int on = -1;
+    if (on < 0) {
+        const char *v = getenv("HYDAMD_VERIFY_PEERS");
+        on = v && *v && *v != '0';
+    }
+    return on;
+}
+
 static void multi_release(HYDEncoder *e) {
     if (e->shards > 1) {
         for (int d = 0; d < e->shards; d++) {
@@ -1153,6 +1165,16 @@ static int finish_frame_multi(HYDEncoder *e, const HydFrameShape *shape) {
         for (int d = 1; d < N; d++) /* the assembling GPU's stream waits for the other shards' exports and may read their memory */
             if ((ret = hydamd_wait_for(ctxs[0], ctxs[d])) != 0)
                 return device_fail(e, ret);
+        if (verify_peers_on()) /* every shard's view summed where it was written and where it is about to be read */
+            for (int d = 1; d < N; d++) {
+                e->dev = ctxs[d];
+                if ((ret = hydamd_verify_enqueue(ctxs[d], ctxs[d], (int)e->multi[d].slots, 0)) != 0)
+                    return device_fail(e, ret);
+                e->dev = ctxs[0];
+                if ((ret = hydamd_verify_enqueue(ctxs[0], ctxs[d], (int)e->multi[d].slots, d)) != 0)
+                    return device_fail(e, ret);
+            }
+        e->dev = ctxs[0];
         ret = hydamd_assembler_run(as, blob, cap, hydamd_get_stream(ctxs[0]), NULL, out_cap);
         if (ret)
             return device_fail(e, ret);
@@ -1177,6 +1199,22 @@ static int finish_frame_multi(HYDEncoder *e, const HydFrameShape *shape) {
             mark_device_failed(e);
             return FAIL(e, ret < HYD_ERROR_START ? ret : HYD_INTERNAL_ERROR, "GPU frame assembly failed");
         }
+        if (verify_peers_on())
+            for (int d = 1; d < N; d++) {
+                unsigned long long written = 0, seen = 0;
+                e->dev = ctxs[d];
+                if ((ret = hydamd_verify_read(ctxs[d], 0, &written)) != 0)
+                    return device_fail(e, ret);
+                e->dev = ctxs[0];
+                if ((ret = hydamd_verify_read(ctxs[0], d, &seen)) != 0)
+                    return device_fail(e, ret);
+                if (written != seen) {
+                    mark_device_failed(e);
+                    snprintf(e->verify_msg, sizeof(e->verify_msg), "peer read mismatch: device %d did not see what device %d wrote (shard %d)",
+                             hydamd_context_device(ctxs[0]), hydamd_context_device(ctxs[d]), d);
+                    return FAIL(e, HYD_INTERNAL_ERROR, e->verify_msg);
+                }
+            }
         uint8_t *dst = hb_extend(&e->stream, size);
         if (!dst)
             return FAIL(e, HYD_NOMEM, "out of memory");
@@ -1230,10 +1268,18 @@ HYDRIUM_EXPORT int hydamd_set_tile_pipeline(HYDEncoder *e, int depth) {
     for (int i = 0; i < TILE_PIPE_MAX; i++)
         if (e->pipe[i].active)
             return FAIL(e, HYD_API_ERROR, "tile frames are in flight");
+    if (e->have_metadata && e->one_frame) {
+        /* the ring belongs to tile mode: a one-frame image has no use for it, and its context(s) — one per shard, tiles
+         * already uploaded — are not the ring's to hand back */
+        e->pipe_request = depth;
+        return HYD_OK;
+    }
     if (depth != e->pipe_request) {
         /* the ring is indexed by the depth: hand its contexts back, the next tile builds the new one */
         pipe_release(e);
-        if (e->dev) { /* the encoder's own context (depth 1): the ring's entries bring theirs */
+        if (e->shards > 1) { /* (an encoder whose metadata changed from a sharded one-frame image) */
+            multi_release(e);
+        } else if (e->dev) { /* the encoder's own context (depth 1): the ring's entries bring theirs */
             ctx_release(e->dev, e->dev_slots, e->dev_linear, !e->dev_failed);
             e->dev = NULL;
         }
@@ -1280,6 +1326,16 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
         const size_t n = e->lfg_per_frame;
         const int by_device = g_device_count, by_size = (int)(n / 2 < HYD_MAX_DEVICES ? n / 2 : HYD_MAX_DEVICES);
         e->shards = e->one_frame && by_device > 1 && n >= (size_t)g_shard_min && !host_assembly_forced() ? (by_device < by_size ? by_device : by_size) : 1;
+        if (e->shards > 1 && !hydamd_peers_reachable(g_devices, e->shards)) {
+            /* a frame's shards meet through peer reads (finish_frame_multi): asked HERE, before the first tile is uploaded,
+             * not when the last one arrives.  Without peer access between all of the devices the frame stays on this
+             * encoder's home device (same bytes, one GPU's rate) */
+            static int said;
+            if (!said++ || trace_on())
+                fprintf(stderr, "[hydrium] no peer access between the %d devices of this frame: coded on device %d alone\n",
+                        e->shards, e->home_device);
+            e->shards = 1;
+        }
         memset(e->multi, 0, sizeof(e->multi));
         for (int d = 0; d < e->shards && e->shards > 1; d++) {
             e->multi[d].first_slot = (size_t)d * n / (size_t)e->shards;

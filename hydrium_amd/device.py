@@ -62,6 +62,7 @@ def dll(path: Optional[str] = None):
         d.hydamd_set_xyb_mode.argtypes = [vp, i]
         d.hydamd_begin_frame.argtypes = [vp, u]
         d.hydamd_set_rans_waves.argtypes = [vp, i]
+        d.hydamd_set_curve_gathers.argtypes = [vp, i]
         lf_args = [vp, i, C.POINTER(vp), C.c_ssize_t, C.c_ssize_t, i, sz, sz, u]
         d.hydamd_encode_lf_group.argtypes = lf_args
         d.hydamd_encode_lf_group_host.argtypes = lf_args
@@ -191,6 +192,10 @@ class DeviceContext:
 
     def set_rans_waves(self, waves: int):
         self._ck(self.d.hydamd_set_rans_waves(self.h, waves))
+
+    def set_curve_gathers(self, mode: int):
+        """0: one curve of a pixel's six gathered unless the last frame was dense (noise); 1 always; 2 never"""
+        self._ck(self.d.hydamd_set_curve_gathers(self.h, mode))
 
     def begin_frame(self, num_presets: int):
         self._ck(self.d.hydamd_begin_frame(self.h, num_presets))

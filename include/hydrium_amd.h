@@ -84,6 +84,13 @@ HYDAMD_EXPORT int hydamd_force_luts(HydAmdContext *ctx, int use_luts);
 HYDAMD_EXPORT int hydamd_xyb_mode(HydAmdContext *ctx);
 HYDAMD_EXPORT int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode);
 
+/* One of a pixel's six transfer / bias curves is read from the uploaded table through the texture path instead of being
+ * evaluated in registers (the values are the reference's own table entries either way): faster for photographic and smooth
+ * content, slower for pixels that scatter over the whole table (noise).  0 (default): decided per frame from the density
+ * of the frame this context finished last (more than 0.75 bytes of HF sections per pixel: registers); 1: always gather
+ * (rounds 1-4); 2: never. */
+HYDAMD_EXPORT int hydamd_set_curve_gathers(HydAmdContext *ctx, int mode);
+
 /* Form of the entropy (rANS) stage.  The recurrence is serial per group, so the forms trade the
  * latency of one frame against how much of the GPU the stage occupies while it runs:
  *   4   one wavefront per group, 4 groups per workgroup (default): lowest single-frame latency
@@ -91,11 +98,11 @@ HYDAMD_EXPORT int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode);
  *       parallel kernel writes the bits straight into the payload; a fifteenth of the instructions and
  *       a sixty-fourth of the wavefronts of form 4 — best when many frames are in flight.  LF groups
  *       with float samples are still coded by form 4.
- *   6   form 5 with its coding tables packed (12-bit slots as a byte and a nibble plane): 62 KB of LDS per chain
- *       instead of 80, at three more dependent instructions a symbol (2.26 against 2.07 ms alone).  For devices so
- *       crowded that the chains' LDS is what keeps transform workgroups off a compute unit; on an MI355X with the
- *       streams laid out as INTEGRATION.md section 3 says it equals form 5 in a pipelined loop and loses elsewhere.
- * Integer frames: forms 4-6 all leave the bits to a second, wave-parallel kernel (k_rans_emit); float frames are
+ *   6   (rounds 3-4: form 5 with its coding tables packed into a byte and a nibble plane, 62 KB of LDS per chain
+ *       instead of 80.)  Since round 5 the lane form's tables are sized by the frame's clustering scheme (9 / 3 / 2 / 1
+ *       clusters per preset: 79.5 / 26.5 / 17.7 / 8.8 KB) and its step is hand-scheduled; packed and plain tables measured
+ *       equal in a pipelined loop, so the packed variant is gone and 6 is accepted as another name of 5.
+ * Integer frames: forms 4 and 5 both leave the bits to a second, wave-parallel kernel (k_rans_emit); float frames are
  * coded by form 4's self-emitting variant.
  * Round 1's row forms 1-3 are gone: asking for one of them (here or through HYDAMD_RANS_WAVES) selects
  * form 5, which replaced them, and says so once on stderr. */
@@ -256,6 +263,17 @@ HYDAMD_EXPORT int hydamd_set_alphabet_floor_device(HydAmdContext *ctx, const uin
 #define HYDAMD_MAX_PEERS 8
 HYDAMD_EXPORT int hydamd_context_device(HydAmdContext *ctx);
 HYDAMD_EXPORT int hydamd_wait_for(HydAmdContext *ctx, HydAmdContext *peer);
+/* 1 if every device of the list can read every other one's memory (hipDeviceCanAccessPeer for every ordered pair of distinct
+ * devices; an index that repeats is its own peer), else 0.  hyd_send_tile asks before it deals a frame out to several
+ * devices and keeps the frame on one device when the answer is no. */
+HYDAMD_EXPORT int hydamd_peers_reachable(const int *devices, int n);
+/* Insurance for the peer reads (what HYDAMD_VERIFY_PEERS=1 makes hyd_send_tile do for every sharded frame): a checksum of
+ * everything `owner`'s exported view names (view, packed LF streams, HF sections), computed in `reader`'s stream — on the
+ * owning device when reader == owner, through peer reads otherwise (hydamd_wait_for(reader, owner) first) — into the
+ * reader's result `index` (0 .. HYDAMD_MAX_PEERS - 1); hydamd_verify_read waits for the reader's stream and returns it.
+ * The owner's and a reader's sums of one view are equal exactly when the reader saw the bytes the owner wrote. */
+HYDAMD_EXPORT int hydamd_verify_enqueue(HydAmdContext *reader, HydAmdContext *owner, int num_slots, int index);
+HYDAMD_EXPORT int hydamd_verify_read(HydAmdContext *reader, int index, unsigned long long *sum);
 HYDAMD_EXPORT int hydamd_alphabet_floor_from_peers(HydAmdContext *ctx, int npeers, HydAmdContext *const *peers);
 
 /*

@@ -555,3 +555,47 @@ def test_upload_streams_shared_by_the_contexts_of_a_device(copy_streams):
                PYTHONPATH=os.path.dirname(os.path.dirname(__file__)))
     r = subprocess.run([sys.executable, "-c", _THREADS], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "ok 36" in r.stdout, r.stdout + r.stderr
+
+
+def test_tile_pipeline_request_in_the_middle_of_a_one_frame_image_changes_nothing(lib, image):
+    """hydamd_set_tile_pipeline used to hand the encoder's device context back whenever the depth changed — also
+    in the middle of a one-frame image, whose uploaded tiles it holds.  The ring belongs to tile mode: a one-frame encoder
+    only notes the request."""
+    import ctypes as C
+
+    img = image("photo", 4300, 2100, 8)
+    want, _ = _expected(img)
+    enc = api.Encoder(lib)
+    enc.check(enc.set_metadata(4300, 2100, 0, -1, -1))
+    buf = (C.c_uint8 * (8 << 20))()
+    enc.check(enc.provide_output(buf))
+    out = bytearray()
+    tiles = [(0, 0), (1, 0), (2, 0), (0, 1), (1, 1), (2, 1)]
+    for i, (tx, ty) in enumerate(tiles):
+        enc.check(enc.send_tile(img, tx, ty, 2048, 2048))
+        if i == 2:
+            enc.check(enc.set_tile_pipeline(4))   # three tiles uploaded: their context must survive this
+            enc.check(enc.set_tile_pipeline(1))
+    while True:
+        ret = enc.check(enc.flush())
+        code, n = enc.release_output()
+        enc.check(code)
+        out += C.string_at(buf, n)
+        enc.check(enc.provide_output(buf))
+        if ret != api.HYD_NEED_MORE_OUTPUT:
+            break
+    enc.close()
+    assert bytes(out) == want
+
+
+def test_in_place_output_returns_the_callers_buffer(lib, image):
+    """api.encode_image(in_place=True) on a multi-tile one-frame image: the file, header included, is found in the caller's
+    buffer (a memoryview of it comes back, no copy) — what bench.py's api_end_to_end leg relies on"""
+    import ctypes as C
+
+    img = image("photo", 4300, 2100, 8)
+    want, _ = _expected(img)
+    buf = (C.c_uint8 * (8 << 20))()
+    got = api.encode_image(lib, img, out_buf=buf, in_place=True)
+    assert isinstance(got, memoryview)
+    assert bytes(got) == want

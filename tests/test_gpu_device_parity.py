@@ -297,3 +297,22 @@ def test_batch_of_frames_as_one_launch_group(image):
         ctx.encode_image_tensor(pics[0])  # and the context codes single frames again afterwards
         ctx.sync()
         assert ctx.read_payload() == alone[0]["payload"]
+
+
+@pytest.mark.parametrize("kind,depth", [("noise", 8), ("noise", 16), ("photo", 16)])
+def test_curve_gather_choice_never_changes_a_byte(image, kind, depth):
+    """The transform kernel reads one of a pixel's six curves from the uploaded table or evaluates all six in registers
+    (hydamd_set_curve_gathers; by default chosen from the density of the context's last frame: a noise frame switches the
+    NEXT one to registers).  Every choice leaves the oracle's sections."""
+    from hydrium_amd import device
+    from oracle import binding as orc
+
+    img = image(kind, 520, 300, depth)
+    want, _ = orc.encode_lf_group(img)
+    t = _torch_image(img)
+    with device.DeviceContext(0, 1, 0) as ctx:
+        for mode in (1, 2, 0, 0, 0):          # forced both ways, then by content: first frame, and frames that follow one
+            ctx.set_curve_gathers(mode)
+            ctx.encode_image_tensor(t)
+            ctx.sync()
+            assert ctx.read_payload() == want.stream, (kind, depth, mode)

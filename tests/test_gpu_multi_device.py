@@ -122,3 +122,25 @@ def test_c_client_unchanged_runs_on_the_device_list(tmp_path):
     _build(theirs, os.path.dirname(ref_path), os.path.basename(ref_path))
     want = subprocess.run([theirs, "6200", "4200"], check=True, capture_output=True, text=True, timeout=600).stdout
     assert r.stdout == want
+
+
+def test_without_peer_access_the_frame_stays_on_one_device():
+    """VERDICT r4 task 2 / ADVICE: peer capability is asked when the frame is dealt out (encoder.c, hydamd_peers_reachable),
+    not at the final tile.  HYDAMD_TEST_NO_P2P=1 makes the probe answer "no": the frame is coded on the encoder's home device,
+    says so once on stderr, and is the reference's file"""
+    ours, ref, err = _run(("photo", 4296, 4168, 8), "0,0,0,0", {"HYDAMD_TEST_NO_P2P": "1"})
+    assert "(shard)" not in err, "the frame was dealt out although the devices cannot read each other"
+    assert "no peer access" in err
+    assert ours == ref
+
+
+def test_verify_peers_checks_every_shards_view_and_names_the_pair_that_differs():
+    """HYDAMD_VERIFY_PEERS=1: owner and assembling device sum every shard's view (hydamd_verify_enqueue); equal sums -> the
+    reference's file as ever; a sum that differs (hook: shard 2's as read by the assembling device) fails the frame with the
+    device pair in the message"""
+    ours, ref, err = _run(("photo", 4296, 4168, 8), "0,0,0,0", {"HYDAMD_VERIFY_PEERS": "1"})
+    assert "(shard)" in err
+    assert ours == ref
+    got, _, _ = _run(("photo", 4296, 4168, 8), "0,0,0,0", {"HYDAMD_VERIFY_PEERS": "1", "HYDAMD_TEST_CORRUPT_PEER_VIEW": "2"},
+                     reference=False)
+    assert got.startswith("ERR") and "peer read mismatch" in got and "shard 2" in got

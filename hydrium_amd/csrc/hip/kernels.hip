@@ -47,7 +47,8 @@ constexpr int kThreads = 256;
  *   HYDK_K1_WAVELOCAL  a wavefront row-transforms exactly the eight blocks whose columns it transforms next, so no
  *                      workgroup barrier separates the two phases
  *   HYDK_K1_SKIP       timing-only builds that leave a stage out (wrong bytes): 1 token walk, 2 curves, 4 bitmaps, 8 column pass
- *   HYDK_K1_PADLDS / HYDK_K1_WAVES_EXACT   occupancy experiments: extra LDS per workgroup / exactly n wavefronts per SIMD */
+ * (Round 4's occupancy switches — HYDK_K1_PADLDS, HYDK_K1_WAVES_EXACT, HYDK_K1_NUM_VGPR, HYDK_LANES_PRIO — and the per-phase
+ * cycle counters are gone with the experiments they served: profiles/r04_pipeline_bounds.txt) */
 #ifndef HYDK_K1_GATHER
 #define HYDK_K1_GATHER 0x10
 #endif
@@ -442,39 +443,6 @@ struct SampleOf<HYDK_FMT_F32> {
 
 } /* namespace */
 
-/* Probe builds only (-DHYDK_PHASE_TIMERS, scripts/probe_k1_phases.py): s_memtime ticks each wave of K1
- * spends in each phase, summed over the launch.  Never compiled into the product library. */
-#ifdef HYDK_PHASE_TIMERS
-__device__ unsigned long long g_phase_ticks[8];
-#define HYDK_PHASE_INIT() long long ph_prev = __builtin_readcyclecounter(); unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define HYDK_PHASE_MARK(i)                                      \
-    do {                                                        \
-        __builtin_amdgcn_sched_barrier(0);                      \
-        const long long ph_now = __builtin_readcyclecounter();  \
-        ph_acc[i] += (unsigned long long)(ph_now - ph_prev);    \
-        ph_prev = ph_now;                                       \
-        __builtin_amdgcn_sched_barrier(0);                      \
-    } while (0)
-#define HYDK_PHASE_FLUSH()                                      \
-    do {                                                        \
-        if ((threadIdx.x & 63) == 0)                            \
-            for (int ph_i = 0; ph_i < 8; ph_i++)                \
-                atomicAdd(&g_phase_ticks[ph_i], ph_acc[ph_i]);  \
-    } while (0)
-extern "C" __attribute__((visibility("default"))) int hydamd_debug_phase_ticks(unsigned long long out[8], int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_ticks), sizeof(unsigned long long) * 8);
-    if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z));
-    }
-    return e == hipSuccess ? 0 : -15;
-}
-#else
-#define HYDK_PHASE_INIT()
-#define HYDK_PHASE_MARK(i)
-#define HYDK_PHASE_FLUSH()
-#endif
-
 /* ==========================================================================================
  * K1: fused transform + tokenise.  grid = 64 group slots per LF group x LF groups of the frame,
  * block = 256 threads (4 waves); one 256x256 group per workgroup, walked as 32 strips of 8 rows.
@@ -495,9 +463,6 @@ extern "C" __attribute__((visibility("default"))) int hydamd_debug_phase_ticks(u
  * already late (its stream holds nothing else): those kernels raise their wavefronts' issue priority so
  * that, sharing a SIMD with other frames' transform waves, they run as fast as they do alone. */
 #define HYDK_URGENT() __builtin_amdgcn_s_setprio(3)
-#ifndef HYDK_LANES_PRIO
-#define HYDK_LANES_PRIO 3 /* issue priority of the lane-form chains' wavefronts (A/B: a chain wave takes ~40 % of its SIMD's VALU issue) */
-#endif
 
 /* inclusive prefix sums in registers (DPP), no LDS round trips */
 #define HYDK_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xF, false))
@@ -539,13 +504,7 @@ __device__ __forceinline__ void store_record(void *tok, uint32_t at, uint32_t to
         HYDK_GLOBAL(uint32_t, tok)[at] = HYDK_REC32(symbol, rbits, residue);
 }
 
-#ifdef HYDK_K1_WAVES_EXACT /* register allocation padded so that exactly this many wavefronts fit a SIMD (occupancy experiments) */
-#define HYDK_K1_OCCUPANCY __attribute__((amdgpu_waves_per_eu(HYDK_K1_WAVES_EXACT, HYDK_K1_WAVES_EXACT))) __launch_bounds__(kThreads)
-#elif defined(HYDK_K1_NUM_VGPR) /* a register budget below what four wavefronts per SIMD allow: room beside them for another kernel's wavefront */
-#define HYDK_K1_OCCUPANCY __attribute__((amdgpu_num_vgpr(HYDK_K1_NUM_VGPR))) __launch_bounds__(kThreads, HYDK_K1_WAVES)
-#else
 #define HYDK_K1_OCCUPANCY __launch_bounds__(kThreads, HYDK_K1_WAVES)
-#endif
 template <int FMT, int XMODE>
 __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
     typedef typename SampleOf<FMT>::type sample_t;
@@ -588,11 +547,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
     __shared__ uint32_t s_blen[32];                   /* symbols of the block's Y | X << 8 | B << 16 runs */
     __shared__ __attribute__((aligned(16))) float s_wq[3 * 64]; /* quantisation weight [channel][kh][kv]: a thread's eight in two 16-byte reads */
 
-#ifdef HYDK_K1_PADLDS /* occupancy experiments: extra LDS per workgroup, so that fewer of them fit a compute unit */
-    __shared__ uint32_t s_pad[HYDK_K1_PADLDS / 4];
-    if (threadIdx.x == 0 && jobs == nullptr)
-        s_pad[blockIdx.x & 255] = 1;
-#endif
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
@@ -661,9 +615,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
     if (t == 0)
         s_rbits = 0;
     bool bad_sample = false;
-    HYDK_PHASE_INIT();
     __syncthreads();
-    HYDK_PHASE_MARK(7);
 
     for (int s = 0; s < gbh; s++) {
         /* ---------------- phase A: 8 px of one block row -> XYB -> row DCT ---------------- */
@@ -831,7 +783,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                     d[(size_t)2 * kDbgPitch * kDbgPitch + i] = bv[i];
                 }
             }
-            HYDK_PHASE_MARK(0);
             float o[8];
             float *dst = s_rowpass + ab * kS0Block + ar * 8;
             dct8(xv, o);
@@ -847,7 +798,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
             for (int k = 0; k < 8; k++)
                 dst[2 * kS0Chan + k] = o[k];
         }
-        HYDK_PHASE_MARK(1);
 #if HYDK_K1_WAVELOCAL
         /* LDS operations of one wavefront execute in order: its own stores are visible to its loads */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -856,7 +806,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
 #else
         __syncthreads();
 #endif
-        HYDK_PHASE_MARK(2);
 
         /* ---------------- phase B: column DCT, quantise (in place in LDS), LF ints, non-zero bitmaps ---------------- */
         unsigned long long msk[3] = {0, 0, 0}; /* per channel X, Y, B: non-zero coefficients by zig-zag position */
@@ -936,9 +885,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
             s_seg[cb * 3 + 1] = make_uint4((uint32_t)msk[0], (uint32_t)(msk[0] >> 32), nX | ((uint32_t)__popcll(msk[0]) << 8), base);
             s_seg[cb * 3 + 2] = make_uint4((uint32_t)msk[2], (uint32_t)(msk[2] >> 32), nB | ((uint32_t)__popcll(msk[2]) << 8), base + 2 * kS0Chan);
         }
-        HYDK_PHASE_MARK(3);
         __syncthreads();
-        HYDK_PHASE_MARK(4);
 
         /* ---------------- phase C1: every wave prefix-sums the 32 block totals for itself ---------------- */
         {
@@ -952,7 +899,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
             __builtin_amdgcn_wave_barrier();
         }
         const uint32_t strip_total = s_boff[32];
-        HYDK_PHASE_MARK(5);
 
         /* ---------------- phase C2: the strip's symbol stream, cut into 256 equal runs ----------------
          * Thread t emits one of 256 consecutive runs of the strip's symbols, equal in length up to one: it finds the
@@ -1049,7 +995,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
             }
         }
         goff += strip_total;
-        HYDK_PHASE_MARK(6);
         /* the next strip's row pass overwrites the coefficients this strip's token phase reads */
         __syncthreads();
     }
@@ -1082,8 +1027,6 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
     }
     if (FMT == HYDK_FMT_F32 && bad_sample)
         atomicOr(status, HYDK_STATUS_BAD_SAMPLE);
-    HYDK_PHASE_MARK(7);
-    HYDK_PHASE_FLUSH();
 }
 
 #include "lf_huffman.h" /* the LF coder's code construction rides in the table kernel's (or the chain kernel's) launch, see below */
@@ -1371,6 +1314,7 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) 
 
 /* one step of the recurrence; the symbol's operands {-2f, floor(2^32/f), table address, threshold}
  * were staged in LDS by the lane that owns it and arrive by one broadcast ds_read_b128 */
+typedef __attribute__((address_space(3))) const uint16_t HydkLdsU16;
 #define HYDK_RANS_STEP(o)                                                                     \
     do {                                                                                      \
         /* lane 0 <- state, lane l <- trail[l-1]: the states file past, newest in lane 0 */   \
@@ -1378,10 +1322,10 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) 
         const uint32_t x = rans_renorm(state, o.w);                                           \
         /* q = mulhi(x, floor(2^32/f)) is floor(x/f) or one less, so r = x - q*f < 2f; the   \
          * doubled table returns slot(r mod f) + 4096*(r >= f), which also repairs q.  The    \
-         * byte address adr + 2r is formed as (adr + 2x) + q*(-2f): one op after the mulhi */  \
+         * LDS address adr + 2r is formed as (adr + 2x) + q*(-2f): one op after the mulhi */  \
         const uint32_t q = __umulhi(x, o.y);                                                  \
         const uint32_t at = mad24(q, o.x, o.z + 2u * x);                                      \
-        const uint32_t ent = *(const uint16_t *)(inv_bytes + at);                             \
+        const uint32_t ent = *(HydkLdsU16 *)(uintptr_t)at;                                    \
         state = (q << 12) + ent;                                                              \
     } while (0)
 
@@ -1437,7 +1381,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
     uint32_t *win = s_win[wave];
     uint4 *ops = s_ops[wave];
     const int n = __builtin_amdgcn_readfirstlane((int)sym_count_all[G]); /* wave-uniform: scalar loop control */
-    const unsigned char *inv_bytes = (const unsigned char *)s_inv;
+    const uint32_t inv_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t *)s_inv;
 
     uint32_t cur = bit_pitch_words * 32u; /* stream start so far (absolute bit position) */
     uint32_t carry = 0;                   /* content of the partly filled word at cur>>5 */
@@ -1507,20 +1451,29 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
         uint4 op;
         op.x = (uint32_t)(-2 * (int)f);
         op.y = s_magic[e];
-        op.z = (((lo >> 8) & 0xF) * (2u * HYDK_ANS_SLOTS) + 2u * (fbv >> 16)) * 2u;
+        op.z = inv_lds + (((lo >> 8) & 0xF) * (2u * HYDK_ANS_SLOTS) + 2u * (fbv >> 16)) * 2u; /* the LDS address of the symbol's doubled slot list */
         op.w = thr;
         ops[lane] = op;
         __builtin_amdgcn_wave_barrier();
         uint32_t trail = 0;
         if (cnt == 64) {
             /* eight steps a block; the next block's operands are requested before this block's walk, so that no
-             * walk starts with an LDS round trip and no slot lookup waits behind operand reads */
+             * walk starts with an LDS round trip and no slot lookup waits behind operand reads.
+             * Round 5: what bounds a step is BOTH its dependent depth (~9.5 cycles per dependent instruction plus the lookup's
+             * ~64) and its instruction count (~6.7 cycles each for a wavefront alone on its SIMD) — cutting the depth to two
+             * by forming 64-bit partial products ahead cost 19 instructions and 30 % (profiles/r05_chain_anatomy.txt).  So only
+             * the cheap part moves behind the lookup's request: the refill test of the NEXT symbol (on bits 12.. of the new
+             * state: it needs the repaired quotient, not the slot) and with it the renormalised state without its slot —
+             * x' = ent k + B, k = 0 after a refill — plus the previous state's trip into the trail.  Depth 4 + lookup
+             * (v_mad_u32_u24, v_mul_hi, v_lshl_add, v_mad_i32_i24) where it was 6; 16 instructions where there were 10. */
             uint4 nxt[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 nxt[u] = ops[u];
+            /* the state between two steps, in pieces: araw + ent = the state the next symbol meets; B, k1 = its renormalised form */
+            uint32_t araw = state, ent = 0, k1 = 0, B = rans_renorm(state, nxt[0].w);
             for (int k = 0; k < 64; k += 8) {
-                uint4 blk[8];
+                uint4 blk[9];
 #pragma unroll
                 for (int u = 0; u < 8; u++)
                     blk[u] = nxt[u];
@@ -1529,11 +1482,41 @@ __global__ __launch_bounds__(64 * WAVES) void k_rans_encode(const HydkLfJob *__r
                     for (int u = 0; u < 8; u++)
                         nxt[u] = ops[k + 8 + u];
                 }
+                blk[8] = nxt[0]; /* (the chunk's last step: unused) */
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 8; u++)
-                    HYDK_RANS_STEP(blk[u]);
+                for (int u = 0; u < 8; u++) {
+                    const uint4 o = blk[u];
+                    uint32_t x, q, t, sd, entn, arawn, Bn, k1n;
+                    asm volatile("v_mad_u32_u24 %[x], %[ent], %[k1], %[B]\n\t"
+                                 "v_mul_hi_u32 %[q], %[x], %[mg]\n\t"
+                                 "v_lshl_add_u32 %[x], %[x], 1, %[adr]\n\t"
+                                 "v_mad_i32_i24 %[x], %[q], %[n2f], %[x]\n\t"  /* adr + 2 (x - q f) */
+                                 "ds_read_u16 %[entn], %[x]\n\t"
+                                 "v_add_u32 %[sd], %[araw], %[ent]\n\t"       /* the state this symbol met ... */
+                                 "v_sub_u32 %[t], %[adr], %[n2f]\n\t"         /* adr + 2f */
+                                 "v_mov_b32_dpp %[sd], %[tr] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" /* ... into the trail: lane 0 keeps it, lane l takes trail[l-1] */
+                                 "v_cmp_ge_u32 vcc, %[x], %[t]\n\t"           /* remainder estimate >= f: the quotient is one short */
+                                 "v_addc_co_u32 %[t], vcc, 0, %[q], vcc\n\t"
+                                 "v_lshlrev_b32 %[t], 12, %[t]\n\t"           /* the new state without its slot */
+                                 "v_lshlrev_b32 %[arawn], 12, %[q]\n\t"       /* ... and as the table will complete it (the entry carries the repair) */
+                                 "v_cmp_gt_u32 vcc, %[t], %[thrn]\n\t"        /* the next symbol's refill test (entropy.c:1092) */
+                                 "v_cndmask_b32_sdwa %[Bn], %[arawn], %[t], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                                 "v_cndmask_b32_e64 %[k1n], 1, 0, vcc\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : [x] "=&v"(x), [q] "=&v"(q), [t] "=&v"(t), [sd] "=&v"(sd), [entn] "=&v"(entn), [arawn] "=&v"(arawn),
+                                   [Bn] "=&v"(Bn), [k1n] "=&v"(k1n)
+                                 : [ent] "v"(ent), [k1] "v"(k1), [B] "v"(B), [araw] "v"(araw), [tr] "v"(trail), [mg] "v"(o.y),
+                                   [adr] "v"(o.z), [n2f] "v"(o.x), [thrn] "v"(blk[u + 1].w)
+                                 : "vcc");
+                    trail = sd;
+                    araw = arawn;
+                    ent = entn;
+                    B = Bn;
+                    k1 = k1n;
+                }
             }
+            state = araw + ent;
         } else {
             for (int k = 0; k < cnt; k++) {
                 const uint4 o1 = ops[k];
@@ -1676,7 +1659,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kLdsBytes];
     uint4 *const s_ops = (uint4 *)s_mem;
     unsigned char *const s_tab = s_mem + kOpsBytes; /* uint16_t[NC * 4096] */
-    __builtin_amdgcn_s_setprio(HYDK_LANES_PRIO);
+    HYDK_URGENT();
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= num_slots) {
         /* passengers: workgroup num_slots + s builds the prefix code of LF group s's coefficient stream

@@ -1723,6 +1723,25 @@ __global__ __launch_bounds__(64) void k_sleep_probe(unsigned long long ticks_100
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz)
         __builtin_amdgcn_s_sleep(127);
 }
+/* the same sleeper holding REGS vector registers as well (a chain wavefront holds ~110): which of a chain's holdings — LDS,
+ * registers, or what it does — costs the loop its transform workgroups?  (profiles/r05_pipeline_bounds.txt) */
+#define HYDK_SLEEP_PROBE_REGS(NAME, REGS)                                                                      \
+    __global__ __launch_bounds__(64) void NAME(unsigned long long ticks_100mhz, uint32_t *sink) {               \
+        uint32_t r[REGS];                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < REGS; i++) r[i] = threadIdx.x * (uint32_t)(i + 1);              \
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();                                       \
+        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz) {                                        \
+            _Pragma("unroll") for (int i = 0; i < REGS; i++) asm volatile("" : "+v"(r[i])); /* stays in a vector register */ \
+            __builtin_amdgcn_s_sleep(127);                                                                    \
+        }                                                                                                     \
+        uint32_t s = 0;                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < REGS; i++) s ^= r[i];                                           \
+        if (s == 0xFFFFFFFFu && sink)                                                                         \
+            *sink = s;                                                                                        \
+    }
+HYDK_SLEEP_PROBE_REGS(k_sleep_probe_regs104, 104)
+HYDK_SLEEP_PROBE_REGS(k_sleep_probe_regs40, 40)
+#undef HYDK_SLEEP_PROBE_REGS
 } /* namespace */
 /* HYDAMD_WAVE_FORM_EMITS=1: form 4 as until round 4, the chain kernel writing its own bits into the reversed buffers (A/B) */
 static bool wave_form_defers() {
@@ -1773,6 +1792,16 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
             if (lds > 65536)
                 (void)hipFuncSetAttribute((const void *)k_sleep_probe, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             static const unsigned long long ticks = getenv("HYDAMD_DEBUG_SLEEP_US") ? 100ull * strtoull(getenv("HYDAMD_DEBUG_SLEEP_US"), nullptr, 10) : 250000ull;
+            static const int regs = getenv("HYDAMD_DEBUG_SLEEP_VGPRS") ? atoi(getenv("HYDAMD_DEBUG_SLEEP_VGPRS")) : 0;
+            if (regs >= 100) {
+                if (lds > 65536)
+                    (void)hipFuncSetAttribute((const void *)k_sleep_probe_regs104, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(k_sleep_probe_regs104, dim3(wgs > 0 ? wgs * count : 1), dim3(64), (size_t)lds, ctx->stream, ticks, (uint32_t *)nullptr);
+            } else if (regs >= 40) {
+                if (lds > 65536)
+                    (void)hipFuncSetAttribute((const void *)k_sleep_probe_regs40, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(k_sleep_probe_regs40, dim3(wgs > 0 ? wgs * count : 1), dim3(64), (size_t)lds, ctx->stream, ticks, (uint32_t *)nullptr);
+            } else
             hipLaunchKernelGGL(k_sleep_probe, dim3(wgs > 0 ? wgs * count : 1), dim3(64), (size_t)lds, ctx->stream, ticks);
         } else if (debug_skip() & 2) {
         } else if (lanes) {

@@ -223,6 +223,11 @@ struct HydAmdContext {
     /* the drop-in API's frame assembly on the device (hydamd_export_frame_owned, hydamd_context_assembler) */
     void *own_blob = nullptr;
     size_t own_blob_cap = 0;
+    void *stage_blob = nullptr;      /* hydamd_stage_frame_blob: the frame's self-contained blob in device memory ... */
+    size_t stage_blob_cap = 0;
+    uint8_t *stage_host = nullptr;   /* ... and where hydamd_read_frame_blob lands it (pinned) */
+    size_t stage_host_cap = 0;
+    int stage_slots = 0;
     HydAmdAssembler *assembler = nullptr;
 
     /* profiling */
@@ -661,6 +666,10 @@ void hydamd_destroy(HydAmdContext *ctx) {
         hydamd_assembler_destroy(ctx->assembler);
     if (ctx->own_blob)
         (void)hipFree(ctx->own_blob);
+    if (ctx->stage_blob)
+        (void)hipFree(ctx->stage_blob);
+    if (ctx->stage_host)
+        (void)hipHostFree(ctx->stage_host);
     drain_timers(ctx);
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
@@ -1699,6 +1708,65 @@ int hydamd_export_frame_owned(HydAmdContext *ctx, int num_slots, const void **bl
         return st;
     *blob_dev = ctx->own_blob;
     *capacity = ctx->own_blob_cap;
+    return ST_OK;
+}
+
+/* A small frame's results in ONE copy.  The drop-in API's host-assembled frames (tile mode: one LF group per frame) used to
+ * read tables, section sizes, LF stream records, LF bytes and HF bytes back one hipMemcpy at a time — six round trips of
+ * ~17 us behind a 1.1 ms chain.  hydamd_stage_frame_blob enqueues the export of the frame's self-contained blob into a
+ * buffer of the context's; hydamd_read_frame_blob (after hydamd_sync) copies exactly its bytes into pinned host memory. */
+int hydamd_stage_frame_blob(HydAmdContext *ctx, int num_slots) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (num_slots < 1 || num_slots > ctx->max_slots)
+        return fail(ctx, ST_API_ERROR, "slot count out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t need = hydamd_blob_bound(ctx, num_slots);
+    if (need > ctx->stage_blob_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->stage_blob)
+            (void)hipFree(ctx->stage_blob);
+        ctx->stage_blob = nullptr;
+        ctx->stage_blob_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->stage_blob, need));
+        ctx->stage_blob_cap = need;
+    }
+    ctx->stage_slots = 0;
+    const int st = export_frame(ctx, num_slots, ctx->stage_blob, ctx->stage_blob_cap, 0);
+    if (st == ST_OK)
+        ctx->stage_slots = num_slots;
+    return st;
+}
+
+int hydamd_read_frame_blob(HydAmdContext *ctx, int num_slots, const void **host_blob, size_t *size) {
+    if (!ctx || !host_blob || !size)
+        return ST_API_ERROR;
+    if (!ctx->results_valid || ctx->stage_slots != num_slots || !ctx->lf_on_device)
+        return fail(ctx, ST_API_ERROR, "no staged blob of this frame: hydamd_stage_frame_blob, then hydamd_sync");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t lf_off = sizeof(HydAmdBlobHeader) + (size_t)num_slots * sizeof(HydAmdBlobSlot);
+    const size_t hf_off = (lf_off + (size_t)ctx->h_lf_total + 15u) & ~(size_t)15u;
+    size_t total = hf_off + (size_t)ctx->h_total;
+    if (total > ctx->stage_blob_cap)
+        return fail(ctx, ST_INTERNAL_ERROR, "staged blob larger than its buffer");
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (total > ctx->stage_host_cap) {
+            if (ctx->stage_host)
+                (void)hipHostFree(ctx->stage_host);
+            ctx->stage_host = nullptr;
+            ctx->stage_host_cap = 0;
+            const size_t want = total + (total >> 1) + 65536;
+            HIP_TRY(ctx, hipHostMalloc((void **)&ctx->stage_host, want, hipHostMallocDefault));
+            ctx->stage_host_cap = want;
+        }
+        HIP_TRY(ctx, hipMemcpy(ctx->stage_host, ctx->stage_blob, total, hipMemcpyDeviceToHost));
+        const HydAmdBlobHeader *h = (const HydAmdBlobHeader *)ctx->stage_host;
+        if (h->total_bytes <= total || h->total_bytes > ctx->stage_blob_cap)
+            break;
+        total = (size_t)h->total_bytes; /* (the blob says it is longer than the published totals implied: take it at its word once) */
+    }
+    *host_blob = ctx->stage_host;
+    *size = total;
     return ST_OK;
 }
 

@@ -942,6 +942,18 @@ static int finish_frame_on_device(HYDEncoder *e, const HydFrameShape *shape) {
     return FAIL(e, HYD_INTERNAL_ERROR, "frame still does not fit after enlarging its buffers");
 }
 
+/* frames assembled on the host from ONE read-back (hydamd_stage_frame_blob / hydamd_read_frame_blob) instead of one small
+ * copy per table, size array and byte string: frames of a single LF group with the LF coder on the device — every tile-mode
+ * frame.  HYDAMD_STAGED_READBACK=0 keeps the separate copies (A/B) */
+static int staged_readback(const HYDEncoder *e, size_t n) {
+    static int on = -1;
+    if (on < 0) {
+        const char *v = getenv("HYDAMD_STAGED_READBACK");
+        on = !(v && *v == '0');
+    }
+    return on && n == 1 && hydamd_lf_coder(e->dev);
+}
+
 /* The host-assembly path in two halves, both on e->dev: every kernel of the frame is enqueued (nothing waits) ... */
 static int finish_frame_launch(HYDEncoder *e, const HydFrameShape *shape) {
     const size_t n = shape->lfg_count;
@@ -955,6 +967,8 @@ static int finish_frame_launch(HYDEncoder *e, const HydFrameShape *shape) {
         ret = hydamd_run_lf_coder(e->dev, (int)n, 1);
     if (!ret)
         ret = hydamd_finish_frame(e->dev, (int)n);
+    if (!ret && staged_readback(e, n)) /* everything the host needs of this frame leaves the device as one blob */
+        ret = hydamd_stage_frame_blob(e->dev, (int)n);
     return ret ? device_fail(e, ret) : 0;
 }
 
@@ -964,6 +978,8 @@ static int finish_frame_collect(HYDEncoder *e, const HydFrameShape *shape) {
     const size_t fg = ((shape->frame_width + 255) >> 8) * ((shape->frame_height + 255) >> 8);
     const int lf_on_gpu = hydamd_lf_coder(e->dev);
     const int early_lf = lf_on_gpu && fg > 1;
+    int staged = staged_readback(e, n); /* finish_frame_launch staged the frame's blob: one copy brings everything */
+    const uint8_t *payload = NULL;      /* staged: the HF sections inside the blob's host copy */
     double t0 = now_ms();
     int ret = 0;
     LfgResult *res = calloc(n, sizeof(LfgResult));
@@ -987,7 +1003,7 @@ static int finish_frame_collect(HYDEncoder *e, const HydFrameShape *shape) {
         goto done;
     }
     t0 = now_ms();
-    if (lf_on_gpu) { /* two copies bring every LF group's coded coefficient stream */
+    if (lf_on_gpu && (early_lf || !staged)) { /* two copies bring every LF group's coded coefficient stream */
         lf_len = hydamd_lf_payload_size(e->dev);
         lf_info = malloc(n * sizeof(HydAmdLfInfo));
         lf_blob = malloc(lf_len ? lf_len : 1);
@@ -1034,7 +1050,69 @@ static int finish_frame_collect(HYDEncoder *e, const HydFrameShape *shape) {
         t0 = now_ms();
     }
     payload_len = hydamd_payload_size(e->dev);
-    for (size_t s = 0; s < n && !ret; s++) {
+    if (staged) {
+        const void *blob = NULL;
+        size_t bsize = 0;
+        ret = hydamd_read_frame_blob(e->dev, (int)n, &blob, &bsize);
+        const HydAmdBlobHeader *h = blob;
+        if (!ret && (bsize < sizeof(*h) || h->magic != 0x42445948u || h->version != 1 || h->num_slots != n || h->lf_coded != 1 ||
+                     h->total_bytes > bsize || (h->status & HYDAMD_BLOB_RETRY)))
+            staged = 0; /* e.g. the frame outgrew a buffer and was rerun inside hydamd_sync: the staged blob is the first run's */
+        if (!ret && staged) {
+            const HydAmdBlobSlot *rec = (const HydAmdBlobSlot *)(h + 1);
+            const uint64_t lf_off = sizeof(*h) + (uint64_t)n * sizeof(HydAmdBlobSlot);
+            const int sane = lf_off <= h->total_bytes && h->lf_bytes <= h->total_bytes - lf_off && h->hf_bytes <= h->total_bytes &&
+                             ((lf_off + h->lf_bytes + 15u) & ~(uint64_t)15u) + h->hf_bytes == h->total_bytes;
+            if (!sane)
+                ret = HYD_INTERNAL_ERROR;
+            const uint8_t *lf_bytes = (const uint8_t *)blob + lf_off;
+            for (size_t s = 0; s < n && !ret; s++) {
+                if (rec[s].table_error || rec[s].lf.error ||
+                    (uint64_t)rec[s].lf.offset + (((uint64_t)rec[s].lf.bit_count + 7) >> 3) > h->lf_bytes) {
+                    ret = HYD_INTERNAL_ERROR;
+                    break;
+                }
+                memcpy(res[s].freq, rec[s].freq, sizeof(res[s].freq));
+                memcpy(res[s].alphabet, rec[s].alphabet, sizeof(res[s].alphabet));
+                memcpy(res[s].bits, rec[s].group_bits, sizeof(res[s].bits));
+                if (rec[s].running_max_alphabet > max_alphabet)
+                    max_alphabet = rec[s].running_max_alphabet;
+                if (!early_lf) {
+                    memcpy(res[s].lf_lengths, rec[s].lf.lengths, HYD_LF_CODES);
+                    res[s].lf_alphabet = rec[s].lf.alphabet;
+                    res[s].lf_run_pairs = rec[s].lf.run_pairs;
+                    res[s].lf_bit_count = rec[s].lf.bit_count;
+                    res[s].lf_bits = (uint8_t *)(uintptr_t)(lf_bytes + rec[s].lf.offset); /* borrowed from the context's pinned copy */
+                }
+            }
+            payload = (const uint8_t *)blob + h->total_bytes - h->hf_bytes;
+            payload_len = (size_t)h->hf_bytes;
+        }
+    }
+    if (!ret && !staged && lf_on_gpu && !early_lf && !lf_info) { /* (the staged blob was stale: the LF streams the old way) */
+        lf_len = hydamd_lf_payload_size(e->dev);
+        lf_info = malloc(n * sizeof(HydAmdLfInfo));
+        lf_blob = malloc(lf_len ? lf_len : 1);
+        if (!lf_info || !lf_blob) {
+            ret = FAIL(e, HYD_NOMEM, "out of memory");
+            goto done;
+        }
+        ret = hydamd_read_lf_streams(e->dev, 0, (int)n, lf_info);
+        if (!ret)
+            ret = hydamd_read_lf_payload(e->dev, lf_blob, lf_len);
+        for (size_t s = 0; s < n && !ret; s++) {
+            if ((size_t)lf_info[s].offset + (((size_t)lf_info[s].bit_count + 7) >> 3) > lf_len) {
+                ret = HYD_INTERNAL_ERROR;
+                break;
+            }
+            memcpy(res[s].lf_lengths, lf_info[s].lengths, HYD_LF_CODES);
+            res[s].lf_alphabet = lf_info[s].alphabet;
+            res[s].lf_run_pairs = lf_info[s].run_pairs;
+            res[s].lf_bit_count = lf_info[s].bit_count;
+            res[s].lf_bits = lf_blob + lf_info[s].offset;
+        }
+    }
+    for (size_t s = 0; s < n && !ret && !staged; s++) {
         const size_t vbw = (shape->lfg[s].width + 7) >> 3, vbh = (shape->lfg[s].height + 7) >> 3;
         uint32_t log_alpha = 0, running = 0;
         if (!lf_on_gpu) {
@@ -1058,7 +1136,7 @@ static int finish_frame_collect(HYDEncoder *e, const HydFrameShape *shape) {
     }
     TRACE("read back results", t0);
     t0 = now_ms();
-    ret = assemble_frame(e, shape, res, max_alphabet, NULL, payload_len, lf_sections, NULL);
+    ret = assemble_frame(e, shape, res, max_alphabet, staged ? payload : NULL, payload_len, lf_sections, NULL);
     TRACE("assemble frame (host)", t0);
 done:
     for (size_t s = 0; s < n; s++) {

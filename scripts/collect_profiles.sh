@@ -53,7 +53,7 @@ grep "^{" /tmp/kt_shard.log | tail -1 > "$out/${tag}_shard_under_rocprof.json"; 
 trace api --memory-copy-trace -- python "$root/scripts/api_frame_times.py"
 db=$(find /tmp/kt_api -name "*.db" 2>/dev/null | head -1)
 if [ -n "$db" ]; then run api_timeline txt python scripts/rocpd_timeline.py "$db" 75; else fail api_timeline /tmp/kt_api.log; fi  # the last frame: uploads, kernels, read-back
-run tile_mode txt python scripts/api_tile_mode.py 4096 8
+run tile_mode txt bash -c 'echo "## default: every hyd_send_tile call ends with its tile frame (the reference s timing)"; python scripts/api_tile_mode.py 4096 8 | grep shift; echo "## eight tile frames in flight (HYDAMD_TILE_PIPELINE=8), GPU_MAX_HW_QUEUES=22"; GPU_MAX_HW_QUEUES=22 HYDAMD_TILE_PIPELINE=8 python scripts/api_tile_mode.py 4096 8 | grep shift'
 run k1_content txt bash -c 'for g in 0 1 2; do echo "== HYDAMD_CURVE_GATHERS=$g (0 by the last frame, 1 always, 2 never)"; HYDAMD_CURVE_GATHERS=$g python scripts/k1_content.py; done'
 # the removal table of the pipelined loop (HYDAMD_DEBUG_SKIP: 1 tables, 2 chains, 4 scan + emit, 8 LF coder; 16: sleeping wavefronts in the chains' place)
 run pipeline_bounds txt bash -c '

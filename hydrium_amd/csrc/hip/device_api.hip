@@ -40,7 +40,7 @@
 
 namespace hydk {
 hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, int xmode, uint32_t *status,
-                            hipStream_t stream);
+                            uint2 *part_info, int plog, hipStream_t stream);
 hipError_t launch_tables(const uint32_t *hist, HydkTables *tabs, const uint32_t *alpha_max, int nclusters, int first_slot,
                          int num_slots, uint32_t alpha_floor, const uint32_t *alpha_floor_dev, const uint32_t *lf_hist,
                          HydkLfStream *lf_streams, void *lf_work, int slots_per_frame, hipStream_t stream);
@@ -100,6 +100,7 @@ static_assert(HYDAMD_MAX_CLUSTERS == HYDK_MAX_CLUSTERS && HYDAMD_ALPHABET == HYD
 namespace {
 
 constexpr int kStaging = 2;
+constexpr int kSplitSlots = 2; /* transform launches of at most this many LF groups split every group over four workgroups */
 constexpr size_t kDbgPlane = (size_t)2048 * 2048;
 
 char g_global_error[256] = "";
@@ -148,6 +149,7 @@ struct HydAmdContext {
     int32_t *dc = nullptr;          /* [slots][3][256][256] */
     uint32_t *hist = nullptr;       /* [slots][9][128] */
     uint32_t *sym_count = nullptr;  /* [slots][64] */
+    uint2 *part_info = nullptr;     /* [kSplitSlots][64][4] {symbols, residue bits} of a group's parts (transform launches of one or two LF groups) */
     uint32_t *group_bits = nullptr; /* [slots][64] */
     uint64_t *offsets = nullptr;    /* [slots][64] */
     uint64_t *total = nullptr;      /* [1] */
@@ -700,7 +702,7 @@ void hydamd_destroy(HydAmdContext *ctx) {
     for (void *p : lfdev)
         if (p)
             (void)hipFree(p);
-    void *dev[] = {ctx->rans_aux, ctx->rans_flags, ctx->rans_final, ctx->rbits_total, ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->accum, ctx->sym_count, ctx->group_bits,
+    void *dev[] = {ctx->rans_aux, ctx->rans_flags, ctx->rans_final, ctx->rbits_total, ctx->tokens, ctx->bitbuf, ctx->tables, ctx->dc, ctx->accum, ctx->sym_count, ctx->part_info, ctx->group_bits,
                    ctx->offsets, ctx->total, ctx->d_jobs, /* the LUTs are the device's, shared by its contexts */
                    ctx->payload, ctx->dbg_xyb, ctx->dbg_dct, ctx->dbg_quant, ctx->d_arena};
     for (void *p : dev)
@@ -882,6 +884,7 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
         ctx->lf_hist = ctx->accum + hist_words + head_words;
     }
     HIP_TRY(ctx, hipMalloc(&ctx->sym_count, slots * G * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->part_info, (size_t)kSplitSlots * G * 4 * sizeof(uint2)));
     HIP_TRY(ctx, hipMalloc(&ctx->group_bits, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->offsets, slots * G * sizeof(uint64_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->total, sizeof(uint64_t)));
@@ -1248,7 +1251,13 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
         if (dense)
             xmode += 3;
     }
-    HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs + first, count, mask, xmode, ctx->status, ctx->stream));
+    /* a launch of one or two LF groups (a tile-mode frame, a tile of the drop-in API's one-frame mode) is 64 or 128
+     * workgroups on 256 compute units, each walking its group's 32 strips one after another: 0.19 ms whatever the tile.
+     * Such launches split every group over four workgroups (eight strips each; k_join_parts closes the token array up):
+     * HYDAMD_K1_SPLIT=0 for A/B */
+    static const bool split_on = !(getenv("HYDAMD_K1_SPLIT") && atoi(getenv("HYDAMD_K1_SPLIT")) == 0);
+    const int plog = split_on && count <= kSplitSlots && ctx->tok_cap % 64 == 0 ? 2 : 0;
+    HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs + first, count, mask, xmode, ctx->status, ctx->part_info, plog, ctx->stream));
     return ST_OK;
 }
 
@@ -1367,7 +1376,7 @@ static int resolve_overflow(HydAmdContext *ctx, uint32_t status, bool *again) {
     if (!(status & HYDK_STATUS_OVERFLOW))
         return ST_OK;
     if (status & HYDK_STATUS_LAYOUT)
-        return fail(ctx, ST_INTERNAL_ERROR, "float LF group in a context laid out for integer token records");
+        return fail(ctx, ST_INTERNAL_ERROR, "the device stages disagree about a group's layout (float records in an integer context, or a section longer than its chain counted)");
     /* the LF coder forked onto its side stream may still be reading the LF ints and adding into the
      * histograms the replay clears and rewrites: it has to be done before anything is re-laid or rerun */
     if (ctx->lf_stream)

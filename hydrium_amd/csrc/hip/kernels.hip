@@ -506,22 +506,29 @@ __device__ __forceinline__ void store_record(void *tok, uint32_t at, uint32_t to
 
 #define HYDK_K1_OCCUPANCY __launch_bounds__(kThreads, HYDK_K1_WAVES)
 template <int FMT, int XMODE>
-__global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status) {
+__global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restrict__ jobs, uint32_t *status, uint2 *part_info,
+                                                       int plog) {
     typedef typename SampleOf<FMT>::type sample_t;
     constexpr bool LUTS = XMODE == kXybGather;
     constexpr int kWords = FMT == HYDK_FMT_U8 ? 6 : 12; /* dwords holding 8 packed RGB pixels */
-    const HydkLfJob job = jobs[blockIdx.x >> 6];
+    /* plog > 0 (launches of one or two LF groups: a tile-mode frame, the drop-in API's closing tile): a group is walked by
+     * 1 << plog workgroups, a run of strips each, so that 64 or 128 groups still fill 256 compute units; every part leaves
+     * its symbols in its own share of the group's token array and k_join_parts closes the gaps (round 5) */
+    const unsigned bid = blockIdx.x >> plog, part = blockIdx.x & ((1u << plog) - 1u);
+    const HydkLfJob job = jobs[bid >> 6];
     if (job.fmt != FMT || (FMT != HYDK_FMT_F32 && job.use_luts != xyb_arith(XMODE)))
         return; /* another template instance of this launch round owns this LF group */
-    if ((int)(blockIdx.x & 63) >= job.gcols * job.grows)
+    if ((int)(bid & 63) >= job.gcols * job.grows)
         return;
     if (FMT == HYDK_FMT_F32 && job.rec_bytes != 8) {
         /* the context's token arrays are laid out for 4-byte records; the host widens them before it
          * records a float LF group, so this is unreachable — kept so that a host bug cannot corrupt memory */
         if (threadIdx.x == 0) {
             atomicOr(status, HYDK_STATUS_LAYOUT);
-            job.sym_count[blockIdx.x & 63] = 0;
-            job.rbits_total[blockIdx.x & 63] = 0;
+            job.sym_count[bid & 63] = 0;
+            job.rbits_total[bid & 63] = 0;
+            if (plog)
+                part_info[blockIdx.x] = uint2{0u, 0u};
         }
         return;
     }
@@ -550,7 +557,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
-    const int g = blockIdx.x & 63;
+    const int g = (int)(bid & 63);
     const int gx = g % job.gcols, gy = g / job.gcols;
     const int px0 = gx << 8, py0 = gy << 8;
     const int gw = min(256, job.width - px0), gh = min(256, job.height - py0);
@@ -606,9 +613,13 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                 nxt[k] = HYDK_GLOBAL(const uint32_t, p)[k];
         }
     };
-    prefetch(0);
+    /* this workgroup's strips [s_first, s_end) and its share of the group's token array */
+    const int s_per = (gbh + (1 << plog) - 1) >> plog;
+    const int s_first = (int)part * s_per, s_end = min(gbh, s_first + s_per);
+    const uint32_t tok_room = job.tok_cap >> plog;
+    prefetch(s_first);
 
-    void *const tok = (char *)job.tokens + (size_t)g * job.tok_cap * job.rec_bytes;
+    void *const tok = (char *)job.tokens + (size_t)g * job.tok_cap * job.rec_bytes + (size_t)part * tok_room * (FMT == HYDK_FMT_F32 ? 8u : 4u);
     uint32_t goff = 0;
     uint32_t rb_sum = 0;     /* residue bits of the symbols this thread emitted */
     bool overflowed = false; /* the group outgrew its token array: stop storing, report, let the host rerun the frame */
@@ -617,7 +628,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
     bool bad_sample = false;
     __syncthreads();
 
-    for (int s = 0; s < gbh; s++) {
+    for (int s = s_first; s < s_end; s++) {
         /* ---------------- phase A: 8 px of one block row -> XYB -> row DCT ---------------- */
         if (ab < gbw) {
             float xv[8], yv[8], bv[8];
@@ -907,7 +918,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
          * (encoder.c:724-738) are carried from symbol to symbol instead of being recounted from the bitmap, and the
          * work is balanced over the workgroup whatever the blocks' sizes. */
         {
-            overflowed = overflowed || goff + strip_total > job.tok_cap;
+            overflowed = overflowed || goff + strip_total > tok_room;
             /* runs of floor(n / 256) symbols, the first n mod 256 threads one more: the longer runs sit in the first
              * wavefronts, so the later ones leave the loop an iteration earlier */
             static_assert(kThreads == 256, "run lengths are computed with shifts");
@@ -1020,8 +1031,13 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
         atomicAdd(&s_rbits, rb_sum);
     __syncthreads();
     if (t == 0) {
-        job.sym_count[g] = overflowed || HYDK_K1_SKIP ? 0u : goff; /* timing-only builds leave no symbols for the later stages */
-        job.rbits_total[g] = s_rbits;
+        const uint32_t count = overflowed || HYDK_K1_SKIP ? 0u : goff; /* timing-only builds leave no symbols for the later stages */
+        if (plog) {
+            part_info[blockIdx.x] = uint2{count, s_rbits};
+        } else {
+            job.sym_count[g] = count;
+            job.rbits_total[g] = s_rbits;
+        }
         if (overflowed)
             atomicOr(status, HYDK_STATUS_TOKENS);
     }
@@ -1030,6 +1046,43 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
 }
 
 #include "lf_huffman.h" /* the LF coder's code construction rides in the table kernel's (or the chain kernel's) launch, see below */
+
+/* a group coded by several transform workgroups (k_transform_tokenize, plog > 0): part q's records sit at q * (tok_cap >> plog)
+ * of the group's token array; moved down so that the array is the group's symbol stream in one piece, and the group's symbol
+ * and residue-bit totals written where the single-workgroup form leaves them.  One workgroup per group; a part moves towards
+ * lower addresses only, chunk by chunk (a chunk is read by all threads before any of it is written, and never reaches into
+ * the chunk after it).  grid = 64 x LF groups of the launch. */
+__global__ __launch_bounds__(kThreads) void k_join_parts(const HydkLfJob *__restrict__ jobs, const uint2 *part_info, int plog) {
+    const HydkLfJob job = jobs[blockIdx.x >> 6];
+    const int g = blockIdx.x & 63;
+    if (g >= job.gcols * job.grows)
+        return;
+    /* records are 8 bytes for float LF groups and 4 for integer ones — also in a context whose arrays were laid out for
+     * 8-byte records by an earlier float frame (job.rec_bytes is the group PITCH's unit, not this group's record size) */
+    const uint32_t parts = 1u << plog, room = job.tok_cap >> plog, wpr = job.fmt == HYDK_FMT_F32 ? 2u : 1u; /* 32-bit words per record */
+    uint32_t *const base = (uint32_t *)((char *)job.tokens + (size_t)g * job.tok_cap * job.rec_bytes);
+    uint32_t total = part_info[(size_t)blockIdx.x * parts].x, rbits = part_info[(size_t)blockIdx.x * parts].y;
+    for (uint32_t q = 1; q < parts; q++) {
+        const uint2 pi = part_info[(size_t)blockIdx.x * parts + q];
+        const uint32_t *src = base + (size_t)q * room * wpr;
+        uint32_t *dst = base + (size_t)total * wpr;
+        const uint32_t words = pi.x * wpr;
+        if (dst != src)
+            for (uint32_t at = 0; at < words; at += kThreads) { /* (uniform trip count: the barrier is reached by all) */
+                const uint32_t i = at + threadIdx.x;
+                const uint32_t v = i < words ? src[i] : 0u;
+                __syncthreads();
+                if (i < words)
+                    dst[i] = v;
+            }
+        total += pi.x;
+        rbits += pi.y;
+    }
+    if (threadIdx.x == 0) {
+        job.sym_count[g] = total;
+        job.rbits_total[g] = rbits;
+    }
+}
 
 /* ==========================================================================================
  * K2: per-LF-group ANS tables.  grid = LF groups of the frame (send order), block = 256.
@@ -1930,6 +1983,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
     uint32_t cur = (uint32_t)(lo_bit & 31ull) + bits; /* stream start so far */
     uint32_t carry = 0;                               /* content of the partly filled word at cur >> 5 */
 
+    bool bad = false;
     auto put = [&](uint32_t word, uint32_t v) {
         const uint32_t d = wbase + word;
         if (d == shared_lo || d == shared_hi)
@@ -1950,6 +2004,14 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
         const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
         if (!total) {
             before_stores();
+            return;
+        }
+        if (total > cur) { /* the records and refill flags hold more bits than the chain kernel counted for this section: the
+                            * stages disagree about the group (a bug upstream).  Stop here instead of walking a window of
+                            * 2^32 bits: the frame fails with an internal error */
+            if (lane == 0)
+                atomicOr((uint32_t *)status, HYDK_STATUS_LAYOUT);
+            bad = true;
             return;
         }
         const uint32_t newcur = cur - total;
@@ -2038,6 +2100,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
             nb[j] = valid ? rbits + (refill ? 16u : 0u) : 0u;
         }
         emit(val, nb, take);
+        if (bad) return;
     }
     {
         /* [preset id][final state, low half first] precede everything (encoder.c:945, entropy.c:1127-1130) */
@@ -2280,9 +2343,9 @@ namespace hydk {
 /* One launch per template instance that owns at least one LF group of this round; an instance
  * returns at once for the LF groups of another sample format. */
 hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt_mask, int xmode, uint32_t *status,
-                            hipStream_t stream) {
-    const dim3 grid(num_slots * HYDK_GROUPS_PER_LFG), block(kThreads);
-#define HYDK_LAUNCH_K1(FMT, XM) hipLaunchKernelGGL((k_transform_tokenize<FMT, XM>), grid, block, 0, stream, d_jobs, status)
+                            uint2 *part_info, int plog, hipStream_t stream) {
+    const dim3 grid((num_slots * HYDK_GROUPS_PER_LFG) << plog), block(kThreads);
+#define HYDK_LAUNCH_K1(FMT, XM) hipLaunchKernelGGL((k_transform_tokenize<FMT, XM>), grid, block, 0, stream, d_jobs, status, part_info, plog)
 #define HYDK_LAUNCH_K1_MODES(FMT)              \
     do {                                       \
         if (xmode == kXybFastRcp)              \
@@ -2304,6 +2367,8 @@ hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt
         HYDK_LAUNCH_K1(HYDK_FMT_F32, kXybIeeeDiv);
 #undef HYDK_LAUNCH_K1_MODES
 #undef HYDK_LAUNCH_K1
+    if (plog)
+        hipLaunchKernelGGL(k_join_parts, dim3(num_slots * HYDK_GROUPS_PER_LFG), block, 0, stream, d_jobs, part_info, plog);
     return hipGetLastError();
 }
 

@@ -1223,6 +1223,7 @@ int hydamd_encode_image_batch(HydAmdContext *ctx, int frames, const void *const 
 }
 
 /* K1 for slots [first, first + count) */
+static int debug_skip();
 static int transform_range(HydAmdContext *ctx, int first, int count) {
     unsigned mask = 0;
     for (int i = first; i < first + count; i++) {
@@ -1376,7 +1377,7 @@ static int resolve_overflow(HydAmdContext *ctx, uint32_t status, bool *again) {
     if (!(status & HYDK_STATUS_OVERFLOW))
         return ST_OK;
     if (status & HYDK_STATUS_LAYOUT)
-        return fail(ctx, ST_INTERNAL_ERROR, "the device stages disagree about a group's layout (float records in an integer context, or a section longer than its chain counted)");
+        return fail(ctx, ST_INTERNAL_ERROR, "float LF group in a context laid out for integer token records");
     /* the LF coder forked onto its side stream may still be reading the LF ints and adding into the
      * histograms the replay clears and rewrites: it has to be done before anything is re-laid or rerun */
     if (ctx->lf_stream)
@@ -2089,6 +2090,9 @@ int hydamd_sync(HydAmdContext *ctx) {
     ctx->h_status = *ctx->h_status_pinned;
     if (ctx->h_status & HYDK_STATUS_BAD_SAMPLE)
         return fail(ctx, ST_API_ERROR, "Invalid NaN Float");
+    /* (with HYDAMD_DEBUG_SKIP the stages are MEANT to disagree: the frame's bytes are stale by design there) */
+    if ((ctx->h_status & HYDK_STATUS_INCONSISTENT) && !debug_skip())
+        return fail(ctx, ST_INTERNAL_ERROR, "a section holds more bits than its rANS chain counted (the device stages disagree about a group)");
     ctx->results_valid = true;
     return ST_OK;
 }

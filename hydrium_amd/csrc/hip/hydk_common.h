@@ -33,7 +33,8 @@
 #define HYDK_STATUS_BAD_SAMPLE 1u /* non-finite float sample */
 #define HYDK_STATUS_TOKENS 2u     /* a group needed more token records than its array holds */
 #define HYDK_STATUS_PAYLOAD 4u    /* the frame's sections need more bytes than the payload holds */
-#define HYDK_STATUS_LAYOUT 8u     /* the stages disagree about a layout: float LF group in 4-byte token arrays, a section longer than its chain counted (bugs) */
+#define HYDK_STATUS_LAYOUT 8u     /* a float LF group met token arrays laid out for 4-byte records (host bug) */
+#define HYDK_STATUS_INCONSISTENT 16u /* k_rans_emit: a section's records and refill flags hold more bits than its chain counted (a bug upstream; the frame fails) */
 #define HYDK_STATUS_OVERFLOW (HYDK_STATUS_TOKENS | HYDK_STATUS_PAYLOAD | HYDK_STATUS_LAYOUT) /* later stages skip the frame */
 
 /* Token record (8 bytes) written by the transform kernel and read by the rANS kernel:

@@ -2010,7 +2010,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
                             * stages disagree about the group (a bug upstream).  Stop here instead of walking a window of
                             * 2^32 bits: the frame fails with an internal error */
             if (lane == 0)
-                atomicOr((uint32_t *)status, HYDK_STATUS_LAYOUT);
+                atomicOr((uint32_t *)status, HYDK_STATUS_INCONSISTENT);
             bad = true;
             return;
         }

@@ -24,7 +24,7 @@ run() { # name, ext, command...  (stdout -> the profile, stderr -> a log; non-ze
   local name=$1 ext=$2; shift 2
   "$@" > "$out/${tag}_$name.$ext" 2> "/tmp/${tag}_$name.err"
   local rc=$?
-  if [ $rc -ne 0 ] || [ ! -s "$out/${tag}_$name.$ext" ] || grep -q "Traceback (most recent call last)" "$out/${tag}_$name.$ext" "/tmp/${tag}_$name.err"; then
+  if [ $rc -ne 0 ] || [ ! -s "$out/${tag}_$name.$ext" ] || grep -qE "Traceback \(most recent call last\)|raise [A-Za-z]*Error|^[A-Za-z.]*Error: " "$out/${tag}_$name.$ext" "/tmp/${tag}_$name.err"; then
     cat "$out/${tag}_$name.$ext" >> "/tmp/${tag}_$name.err" 2>/dev/null
     fail "$name" "/tmp/${tag}_$name.err"
   fi

@@ -25,6 +25,7 @@ ap.add_argument("--lf", type=int, default=2)
 ap.add_argument("--rans", type=int, default=5)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--size", type=int, default=8192)
+ap.add_argument("--depth", type=int, default=16, choices=(8, 16))
 ap.add_argument("--height", type=int, default=0, help="frame height if not square: a frame of k x 8192 rows stands for k frames coded as one launch group")
 ap.add_argument("--no-bind", action="store_true")
 ap.add_argument("--only-transform", action="store_true", help="enqueue the transform stage only (no entropy stage, no LF coder)")
@@ -36,7 +37,7 @@ a = ap.parse_args()
 if not a.no_bind:
     placement.bind_near_gpu(0)
 H = a.height or a.size
-img = synth.make_image("photo", a.size, H, 16, device=torch.device("cuda", 0))
+img = synth.make_image("photo", a.size, H, a.depth, device=torch.device("cuda", 0))
 lfg = (-(-a.size // 2048)) * (-(-H // 2048))
 ctxs = [device.DeviceContext(0, lfg * a.batch, 0) for _ in range(a.streams)]
 if a.batch > 1:

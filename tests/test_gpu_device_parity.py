@@ -316,3 +316,33 @@ def test_curve_gather_choice_never_changes_a_byte(image, kind, depth):
             ctx.encode_image_tensor(t)
             ctx.sync()
             assert ctx.read_payload() == want.stream, (kind, depth, mode)
+
+
+@pytest.mark.parametrize("form", [4, 5])
+def test_integer_frame_in_a_context_an_earlier_float_frame_widened(image, form):
+    """A float LF group re-lays the context's token arrays for 8-byte records and the context stays wide; an integer frame
+    that follows still writes 4-byte records.  Small launches split every group over four transform workgroups whose parts
+    k_join_parts closes up: the record width there is the LF group's, not the array's (round 5: the first version used the
+    array's, and k_rans_emit walked off the end of a section)."""
+    from hydrium_amd import device, synth
+    from oracle import binding as orc
+    import torch
+
+    f = synth.make_image_f32("photo", 264, 136)
+    want_f, _ = orc.encode_lf_group(f)
+    with device.DeviceContext(0, 1, 0) as ctx:
+        ctx.set_rans_waves(form)
+        t_f = torch.from_numpy(f).cuda()
+        ctx.encode_image_tensor(t_f)
+        ctx.sync()
+        assert ctx.read_payload() == want_f.stream
+        for kind, w, h, depth in (("photo", 72, 40, 8), ("photo", 520, 300, 16), ("noise", 257, 255, 8)):
+            img = image(kind, w, h, depth)
+            want, _ = orc.encode_lf_group(img)
+            t = _torch_image(img)
+            ctx.encode_image_tensor(t)
+            ctx.sync()
+            assert ctx.read_payload() == want.stream, (kind, w, h, depth)
+        ctx.encode_image_tensor(t_f)      # and a float frame again
+        ctx.sync()
+        assert ctx.read_payload() == want_f.stream

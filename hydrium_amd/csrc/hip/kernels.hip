@@ -1067,14 +1067,24 @@ __global__ __launch_bounds__(kThreads) void k_join_parts(const HydkLfJob *__rest
         const uint32_t *src = base + (size_t)q * room * wpr;
         uint32_t *dst = base + (size_t)total * wpr;
         const uint32_t words = pi.x * wpr;
-        if (dst != src)
-            for (uint32_t at = 0; at < words; at += kThreads) { /* (uniform trip count: the barrier is reached by all) */
-                const uint32_t i = at + threadIdx.x;
-                const uint32_t v = i < words ? src[i] : 0u;
+        if (dst != src) {
+            constexpr uint32_t kPer = 8; /* words a thread carries per chunk: eight loads in flight, one barrier per 2048 words */
+            for (uint32_t at = 0; at < words; at += kPer * kThreads) { /* (uniform trip count: the barrier is reached by all) */
+                uint32_t v[kPer];
+#pragma unroll
+                for (uint32_t k = 0; k < kPer; k++) {
+                    const uint32_t i = at + k * kThreads + threadIdx.x;
+                    v[k] = i < words ? src[i] : 0u;
+                }
                 __syncthreads();
-                if (i < words)
-                    dst[i] = v;
+#pragma unroll
+                for (uint32_t k = 0; k < kPer; k++) {
+                    const uint32_t i = at + k * kThreads + threadIdx.x;
+                    if (i < words)
+                        dst[i] = v[k];
+                }
             }
+        }
         total += pi.x;
         rbits += pi.y;
     }

@@ -1757,8 +1757,14 @@ int hydamd_read_frame_blob(HydAmdContext *ctx, int num_slots, const void **host_
     const size_t lf_off = sizeof(HydAmdBlobHeader) + (size_t)num_slots * sizeof(HydAmdBlobSlot);
     const size_t hf_off = (lf_off + (size_t)ctx->h_lf_total + 15u) & ~(size_t)15u;
     size_t total = hf_off + (size_t)ctx->h_total;
-    if (total > ctx->stage_blob_cap)
-        return fail(ctx, ST_INTERNAL_ERROR, "staged blob larger than its buffer");
+    if (total > ctx->stage_blob_cap) {
+        /* the frame outgrew the context's buffers and was rerun inside hydamd_sync with larger ones: what was staged is the
+         * first run's (its header says "incomplete") and the rerun's results do not fit the staging buffer sized before it.
+         * No blob: the caller reads the results the separate way */
+        *host_blob = nullptr;
+        *size = 0;
+        return ST_OK;
+    }
     for (int attempt = 0; attempt < 2; attempt++) {
         if (total > ctx->stage_host_cap) {
             if (ctx->stage_host)

@@ -309,7 +309,8 @@ HYDAMD_EXPORT size_t hydamd_blob_bound(HydAmdContext *ctx, int num_slots);
 HYDAMD_EXPORT int hydamd_export_frame(HydAmdContext *ctx, int num_slots, void *device_dst, size_t capacity);
 /* The same blob through a device buffer and a pinned host buffer of the context's own: stage (enqueued on the context's
  * stream, behind hydamd_finish_frame), hydamd_sync, read — ONE device-to-host copy of exactly the blob's bytes; *host_blob
- * stays valid until the context's next staged read.  What hyd_send_tile uses for the frames it assembles on the host
+ * stays valid until the context's next staged read; *size = 0 (and a blob whose header carries HYDAMD_BLOB_RETRY) when the frame
+ * was rerun with larger buffers after it was staged: read the results the separate way then.  What hyd_send_tile uses for the frames it assembles on the host
  * (tile mode): six small read-backs became one. */
 HYDAMD_EXPORT int hydamd_stage_frame_blob(HydAmdContext *ctx, int num_slots);
 HYDAMD_EXPORT int hydamd_read_frame_blob(HydAmdContext *ctx, int num_slots, const void **host_blob, size_t *size);

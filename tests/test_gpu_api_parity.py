@@ -599,3 +599,29 @@ def test_in_place_output_returns_the_callers_buffer(lib, image):
     got = api.encode_image(lib, img, out_buf=buf, in_place=True)
     assert isinstance(got, memoryview)
     assert bytes(got) == want
+
+
+def test_tile_frame_rerun_for_overflow_after_its_results_were_staged():
+    """Tile-mode frames leave the device as one staged blob (hydamd_stage_frame_blob / hydamd_read_frame_blob).  A frame that
+    outgrows its buffers is rerun inside hydamd_sync with larger ones AFTER it was staged: the staged blob is the first
+    run's, and the rerun's results may not even fit the staging buffer (round 5: that was an error until the fuzz sweep found
+    it) — the encoder then reads the results the separate way.  Small buffers force the rerun on every noise tile."""
+    import subprocess
+    import sys
+
+    code = """
+import numpy as np
+from hydrium_amd import api, synth
+from oracle import refprobe
+img = synth.make_image("noise", 600, 300, 8)
+for kw in (dict(shift_x=0, shift_y=0), dict(shift_x=1, shift_y=1), dict()):
+    want = api.encode_image(refprobe.reference_library(), img, **kw)
+    for _ in range(2):       # the second pass meets contexts already enlarged
+        assert api.encode_image(api.Library(), img, **kw) == want, kw
+print("ok")
+"""
+    assert reference_expected()
+    env = dict(os.environ, HYDAMD_TOKEN_CAP="4096", HYDAMD_PAYLOAD_CAP="16384",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

@@ -1223,7 +1223,6 @@ int hydamd_encode_image_batch(HydAmdContext *ctx, int frames, const void *const 
 }
 
 /* K1 for slots [first, first + count) */
-static int debug_skip();
 static int transform_range(HydAmdContext *ctx, int first, int count) {
     unsigned mask = 0;
     for (int i = first; i < first + count; i++) {
@@ -1570,15 +1569,18 @@ int hydamd_alphabet_floor_from_peers(HydAmdContext *ctx, int npeers, HydAmdConte
 
 /* Can every device of the list read every other one's memory?  hyd_send_tile asks BEFORE it deals a frame out to several
  * devices (a frame that cannot be assembled from peer reads stays on one device).  HYDAMD_TEST_NO_P2P=1 answers "no" for
- * any list of two or more entries — how the tests reach the fallback on a box with one GPU. */
+ * any list of two or more entries — how the tests reach the fallback on a box with one GPU (HYD_TEST_HOOKS flavour of the
+ * library only). */
 int hydamd_peers_reachable(const int *devices, int n) {
     if (!devices || n < 1)
         return 0;
     if (n == 1)
         return 1;
+#ifdef HYD_TEST_HOOKS
     if (const char *e = getenv("HYDAMD_TEST_NO_P2P"))
         if (*e && *e != '0')
             return 0;
+#endif
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) {
         (void)hipGetLastError();
@@ -1658,9 +1660,11 @@ int hydamd_verify_read(HydAmdContext *reader, int index, unsigned long long *sum
     HIP_TRY(reader, hipSetDevice(reader->device));
     HIP_TRY(reader, hipStreamSynchronize(reader->stream));
     HIP_TRY(reader, hipMemcpy(sum, reader->verify_sums + index, sizeof(*sum), hipMemcpyDeviceToHost));
+#ifdef HYD_TEST_HOOKS
     if (const char *e = getenv("HYDAMD_TEST_CORRUPT_PEER_VIEW")) /* test hook: the sum of view `index` as a faulty link would leave it */
         if (*e && atoi(e) == index)
             *sum ^= 1ull;
+#endif
     return ST_OK;
 }
 
@@ -1798,9 +1802,20 @@ HydAmdAssembler *hydamd_context_assembler(HydAmdContext *ctx) {
     return ctx->assembler;
 }
 
-/* HYDAMD_DEBUG_SKIP (bit mask, measurements only — the frame's bytes are then stale or wrong): leave a stage of the closing
- * sequence out of the stream: 1 table kernel, 2 rANS chains, 4 section scan + emit, 8 the LF coder's kernels.
- * scripts/pipe_probe.py uses it to price each stage's share of the pipelined frame rate. */
+/* HYDAMD_WAVE_FORM_EMITS=1: form 4 as until round 4, the chain kernel writing its own bits into the reversed buffers (A/B) */
+static bool wave_form_defers() {
+    static const bool v = !(getenv("HYDAMD_WAVE_FORM_EMITS") && atoi(getenv("HYDAMD_WAVE_FORM_EMITS")) != 0);
+    return v;
+}
+
+/* Measurement and test hooks live in the HYD_TEST_HOOKS flavour of the library only (hydrium_amd/lib/libhydrium_probe.so,
+ * loaded explicitly by scripts/pipe_probe.py and the tests that need them): the shipped libhydrium.so.0 reads none of
+ * these variables and never returns HYD_OK for a frame whose stages disagree.
+ *   HYDAMD_DEBUG_SKIP (bit mask; the frame's bytes are then stale or wrong): leave a stage of the closing sequence out of
+ *   the stream: 1 table kernel, 2 rANS chains, 4 section scan + emit, 8 the LF coder's kernels, 16 stand-ins in the
+ *   chains' place (HYDAMD_DEBUG_STANDIN: sleep | valu | lds | both | valu4; HYDAMD_DEBUG_SLEEP_US / _LDS / _VGPRS / _WGS,
+ *   HYDAMD_DEBUG_STANDIN_STEPS).  scripts/pipe_probe.py prices each stage's share of the pipelined frame rate with it. */
+#ifdef HYD_TEST_HOOKS
 namespace {
 __global__ __launch_bounds__(64) void k_sleep_probe(unsigned long long ticks_100mhz) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -1826,16 +1841,140 @@ __global__ __launch_bounds__(64) void k_sleep_probe(unsigned long long ticks_100
 HYDK_SLEEP_PROBE_REGS(k_sleep_probe_regs104, 104)
 HYDK_SLEEP_PROBE_REGS(k_sleep_probe_regs40, 40)
 #undef HYDK_SLEEP_PROBE_REGS
-} /* namespace */
-/* HYDAMD_WAVE_FORM_EMITS=1: form 4 as until round 4, the chain kernel writing its own bits into the reversed buffers (A/B) */
-static bool wave_form_defers() {
-    static const bool v = !(getenv("HYDAMD_WAVE_FORM_EMITS") && atoi(getenv("HYDAMD_WAVE_FORM_EMITS")) != 0);
-    return v;
+
+/* Stand-ins that DO one part of what a lane-form chain wavefront does, for `steps` steps, holding 96 registers and the
+ * launch's dynamic LDS (round 6, VERDICT r5 task 1: which part of a chain's work costs the loop?).
+ *   VALU: per step the chain's 17 vector instructions (same classes, one dependent chain through x), no LDS access;
+ *   LDS : per step one ds_read_b128 of a lane-random 16-byte row in the first 32 KB (the operand rows: 64 lanes, random
+ *         rows, bank conflicts as in the chain) and one dependent ds_read_u16 (the slot lookup), then s_sleep for the
+ *         rest of the step; no arithmetic beyond the address generator;
+ *   QUARTER: the VALU stand-in's work at a quarter of the rate (three steps in four are slept away): four such
+ *         wavefronts, one per SIMD of a 256-thread workgroup, issue what ONE chain issues — the same instruction load
+ *         spread evenly over a compute unit's four SIMDs instead of concentrated on one. */
+__global__ __launch_bounds__(256) void k_chain_standin(int mode /* 1 VALU | 2 LDS | 4 QUARTER */, uint32_t steps, uint32_t lds_bytes,
+                                                       uint32_t *sink) {
+    const bool VALU = mode & 1, LDS = mode & 2, QUARTER = mode & 4; /* launch-uniform: scalar branches */
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    uint32_t hold[96];
+#pragma unroll
+    for (int i = 0; i < 96; i++)
+        hold[i] = threadIdx.x * (uint32_t)(i + 1);
+    __builtin_amdgcn_s_setprio(3);
+    uint32_t x = 0x130000u + threadIdx.x * 2654435761u, acc = 0;
+    const uint32_t row_mask = (lds_bytes >= 32768u ? 32768u : lds_bytes >= 16u ? lds_bytes : 16u) - 16u;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_dyn;
+    if (LDS) /* something to read */
+        for (uint32_t i = threadIdx.x * 4u; i + 4u <= lds_bytes; i += blockDim.x * 4u)
+            *(uint32_t *)(s_dyn + i) = i * 2246822519u;
+    __syncthreads();
+    for (uint32_t s = 0; s < steps; s++) {
+        if (QUARTER && (s & 3u) != (threadIdx.x >> 6)) { /* this wavefront's turn is every fourth step */
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        uint32_t t0, t1, q, a, b, sm, fl = acc, row = 0, slot = 0;
+        if (LDS) {
+            const uint32_t radr = lds0 + ((x * 2654435761u >> 7) & row_mask & ~15u);
+            uint4 o;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(o) : "v"(radr));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            row = o.x ^ o.y ^ o.z ^ o.w;
+        }
+        if (VALU) {
+            asm volatile("v_and_or_b32 %[x], %[x], %[k], %[h0]\n\t"
+                         "v_mul_hi_u32 %[q], %[x], %[h1]\n\t"
+                         "v_mad_i32_i24 %[t0], %[q], %[h2], %[x]\n\t"
+                         "v_add_co_u32 %[t1], vcc, %[t0], %[h2]\n\t"
+                         "v_min_u32 %[t0], %[t0], %[t1]\n\t"
+                         "v_lshl_add_u32 %[t1], %[t0], 1, %[h3]\n\t"
+                         "v_or_b32 %[a], %[h0], %[t1]\n\t"
+                         "v_perm_b32 %[b], %[a], %[t0], %[h1]\n\t"
+                         "v_addc_co_u32 %[q], vcc, 0, %[q], vcc\n\t"
+                         "v_lshlrev_b32 %[a], 12, %[q]\n\t"
+                         "v_cmp_gt_u32 vcc, %[a], %[h2]\n\t"
+                         "v_cndmask_b32_sdwa %[b], %[a], %[a], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                         "v_cndmask_b32_e64 %[sm], %[k], 0, vcc\n\t"
+                         "v_addc_co_u32 %[fl], vcc, %[fl], %[fl], vcc\n\t"
+                         "v_xor_b32 %[x], %[b], %[t1]\n\t"
+                         "v_add_u32 %[x], %[x], %[sm]\n\t"
+                         "v_or_b32 %[x], 0x10000, %[x]"
+                         : [x] "+v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [a] "=&v"(a), [b] "=&v"(b), [sm] "=&v"(sm), [fl] "+v"(fl)
+                         : [k] "v"(hold[0] | 0xfffu), [h0] "v"(hold[1]), [h1] "v"(hold[2] | 0x10001u), [h2] "v"(hold[3] | 1u), [h3] "v"(hold[4])
+                         : "vcc");
+            acc = fl;
+        } else {
+            x = x * 1664525u + 1013904223u + row;
+        }
+        if (LDS) {
+            const uint32_t sadr = lds0 + (__umulhi(x, lds_bytes > 2u ? lds_bytes - 2u : 1u) & ~1u);
+            asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(sadr) : "memory");
+            x ^= slot;
+        }
+        if (!VALU)
+            __builtin_amdgcn_s_sleep(1); /* 64 clocks: what the chain spends issuing */
+#pragma unroll
+        for (int i = 0; i < 96; i++)
+            asm volatile("" : "+v"(hold[i])); /* the registers stay allocated (no instruction is emitted) */
+    }
+    uint32_t r = x ^ acc;
+#pragma unroll
+    for (int i = 0; i < 96; i++)
+        r ^= hold[i];
+    if (r == 0xFFFFFFFFu && sink)
+        *sink = r;
 }
+} /* namespace */
 static int debug_skip() {
     static const int v = getenv("HYDAMD_DEBUG_SKIP") ? atoi(getenv("HYDAMD_DEBUG_SKIP")) : 0;
     return v;
 }
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+/* the stand-ins of HYDAMD_DEBUG_SKIP & 16 for `count` LF groups, in the chains' place in ctx's stream */
+static void launch_chain_standins(HydAmdContext *ctx, int count) {
+    static const int wgs = env_int("HYDAMD_DEBUG_SLEEP_WGS", 1);
+    static const int lds = env_int("HYDAMD_DEBUG_SLEEP_LDS", 0);
+    static const unsigned long long ticks = 100ull * (unsigned long long)env_int("HYDAMD_DEBUG_SLEEP_US", 2500);
+    static const int regs = env_int("HYDAMD_DEBUG_SLEEP_VGPRS", 0);
+    static const int steps = env_int("HYDAMD_DEBUG_STANDIN_STEPS", 30000);
+    static const char *kind = getenv("HYDAMD_DEBUG_STANDIN") ? getenv("HYDAMD_DEBUG_STANDIN") : "sleep";
+    const dim3 grid(wgs > 0 ? wgs * count : 1);
+#define HYDK_STANDIN(MODE, THREADS)                                                                                         \
+    do {                                                                                                                    \
+        if (lds > 65536)                                                                                                    \
+            (void)hipFuncSetAttribute((const void *)k_chain_standin, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      \
+        hipLaunchKernelGGL(k_chain_standin, grid, dim3(THREADS), (size_t)lds, ctx->stream, MODE, (uint32_t)steps,           \
+                           (uint32_t)lds, (uint32_t *)nullptr);                                                             \
+    } while (0)
+    if (!strcmp(kind, "valu"))
+        HYDK_STANDIN(1, 64);
+    else if (!strcmp(kind, "lds"))
+        HYDK_STANDIN(2, 64);
+    else if (!strcmp(kind, "both"))
+        HYDK_STANDIN(3, 64);
+    else if (!strcmp(kind, "valu4"))
+        HYDK_STANDIN(5, 256);
+    else if (regs >= 100) {
+        if (lds > 65536)
+            (void)hipFuncSetAttribute((const void *)k_sleep_probe_regs104, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(k_sleep_probe_regs104, grid, dim3(64), (size_t)lds, ctx->stream, ticks, (uint32_t *)nullptr);
+    } else if (regs >= 40) {
+        if (lds > 65536)
+            (void)hipFuncSetAttribute((const void *)k_sleep_probe_regs40, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(k_sleep_probe_regs40, grid, dim3(64), (size_t)lds, ctx->stream, ticks, (uint32_t *)nullptr);
+    } else {
+        if (lds > 65536)
+            (void)hipFuncSetAttribute((const void *)k_sleep_probe, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(k_sleep_probe, grid, dim3(64), (size_t)lds, ctx->stream, ticks);
+    }
+#undef HYDK_STANDIN
+}
+#else
+static constexpr int debug_skip() { return 0; }
+static void launch_chain_standins(HydAmdContext *, int) {}
+#endif /* HYD_TEST_HOOKS */
 
 /* K2 + the rANS chains for slots [first, first + count); with_lf_codes: the lane-form launch also builds the
  * LF coder's prefix codes of the same slots (their token kernel must be enqueued already) */
@@ -1869,24 +2008,8 @@ static int entropy_range(HydAmdContext *ctx, int first, int count, bool with_lf_
         if (with_lf_codes && !lanes)
             return fail(ctx, ST_INTERNAL_ERROR, "LF code construction can only ride with the lane-form entropy stage");
         (void)lanes;
-        if (debug_skip() & 16) { /* ... 16: sleeping wavefronts of the chains' duration in their place: HYDAMD_DEBUG_SLEEP_WGS of them
-                                  * (default 1), each holding HYDAMD_DEBUG_SLEEP_LDS bytes of LDS (default 0) */
-            static const int wgs = getenv("HYDAMD_DEBUG_SLEEP_WGS") ? atoi(getenv("HYDAMD_DEBUG_SLEEP_WGS")) : 1;
-            static const int lds = getenv("HYDAMD_DEBUG_SLEEP_LDS") ? atoi(getenv("HYDAMD_DEBUG_SLEEP_LDS")) : 0;
-            if (lds > 65536)
-                (void)hipFuncSetAttribute((const void *)k_sleep_probe, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            static const unsigned long long ticks = getenv("HYDAMD_DEBUG_SLEEP_US") ? 100ull * strtoull(getenv("HYDAMD_DEBUG_SLEEP_US"), nullptr, 10) : 250000ull;
-            static const int regs = getenv("HYDAMD_DEBUG_SLEEP_VGPRS") ? atoi(getenv("HYDAMD_DEBUG_SLEEP_VGPRS")) : 0;
-            if (regs >= 100) {
-                if (lds > 65536)
-                    (void)hipFuncSetAttribute((const void *)k_sleep_probe_regs104, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipLaunchKernelGGL(k_sleep_probe_regs104, dim3(wgs > 0 ? wgs * count : 1), dim3(64), (size_t)lds, ctx->stream, ticks, (uint32_t *)nullptr);
-            } else if (regs >= 40) {
-                if (lds > 65536)
-                    (void)hipFuncSetAttribute((const void *)k_sleep_probe_regs40, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipLaunchKernelGGL(k_sleep_probe_regs40, dim3(wgs > 0 ? wgs * count : 1), dim3(64), (size_t)lds, ctx->stream, ticks, (uint32_t *)nullptr);
-            } else
-            hipLaunchKernelGGL(k_sleep_probe, dim3(wgs > 0 ? wgs * count : 1), dim3(64), (size_t)lds, ctx->stream, ticks);
+        if (debug_skip() & 16) { /* measurement builds only: stand-ins in the chains' place */
+            launch_chain_standins(ctx, count);
         } else if (debug_skip() & 2) {
         } else if (lanes) {
             HIP_TRY(ctx, hydk::launch_rans_lanes(jobs, ctx->sym_count + g0, ctx->tables + first,
@@ -2096,7 +2219,7 @@ int hydamd_sync(HydAmdContext *ctx) {
     ctx->h_status = *ctx->h_status_pinned;
     if (ctx->h_status & HYDK_STATUS_BAD_SAMPLE)
         return fail(ctx, ST_API_ERROR, "Invalid NaN Float");
-    /* (with HYDAMD_DEBUG_SKIP the stages are MEANT to disagree: the frame's bytes are stale by design there) */
+    /* (the measurement flavour's stage skipping makes the stages disagree by design; the shipped library has no such switch) */
     if ((ctx->h_status & HYDK_STATUS_INCONSISTENT) && !debug_skip())
         return fail(ctx, ST_INTERNAL_ERROR, "a section holds more bits than its rANS chain counted (the device stages disagree about a group)");
     ctx->results_valid = true;

@@ -61,6 +61,22 @@ constexpr int kThreads = 256;
 #ifndef HYDK_K1_ILP
 #define HYDK_K1_ILP 2
 #endif
+/* Round 6 (VERDICT r5 task 1): what of a lane-form chain's work costs the pipelined loop?  Timing-only variants of the
+ * chain kernel (wrong bytes; scripts/k1_variants.py builds them, scripts/pipe_probe.py runs them with the emit stage off):
+ *   HYDK_CHAIN_PROBE   1: every operand row from ONE address (no bank conflicts among the 64 lanes' ds_read_b128);
+ *                      4: no global traffic after the first round (a lane walks its first 16 records again and again and
+ *                         stores nothing)
+ *   HYDK_CHAIN_PRIO    issue priority of the chain wavefronts (product: 3)
+ *   HYDK_K1_PRIO       issue priority of the transform kernel's wavefronts (product: none set = 0) */
+#ifndef HYDK_CHAIN_PROBE
+#define HYDK_CHAIN_PROBE 0
+#endif
+#ifndef HYDK_CHAIN_PRIO
+#define HYDK_CHAIN_PRIO 3
+#endif
+#ifndef HYDK_K1_PRIO
+#define HYDK_K1_PRIO 0
+#endif
 constexpr int kS0Block = 72;            /* floats per block in the row-pass buffer: 64 + 8 pad -> conflict-free column reads */
 constexpr int kS0Chan = 32 * kS0Block;  /* floats per channel */
 constexpr int kDbgPitch = 2048;
@@ -511,6 +527,9 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
     typedef typename SampleOf<FMT>::type sample_t;
     constexpr bool LUTS = XMODE == kXybGather;
     constexpr int kWords = FMT == HYDK_FMT_U8 ? 6 : 12; /* dwords holding 8 packed RGB pixels */
+#if HYDK_K1_PRIO
+    __builtin_amdgcn_s_setprio(HYDK_K1_PRIO);
+#endif
     /* plog > 0 (launches of one or two LF groups: a tile-mode frame, the drop-in API's closing tile): a group is walked by
      * 1 << plog workgroups, a run of strips each, so that 64 or 128 groups still fill 256 compute units; every part leaves
      * its symbols in its own share of the group's token array and k_join_parts closes the gaps (round 5) */
@@ -1722,7 +1741,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kLdsBytes];
     uint4 *const s_ops = (uint4 *)s_mem;
     unsigned char *const s_tab = s_mem + kOpsBytes; /* uint16_t[NC * 4096] */
-    HYDK_URGENT();
+    __builtin_amdgcn_s_setprio(HYDK_CHAIN_PRIO);
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= num_slots) {
         /* passengers: workgroup num_slots + s builds the prefix code of LF group s's coefficient stream
@@ -1873,7 +1892,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
         uint4 cur[4];                                                                                            \
         _Pragma("unroll") for (int q = 0; q < 4; q++) cur[q] = nx[q];                                            \
         const int rjn = rj - 1;                                                                                  \
-        if (rjn >= 0) { /* the next round's line travels during this round's walk */                             \
+        if (rjn >= 0 && !(HYDK_CHAIN_PROBE & 4)) { /* the next round's line travels during this round's walk */  \
             _Pragma("unroll") for (int q = 0; q < 4; q++) nx[q] = load_records4(tok, rjn * 4 + q);               \
         }                                                                                                        \
         if (rj >= 0) {                                                                                           \
@@ -1885,8 +1904,14 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
              * read past the table returns 0).  All sixteen rows are requested before the walk: a row requested  \
              * inside its step returns behind the step's slot lookup and lengthens every wait */                 \
             uint4 ov[16];                                                                                        \
-            _Pragma("unroll") for (int pos = 15; pos >= 0; pos--)                                                \
-                ov[pos] = *(const uint4 *)(s_mem + ((FIRST) && !(pos < first_count) ? 0u : recs[pos] & 0x7FF0u)); \
+            _Pragma("unroll") for (int pos = 15; pos >= 0; pos--) {                                              \
+                uint32_t row = (FIRST) && !(pos < first_count) ? 0u : recs[pos] & 0x7FF0u;                       \
+                if (HYDK_CHAIN_PROBE & 1) { /* one address for all lanes, sixteen requests all the same */       \
+                    row = 1920u;                                                                                 \
+                    asm volatile("" : "+v"(row));                                                                \
+                }                                                                                                \
+                ov[pos] = *(const uint4 *)(s_mem + row);                                                         \
+            }                                                                                                    \
             __builtin_amdgcn_sched_barrier(0); /* (the scheduler would sink the requests back into the steps) */ \
             uint32_t A = 0, B = 0, sm = 0, sl = 0, so = 0; /* the walk's state between two steps of a round */   \
             if (FIRST) {                                                                                         \
@@ -1901,7 +1926,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
              * stores too, and stored at a round's end they were the youngest memory operations when the next round \
              * took its records — that wait was a wait for the stores' round trip */                             \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
-            if (prj >= 0) {                                                                                      \
+            if (prj >= 0 && !(HYDK_CHAIN_PROBE & 4)) {                                                           \
                 aux[prj * 2] = uint4{pw[0], pw[1], pw[2], pw[3]};                                                \
                 aux[prj * 2 + 1] = uint4{pw[4], pw[5], pw[6], pw[7]};                                            \
                 flags[prj] = (uint16_t)pfl; /* bit (p mod 16): symbol p refills */                               \

@@ -5,9 +5,17 @@
 #   tile mode; the transform kernel by content and curve-gather choice; the removal table of the pipelined loop.
 # Every probe's exit status and output are checked: a probe that fails leaves <name>.FAILED with its log's tail and the script
 # exits non-zero at the end (round 4 committed a Python traceback as a profile).
-# usage: bash scripts/collect_profiles.sh <tag>          e.g. r05
+# usage: bash scripts/collect_profiles.sh <tag> [target ...]      e.g. r06            (every target)
+#                                                                     r06 chain_probes pmc
+# One target per file under profiles/ (the name after the tag): bench_default, kernel_stats (single, single_form4, pipe, shard,
+# api + api_timeline), tile_mode, k1_content, pipeline_bounds, chain_probes, priorities, icache, pmc_8k_photo, fuzz.
+# The probes that skip stages or run stand-in kernels load hydrium_amd/lib/libhydrium_probe.so (HYD_TEST_HOOKS flavour;
+# scripts/pipe_probe.py selects it) or a variant built by `python scripts/k1_variants.py --build ...` (chain_probes and
+# priorities build theirs HERE, before the gpurun call: hipcc cross-compiles, the .so files travel with the snapshot).
 set -u
-tag=$1
+tag=$1; shift
+targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities icache pmc_8k_photo} "
+want() { [[ "$targets" == *" $1 "* ]]; }
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
@@ -43,7 +51,11 @@ trace() { # name, summariser args..., -- command...: rocprofv3 kernel trace of t
   run "kernel_stats_$name" txt bash -c "python $root/scripts/rocpd_summary.py $db | grep -v 'at::native'"
 }
 
+if want bench_default; then
 run bench_default json python bench.py
+fi
+
+if want kernel_stats; then
 trace single -- python "$root/scripts/one_frame.py" 5 5 2
 trace single_form4 -- python "$root/scripts/one_frame.py" 5 4 2
 trace pipe -- python "$root/bench.py" --steps 256 --no-cpu-baseline --no-api --no-legs
@@ -53,27 +65,103 @@ grep "^{" /tmp/kt_shard.log | tail -1 > "$out/${tag}_shard_under_rocprof.json"; 
 trace api --memory-copy-trace -- python "$root/scripts/api_frame_times.py"
 db=$(find /tmp/kt_api -name "*.db" 2>/dev/null | head -1)
 if [ -n "$db" ]; then run api_timeline txt python scripts/rocpd_timeline.py "$db" 75; else fail api_timeline /tmp/kt_api.log; fi  # the last frame: uploads, kernels, read-back
+fi
+
+if want tile_mode; then
 run tile_mode txt bash -c 'echo "## default: every hyd_send_tile call ends with its tile frame (the reference s timing)"; python scripts/api_tile_mode.py 4096 8 | grep shift; echo "## eight tile frames in flight (HYDAMD_TILE_PIPELINE=8), GPU_MAX_HW_QUEUES=22"; GPU_MAX_HW_QUEUES=22 HYDAMD_TILE_PIPELINE=8 python scripts/api_tile_mode.py 4096 8 | grep shift'
+fi
+
+if want k1_content; then
 run k1_content txt bash -c 'for g in 0 1 2; do echo "== HYDAMD_CURVE_GATHERS=$g (0 by the last frame, 1 always, 2 never)"; HYDAMD_CURVE_GATHERS=$g python scripts/k1_content.py; done'
-# the removal table of the pipelined loop (HYDAMD_DEBUG_SKIP: 1 tables, 2 chains, 4 scan + emit, 8 LF coder; 16: sleeping wavefronts in the chains' place)
+fi
+
+# one sustained figure of the pipelined loop (16 contexts x 2 frames per launch group, lane-form chains), two repetitions
+export PIPE_PROBE='p() { python scripts/pipe_probe.py --streams 16 --batch 2 --frames 512 --rans 5 --reps 2 "$@" 2>&1 | grep -E "SUSTAINED|rror" | sed "s/.*: //" | tr "\n" " "; echo; }'
+
+# the removal table of the pipelined loop (HYDAMD_DEBUG_SKIP: 1 tables, 2 chains, 4 scan + emit, 8 LF coder; 16: stand-ins in
+# the chains' place).  Every row without the real chain also skips scan + emit (their input is stale then and the emit kernel's
+# consistency guard would stop it early): ONE commit, one box, comparable rows.
+if want pipeline_bounds; then
 run pipeline_bounds txt bash -c '
-  p() { python scripts/pipe_probe.py --streams 16 --batch 2 --frames 512 --rans 5 --reps 2 "$@" 2>&1 | grep -E "SUSTAINED|rror" | sed "s/.*: //" | tr "\n" " "; echo; }
-  echo "# the pipelined loop (16 contexts x 2 frames per launch group, lane-form chains), sustained Gpixel/s, two runs each; one box"
-  echo -n "whole frame:                          "; p
-  echo -n "without scan + emit (skip 4):         "; HYDAMD_DEBUG_SKIP=4 p
-  echo -n "without the chain kernel (skip 2):    "; HYDAMD_DEBUG_SKIP=2 p
-  echo -n "without chains, scan, emit (skip 6):  "; HYDAMD_DEBUG_SKIP=6 p
-  echo -n "without the LF coder (skip 8):        "; HYDAMD_DEBUG_SKIP=8 p
+  eval "$PIPE_PROBE"
+  echo "# the pipelined loop (16 contexts x 2 frames per launch group, lane-form chains), sustained Gpixel/s, two runs each; one box; commit $(cat .commit 2>/dev/null)"
+  echo -n "whole frame:                                     "; p
+  echo -n "without scan + emit (skip 4):                    "; HYDAMD_DEBUG_SKIP=4 p
+  echo -n "without chains, scan, emit (skip 6):             "; HYDAMD_DEBUG_SKIP=6 p
+  echo -n "without chains, scan, emit, LF coder (skip 14):  "; HYDAMD_DEBUG_SKIP=14 p
+  echo -n "without the LF coder (skip 8):                   "; HYDAMD_DEBUG_SKIP=8 p
   t() { python scripts/pipe_probe.py --streams $1 --frames 512 --rans 5 --reps 2 --only-transform 2>&1 | grep -E "SUSTAINED|rror" | sed "s/.*: //" | tr "\n" " "; echo; }
-  echo -n "transform kernel only, 16 contexts:   "; t 16
-  echo -n "transform kernel only, 32 contexts:   "; t 32
-  for us in 4000 1750; do for lds in 0 24576 45056 65536 81920; do
-    echo -n "sleeping wavefronts for ${us} us holding ${lds} B of LDS in the chains place: "; HYDAMD_DEBUG_SKIP=16 HYDAMD_DEBUG_SLEEP_US=$us HYDAMD_DEBUG_SLEEP_LDS=$lds p
+  echo -n "transform kernel only, 16 contexts:              "; t 16
+  for lds in 0 65536 81920; do for regs in 0 104; do
+    echo -n "sleepers 2500 us, $regs VGPRs, $lds B LDS, no scan + emit (skip 20): "; HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_US=2500 HYDAMD_DEBUG_SLEEP_LDS=$lds HYDAMD_DEBUG_SLEEP_VGPRS=$regs p
   done; done
-  echo -n "LF code construction riding the table kernel (HYDAMD_LF_CODES_RIDE=tables): "; HYDAMD_LF_CODES_RIDE=tables p
 '
+fi
+
+# VERDICT r5 task 1: WHICH part of a chain's work costs the loop?  Stand-ins that do one part of it (device_api.hip
+# k_chain_standin: 112 registers, 64 KB of LDS, 30 000 steps = the photo frame's longest group) and timing-only variants of
+# the real chain (kernels.hip HYDK_CHAIN_PROBE), all with scan + emit off, on one box.
+if want chain_probes; then
+run chain_probes txt bash -c '
+  eval "$PIPE_PROBE"
+  v() { HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$1.so; export HYDAMD_LIB; shift; "$@"; unset HYDAMD_LIB; }
+  echo "# what a lane-form chain DOES, taken apart inside the pipelined loop; sustained Gpixel/s, two runs each; one box; commit $(cat .commit 2>/dev/null)"
+  echo -n "real chain, no scan + emit (skip 4):                          "; HYDAMD_DEBUG_SKIP=4 p
+  echo -n "no chain at all (skip 6):                                     "; HYDAMD_DEBUG_SKIP=6 p
+  S="HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=65536"
+  echo -n "sleepers, 104 VGPRs + 64 KB, 2500 us:                         "; env $S HYDAMD_DEBUG_SLEEP_VGPRS=104 HYDAMD_DEBUG_SLEEP_US=2500 bash -c "$PIPE_PROBE; p"
+  echo -n "stand-in: the chain s 17 VALU instructions per step, no LDS:  "; env $S HYDAMD_DEBUG_STANDIN=valu bash -c "$PIPE_PROBE; p"
+  echo -n "stand-in: its LDS reads only (random rows, conflicts):        "; env $S HYDAMD_DEBUG_STANDIN=lds bash -c "$PIPE_PROBE; p"
+  echo -n "stand-in: both:                                               "; env $S HYDAMD_DEBUG_STANDIN=both bash -c "$PIPE_PROBE; p"
+  echo -n "stand-in: the VALU load on FOUR wavefronts, a quarter each:   "; env $S HYDAMD_DEBUG_STANDIN=valu4 bash -c "$PIPE_PROBE; p"
+  echo -n "stand-in: VALU, 80 KB of LDS:                                 "; env HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=81408 HYDAMD_DEBUG_STANDIN=valu bash -c "$PIPE_PROBE; p"
+  echo -n "stand-in: VALU, no LDS held:                                  "; env HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=0 HYDAMD_DEBUG_STANDIN=valu bash -c "$PIPE_PROBE; p"
+  for n in base p1 p4 p5; do
+    echo -n "real chain variant $n (HYDK_CHAIN_PROBE: 1 rows from one address, 4 no global traffic, 5 both), skip 4: "; HYDAMD_DEBUG_SKIP=4 v $n p
+  done
+  echo "# the stand-ins and variants ALONE (one frame at a time, ms per chain launch by the library s event timers)"
+  for k in valu lds both valu4; do echo -n "stand-in $k alone: "; HYDAMD_LIB=$PWD/hydrium_amd/lib/libhydrium_probe.so HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=65536 HYDAMD_DEBUG_STANDIN=$k python scripts/one_frame.py 2 5 2 t 2>&1 | grep rans_encode; done
+  for n in base p1 p4 p5; do echo -n "variant $n alone: "; HYDAMD_DEBUG_SKIP=4 v $n python scripts/one_frame.py 2 5 2 t 2>&1 | grep rans_encode; done
+'
+fi
+
+# issue priorities: the transform kernel ABOVE the chains (rounds 4-5 only ever lowered the chains to the transform kernel s 0,
+# where the oldest wavefront — the chain — still wins)
+if want priorities; then
+run priorities txt bash -c '
+  eval "$PIPE_PROBE"
+  v() { HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$1.so; export HYDAMD_LIB; shift; "$@"; unset HYDAMD_LIB; }
+  echo "# s_setprio of the transform kernel (k) and of the chain wavefronts (c); the product is k0 c3; whole frame, sustained Gpixel/s, alternating; commit $(cat .commit 2>/dev/null)"
+  for rep in 1 2; do for n in base k1c0 k2c0 k3c0 k3c2; do echo -n "$n: "; v $n p; done; done
+'
+fi
+
+# instruction cache: the transform kernel is 29.6 KB of code, the chain kernel 17 KB, the table kernel 23 KB (llvm-readelf -s)
+if want icache; then
+mkdir -p /tmp/pmc_ic
+(cd /tmp && rocprofv3 -L > /tmp/pmc_ic/list.txt 2>&1; grep -i -E "ICACHE|IFETCH|INST_CACHE" /tmp/pmc_ic/list.txt | sort -u | head -40 > "$root/$out/${tag}_icache_counters_available.txt")
+for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "SQ_IFETCH SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
+  n=$(echo $set | cut -d" " -f1)
+  rm -rf /tmp/pmc_ic/$n
+  (cd /tmp && rocprofv3 --pmc $set --kernel-include-regex "k_transform|k_rans" -d /tmp/pmc_ic/$n -o p -- python "$root/scripts/pipe_probe.py" --streams 16 --batch 2 --frames 64 --rans 5 --reps 1 > /tmp/pmc_ic/$n.log 2>&1)
+  db=$(find /tmp/pmc_ic/$n -name "*.db" | head -1)
+  if [ -n "$db" ]; then python scripts/pmc_summary.py "$db" > "$out/${tag}_icache_loop_$n.txt" 2>&1; else tail -5 /tmp/pmc_ic/$n.log > "$out/${tag}_icache_loop_$n.FAILED"; fi
+  rm -rf /tmp/pmc_ic/${n}_alone
+  (cd /tmp && rocprofv3 --pmc $set --kernel-include-regex "k_transform|k_rans" -d /tmp/pmc_ic/${n}_alone -o p -- python "$root/scripts/one_frame.py" 3 5 2 > /tmp/pmc_ic/${n}_alone.log 2>&1)
+  db=$(find /tmp/pmc_ic/${n}_alone -name "*.db" | head -1)
+  if [ -n "$db" ]; then python scripts/pmc_summary.py "$db" > "$out/${tag}_icache_alone_$n.txt" 2>&1; fi
+done
+fi
+
+if want pmc_8k_photo; then
 bash scripts/collect_pmc.sh "$out/pmc" python scripts/one_frame.py 3 5 2 > /tmp/${tag}_pmc.log 2>&1
 cat "$out"/pmc/pmc_set*.txt > "$out/${tag}_pmc_8k_photo.txt" 2>/dev/null
 if ! grep -q "SQ_INSTS_VALU" "$out/${tag}_pmc_8k_photo.txt" || ! grep -q "FETCH_SIZE" "$out/${tag}_pmc_8k_photo.txt"; then fail pmc_8k_photo /tmp/${tag}_pmc.log; fi
+fi
+
+# seeded fuzz of the drop-in API against the reference (scripts/fuzz_api_parity.py); not part of the default set
+if want fuzz; then
+run fuzz txt bash -c 'echo "# commit $(cat .commit 2>/dev/null)"; for seed in 61 62 63; do FUZZ_BUDGET_S=${FUZZ_BUDGET_S:-600} python scripts/fuzz_api_parity.py 4000 $seed 2>&1 | tail -3; done; FUZZ_BUDGET_S=${FUZZ_BUDGET_S:-600} python scripts/fuzz_api_parity.py 400 64 large 2>&1 | tail -3'
+fi
 ls -la "$out"
 exit $failed

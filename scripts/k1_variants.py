@@ -30,8 +30,10 @@ def build(specs):
 
     hb.build()
     os.makedirs(OUT, exist_ok=True)
-    base_objs = [os.path.join(hb.OBJ_DIR, f) for f in sorted(os.listdir(hb.OBJ_DIR))
-                 if f.endswith(".o") and not f.endswith(".test.o") and f != "kernels.hip.o"]
+    # the HYD_TEST_HOOKS flavour's objects (the probes skip stages through HYDAMD_DEBUG_SKIP), kernels.hip recompiled per variant
+    names = sorted(os.listdir(hb.OBJ_DIR))
+    base_objs = [os.path.join(hb.OBJ_DIR, f) for f in names
+                 if f != "kernels.hip.o" and (f.endswith(".test.o") or (f.endswith(".o") and f[:-2] + ".test.o" not in names))]
     procs = []
     for spec in specs:
         name, _, flags = spec.partition("=")

@@ -13,6 +13,8 @@ import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "28")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the measurement switches (HYDAMD_DEBUG_SKIP, the stand-in kernels) exist in the HYD_TEST_HOOKS flavour of the library only
+os.environ.setdefault("HYDAMD_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hydrium_amd", "lib", "libhydrium_probe.so"))
 import torch  # noqa: E402
 
 from hydrium_amd import device, placement, synth  # noqa: E402

@@ -126,9 +126,9 @@ def test_c_client_unchanged_runs_on_the_device_list(tmp_path):
 
 def test_without_peer_access_the_frame_stays_on_one_device():
     """VERDICT r4 task 2 / ADVICE: peer capability is asked when the frame is dealt out (encoder.c, hydamd_peers_reachable),
-    not at the final tile.  HYDAMD_TEST_NO_P2P=1 makes the probe answer "no": the frame is coded on the encoder's home device,
+    not at the final tile.  HYDAMD_TEST_NO_P2P=1 (the HYD_TEST_HOOKS flavour of the library only) makes the probe answer "no": the frame is coded on the encoder's home device,
     says so once on stderr, and is the reference's file"""
-    ours, ref, err = _run(("photo", 4296, 4168, 8), "0,0,0,0", {"HYDAMD_TEST_NO_P2P": "1"})
+    ours, ref, err = _run(("photo", 4296, 4168, 8), "0,0,0,0", {"HYDAMD_TEST_NO_P2P": "1", "HYDAMD_LIB": hbuild.PROBE_PATH})
     assert "(shard)" not in err, "the frame was dealt out although the devices cannot read each other"
     assert "no peer access" in err
     assert ours == ref
@@ -141,6 +141,6 @@ def test_verify_peers_checks_every_shards_view_and_names_the_pair_that_differs()
     ours, ref, err = _run(("photo", 4296, 4168, 8), "0,0,0,0", {"HYDAMD_VERIFY_PEERS": "1"})
     assert "(shard)" in err
     assert ours == ref
-    got, _, _ = _run(("photo", 4296, 4168, 8), "0,0,0,0", {"HYDAMD_VERIFY_PEERS": "1", "HYDAMD_TEST_CORRUPT_PEER_VIEW": "2"},
+    got, _, _ = _run(("photo", 4296, 4168, 8), "0,0,0,0", {"HYDAMD_VERIFY_PEERS": "1", "HYDAMD_TEST_CORRUPT_PEER_VIEW": "2", "HYDAMD_LIB": hbuild.PROBE_PATH},
                      reference=False)
     assert got.startswith("ERR") and "peer read mismatch" in got and "shard 2" in got

@@ -38,6 +38,16 @@ def test_only_api_symbols_are_exported():
     assert syms and all(s.startswith(("hyd_", "hydamd_")) for s in syms), syms
 
 
+def test_shipped_library_carries_no_measurement_or_test_hooks():
+    """VERDICT r5 task 4: stage skipping, stand-in kernels and fault injection (HYDAMD_DEBUG_*, HYDAMD_TEST_*) exist in the
+    HYD_TEST_HOOKS flavour only (libhydrium_probe.so, loaded explicitly by the probes and the tests that need them)"""
+    hbuild.build()
+    pat = re.compile(rb"HYDAMD_DEBUG_|HYDAMD_TEST_|k_sleep_probe|k_chain_standin")
+    assert not pat.findall(open(hbuild.LIB_PATH, "rb").read())
+    assert pat.findall(open(hbuild.PROBE_PATH, "rb").read()), "the probe flavour lost its hooks"
+    assert os.path.realpath(api.DEFAULT_LIB) != os.path.realpath(hbuild.PROBE_PATH) or os.environ.get("HYDAMD_LIB")
+
+
 def test_product_does_not_reference_the_oracle():
     bad = []
     for base, _, files in os.walk(os.path.join(ROOT, "hydrium_amd")):

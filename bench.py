@@ -11,9 +11,14 @@ additive C-ABI of include/hydrium_amd.h.  Consecutive steps are spread over `--s
 independent contexts so that the latency-bound rANS kernel of one frame overlaps the transform
 kernel of the next, as a production encoder serving a queue of frames would.
 
-N > 1 (launched by torch.distributed.run): weak scaling — rank r codes its own 8192x8192 slab
-(a window of one larger synthetic image), then the packed HF sections of all ranks are
-concatenated with one RCCL all-gather of sizes and one of payload bytes per step.
+N > 1: weak scaling — one process per GPU over RCCL, rank r codes its own 8192x8192 frames (windows of one larger
+synthetic image); no collective in the data path (the frames are independent), only the barriers and the clock are
+shared (`--exchange` adds a per-frame blob gather to a rotating rank).  `python bench.py --gpus N` starts the N ranks
+ITSELF (re-executing under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N`) when it is not already
+running inside a process group; launched by torch.distributed.run it checks that the world it finds is the `--gpus` it
+was given.  `n_gpus` is the process group's size and `rccl_ranks` the sum of an all-reduce of ones over it.
+`--mode shard` is the strong-scaling leg (ONE 16384x16384 frame per step, LF groups sharded over the ranks, one blob
+gather per frame to the assembling rank).
 
 Prints ONE JSON line on rank 0.  `value` is whole-job Mpixel/s over all GPUs.
 """
@@ -49,7 +54,12 @@ def emit(out):
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs of this node to run on, one rank each (default: the world size torch.distributed.run gave us, else 1); "
+                         "with N > 1 and no process group in the environment bench.py launches the N ranks itself")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="start the ranks exactly as a real run does, form the process group (gloo where there is no GPU), all-reduce a "
+                         "one per rank, print {n_gpus, rccl_ranks} on rank 0 and stop: proves `--gpus N` reaches N ranks")
     ap.add_argument("--steps", type=int, default=120,
                     help="frames in the timed interval (the pipeline is primed before it and kept full behind it)")
     ap.add_argument("--warmup", type=int, default=3)
@@ -95,6 +105,78 @@ def parse():
     ap.add_argument("--no-bind", action="store_true",
                     help="leave the process where the scheduler put it instead of binding it to the CPUs of the GPU's NUMA node")
     return ap.parse_args()
+
+
+def launch_ranks(args, argv=None):
+    """`--gpus N` names the job's size.  Inside a process group (torch.distributed.run exported WORLD_SIZE) it must be the
+    group's; outside one, N > 1 means: start the N ranks here — the same command under torch.distributed.run, one rank per
+    GPU of this node, rendezvous on 127.0.0.1 — and return their exit status.  Returns None when this process is a rank
+    (or the whole job, N = 1) and should carry on."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        world = int(env_world)
+        if args.gpus is None:
+            args.gpus = world
+        if args.gpus != world:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} ranks "
+                             f"(WORLD_SIZE): launch with --nproc-per-node {args.gpus} or leave --gpus to the launcher")
+        return None
+    if args.gpus is None:
+        args.gpus = 1
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.gpus == 1:
+        return None
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:  # a free rendezvous port (two benches on one node must not meet)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), HYDAMD_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    print(f"bench.py: --gpus {args.gpus} outside a process group: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def check_world(args, dist, device=None):
+    """after init_process_group: the group IS the job --gpus named, and every rank answers (-> rccl_ranks)"""
+    import torch
+
+    world = dist.get_world_size()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} ranks")
+    one = torch.ones(1, dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(one)
+    ranks = int(one.item())
+    if ranks != world:
+        raise SystemExit(f"bench.py: an all-reduce of ones over {world} ranks returned {ranks}")
+    return ranks
+
+
+def dry_run_launch(args):
+    import torch
+    import torch.distributed as dist
+
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29535"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        os.environ.setdefault(k, v)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    gpu = torch.cuda.is_available()
+    if gpu:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo")
+    ranks = check_world(args, dist, torch.device("cuda", local) if gpu else None)
+    out = {"dry_run_launch": True, "n_gpus": dist.get_world_size(), "rccl_ranks": ranks, "backend": "nccl" if gpu else "gloo",
+           "launched_by": "bench.py itself" if os.environ.get("HYDAMD_BENCH_SELF_LAUNCHED") else
+                          "the caller's torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else "nobody: a single process"}
+    rank = dist.get_rank()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        emit(out)
 
 
 def cpu_baseline(host_img):
@@ -343,7 +425,10 @@ def run_shard(args):
     for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29534"), ("RANK", "0"), ("WORLD_SIZE", "1")):
         os.environ.setdefault(k, v)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    ranks = check_world(args, dist, torch.device("cuda", local))
     out = shard_leg(args, args.steps, args.warmup, args.size if args.size != 8192 else 16384, assemble=args.assemble)
+    if out is not None:
+        out["rccl_ranks"] = ranks
     dist.barrier()
     torch.cuda.synchronize()
     dist.destroy_process_group()  # RCCL has seen the contexts' streams: it goes first
@@ -533,9 +618,13 @@ def run_batch(args):
         from hydrium_amd import placement
 
         placement.bind_near_gpu(local)
+    ranks = 1
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        ranks = check_world(args, dist, torch.device("cuda", local))
     out = batch_leg(args, args.frames, args.threads)
+    if out is not None:
+        out["rccl_ranks"] = ranks
     if world > 1:
         dist.destroy_process_group()
     if out is not None:
@@ -706,6 +795,11 @@ def api_multi_device_leg(ndev, size=16384):
 
 def main():
     args = parse()
+    rc = launch_ranks(args)
+    if rc is not None:
+        sys.exit(rc)
+    if args.dry_run_launch:
+        return dry_run_launch(args)
     if args.mode == "shard":
         return run_shard(args)
     if args.mode == "batch":
@@ -736,6 +830,9 @@ def main():
         # before the contexts exist: HIP hands hardware queues to streams in creation order, and RCCL's streams created
         # after sixteen contexts' land on queues the contexts use (measured in a world of one: 81 instead of 121 Gpixel/s)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        rccl_ranks = check_world(args, dist, torch.device("cuda", local))
+    else:
+        rccl_ranks = 1
     from hydrium_amd import api, device, sharding, synth
 
     W = H = args.size
@@ -1141,7 +1238,7 @@ def main():
             "metric": "Mpixel/s encode (8K RGB, default q)",
             "value": round(world * W * H * K / dt / 1e6, 1),
             "unit": "Mpixel/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / K * 1e3, 4),
             "value_is": "the SUSTAINED rate: median of three consecutive windows (timing.timed_frames frames each) of one continuous run behind ten launch groups per stream of priming "
                         "(it equals the barrier-to-barrier rate of the whole run, timing.Mpixel/s_wall, within a few per cent)",

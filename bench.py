@@ -793,6 +793,71 @@ def api_multi_device_leg(ndev, size=16384):
     return out
 
 
+_INPROCESS_CLIENT = r"""
+import hashlib, json, sys, time
+import numpy as np
+import torch
+from hydrium_amd import device, synth
+ndev, size, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+devices = list(range(ndev)) if ndev > 1 else [0, 0, 0, 0]
+n = len(devices)
+D = 4 if ndev <= 1 else 8                       # frames in flight: one HydAmdMulti each (n contexts, n streams)
+pics = {d: synth.make_image("photo", size, size, 8, device=torch.device("cuda", d)) for d in sorted(set(devices))}
+for d in pics:
+    torch.cuda.synchronize(d)
+origins = [pics[d] for d in devices]
+frames = [device.MultiFrame(devices, size, size) for _ in range(D)]
+for i, m in enumerate(frames):                  # first use: contexts' lazy allocations, the peer pairs' first-use verification
+    m.encode(origins, assembling_shard=i % n)
+sizes = {m.result() for m in frames}
+def run(steps, to_host):
+    pinned = torch.empty(max(sizes) + 4096, dtype=torch.uint8).pin_memory().numpy() if to_host else None
+    t0 = time.perf_counter()
+    for i in range(steps + D):
+        m = frames[i % D]
+        if i >= D:
+            m.read(pinned) if to_host else m.result()
+        if i < steps:
+            m.encode(origins, assembling_shard=i % n)
+    return (time.perf_counter() - t0) / steps
+run(D, False)
+ms_hbm = run(steps, False) * 1e3
+ms_host = run(steps, True) * 1e3
+frames[0].encode(origins, assembling_shard=0)
+data = bytes(frames[0].read())
+reruns = sum(m.context_overflow_reruns(d) for m in frames for d in range(n))
+print("RESULT " + json.dumps({"ms_per_frame": round(ms_hbm, 3), "ms_per_frame_file_to_pinned_host": round(ms_host, 3), "frames_in_flight": D,
+                              "shards": n, "devices": devices, "steps": steps, "frame_bytes": len(data), "frame_md5": hashlib.md5(data).hexdigest(),
+                              "overflow_reruns": reruns}))
+for m in frames:
+    m.close()
+"""
+
+
+def shard_inprocess_leg(ndev, size=16384, steps=40):
+    """configs[3] through ONE C call per frame in ONE process (include/hydrium_amd.h hydamd_encode_image_multi,
+    csrc/host/multi.c): the pixels already in HBM on every device, LF groups dealt in raster runs, floors by peer read,
+    every shard's blob a view, the file assembled on a rotating shard's GPU from peer reads — hyd_send_tile's
+    multi-device closing stage without the uploads, no RCCL.  One GPU: the list 0,0,0,0 (four contexts, every
+    cross-context step, only the xGMI hop missing); at --gpus N rank 0's subprocess drives all N devices."""
+    import subprocess
+
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("HYDAMD_DEVICE", "HYDAMD_DEVICES", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _INPROCESS_CLIENT, str(ndev), str(size), str(steps)], capture_output=True, text=True, env=env, timeout=900)
+    line = next((l for l in r.stdout.splitlines() if l.startswith("RESULT ")), None)
+    if r.returncode or not line:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    out = json.loads(line[7:])
+    out["aliased"] = ndev <= 1
+    out["Mpixel/s"] = round(size * size / out["ms_per_frame"] / 1e3, 1)
+    out["workload"] = (f"one {size}x{size} RGB8 'photo' frame per step (BASELINE configs[3]), device-resident on every device, "
+                       "hydamd_encode_image_multi + hydamd_multi_result per frame, the finished file left in the assembling device's HBM "
+                       "(ms_per_frame) or copied into pinned host memory (ms_per_frame_file_to_pinned_host); wall clock over `steps` frames")
+    return out
+
+
 def main():
     args = parse()
     rc = launch_ranks(args)
@@ -1404,6 +1469,14 @@ def main():
                     out["api_multi_device"]["same_file_as_shard_16k"] = out["api_multi_device"]["md5"] == out["shard_16k"]["frame_md5"]
             except Exception as exc:
                 out["api_multi_device"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if not args.no_legs:
+            # the same frame as shard_16k through the C library's in-process composition (no RCCL, no host pixels)
+            try:
+                out["shard_16k_inprocess"] = shard_inprocess_leg(world)
+                if "shard_16k" in out and "frame_md5" in out["shard_16k"] and "frame_md5" in out["shard_16k_inprocess"]:
+                    out["shard_16k_inprocess"]["same_file_as_shard_16k"] = out["shard_16k_inprocess"]["frame_md5"] == out["shard_16k"]["frame_md5"]
+            except Exception as exc:
+                out["shard_16k_inprocess"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_img)
             if "api_end_to_end" in out and "md5" in out["cpu_baseline"]:

@@ -590,7 +590,8 @@ struct HydkAsm {
     hipStream_t last_stream = nullptr; /* ... and the stream it ran in (the caller's: it must outlive hydk_asm_read of that run) */
     hipEvent_t done = nullptr;    /* the assembler's own: recorded behind every run; what a plan change and a run in another stream wait for */
     uint64_t last_cap = 0;        /* ... and how large that buffer is */
-    bool ran = false;
+    bool ran = false;             /* `done` was recorded behind a complete run */
+    bool unsettled = false;       /* a run's launches began and its event was never recorded (a launch failed in between): `done` says nothing about them */
     uint8_t *bounce = nullptr;    /* pinned: hydk_asm_read lands frames here (DMA engines), then copies to the caller's memory */
     size_t bounce_cap = 0;
 };
@@ -695,6 +696,10 @@ int hydk_asm_set_plan(HydkAsm *a, const void *plan, size_t bytes) {
      * encoder thread's frames in a batch of differently shaped images) — by the assembler's own event, not by the caller's
      * stream handle, which may be gone by now; runs in different streams are chained behind each other (hydk_asm_run), so
      * the last run's event covers them all */
+    if (a->unsettled) { /* kernels of a run that failed half-way may still be reading the old plan and scratch arrays */
+        ASM_TRY(a, hipDeviceSynchronize());
+        a->unsettled = false;
+    }
     if (a->ran)
         ASM_TRY(a, hipEventSynchronize(a->done));
     if (bytes > a->plan_cap) {
@@ -739,12 +744,16 @@ int hydk_asm_run(HydkAsm *a, const void *const *blobs, const uint64_t *blob_caps
     /* k_asm_copy moves whole 32-bit words of the output and 16-byte-aligned records of the blobs */
     if ((uintptr_t)out & 3u)
         return afail(a, ST_API_ERROR, "output buffer must be 4-byte aligned");
+    if (a->unsettled) { /* the last run failed half-way: nothing says when its kernels are done with the scratch arrays */
+        ASM_TRY(a, hipDeviceSynchronize());
+        a->unsettled = false;
+    }
     if (a->ran && st != a->last_stream) /* the runs share the assembler's scratch arrays: one behind the other */
         ASM_TRY(a, hipStreamWaitEvent(st, a->done, 0));
     a->last_out = (uint8_t *)out;
     a->last_cap = out_cap;
     a->last_stream = st;
-    a->ran = true;
+    a->unsettled = true; /* until this run's event is recorded (`ran` used to be set here, before the launches) */
     BlobArgs args;
     memset(&args, 0, sizeof(args));
     for (uint32_t b = 0; b < a->hplan.num_blobs; b++) {
@@ -760,6 +769,8 @@ int hydk_asm_run(HydkAsm *a, const void *const *blobs, const uint64_t *blob_caps
     hipLaunchKernelGGL(k_asm_copy, dim3(kCopyBlocks), dim3(256), 0, st, a->S, (uint8_t *)out);
     ASM_TRY(a, hipGetLastError());
     ASM_TRY(a, hipEventRecord(a->done, st));
+    a->ran = true;
+    a->unsettled = false;
     return ST_OK;
 }
 

@@ -120,6 +120,7 @@ struct HydAmdContext {
     int best_register_mode = 2;     /* best mode that passed the bit-exactness self-test */
     int curve_gathers = 0;          /* hydamd_set_curve_gathers: 0 by the last frame's density, 1 always (round 4), 2 never */
     uint64_t published_pixels = 0;  /* pixels of the frame whose section total k_publish wrote last */
+    uint64_t seen_bytes = 0, seen_pixels = 0; /* HF section bytes and pixels of the last frame hydamd_sync waited for: ONE frame's pair (curve-gather choice) */
     int register_luts_ok = 0;
     int rans_lanes = 0;             /* entropy-stage form: 0 wave per group (form 4), non-zero lane per group (form 5, also what 6 asks for; float frames still take form 4) */
     uint32_t tok_cap = HYDK_DEFAULT_TOKEN_CAP; /* token records per group the arrays below hold */
@@ -999,9 +1000,20 @@ int hydamd_uses_register_luts(HydAmdContext *ctx) { return ctx && ctx->use_luts 
 
 int hydamd_xyb_mode(HydAmdContext *ctx) { return ctx ? ctx->use_luts : -1; }
 
+/* an LF group's descriptor names the transform kernel variant of the mode it was RECORDED under (job.use_luts); the launch
+ * picks its variant from the context's mode at launch time: a mode change in between would leave the group to no kernel */
+static bool recorded_but_not_transformed(const HydAmdContext *ctx) {
+    for (int i = ctx->transformed; i < ctx->max_slots; i++)
+        if (ctx->h_jobs[i].width)
+            return true;
+    return false;
+}
+
 int hydamd_force_luts(HydAmdContext *ctx, int use_luts) {
     if (!ctx)
         return ST_API_ERROR;
+    if (recorded_but_not_transformed(ctx))
+        return fail(ctx, ST_API_ERROR, "the XYB mode cannot change between recording an LF group and its transform stage");
     if (!use_luts && !ctx->register_luts_ok)
         return fail(ctx, ST_INTERNAL_ERROR, "register LUT evaluation failed its self-test on this device");
     ctx->use_luts = use_luts ? 2 : ctx->best_register_mode;
@@ -1011,9 +1023,18 @@ int hydamd_force_luts(HydAmdContext *ctx, int use_luts) {
 int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode) {
     if (!ctx)
         return ST_API_ERROR;
+    if (recorded_but_not_transformed(ctx))
+        return fail(ctx, ST_API_ERROR, "the XYB mode cannot change between recording an LF group and its transform stage");
     if (mode < ctx->best_register_mode || mode > 2)
         return fail(ctx, ST_API_ERROR, "XYB mode not available (it must have passed the bit-exactness self-test)");
     ctx->use_luts = mode;
+    return ST_OK;
+}
+
+int hydamd_forget_content(HydAmdContext *ctx) {
+    if (!ctx)
+        return ST_API_ERROR;
+    ctx->seen_bytes = ctx->seen_pixels = 0;
     return ST_OK;
 }
 
@@ -1240,14 +1261,18 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
     ScopedTimer timer(ctx, HYDAMD_K_TRANSFORM);
     /* One of a pixel's six curves comes from the uploaded table through the texture path (HYDK_K1_GATHER: photo -9 %,
      * smooth -8 %) — unless the picture's pixels scatter over the whole table, where every lane's gather is its own L2
-     * miss (random noise +12 %).  No one tells the encoder what it is about to see; what it has is the frame this context
-     * published last (HF section bytes in pinned memory, possibly a frame behind, no wait): above 0.75 bytes per pixel —
-     * photographic content has 0.15, noise 2 — the next transform kernels evaluate all six curves in registers (modes 3, 4). */
+     * miss (random noise +12 %).  No one tells the encoder what it is about to see; what it has is the last frame of this
+     * context that hydamd_sync waited for — section bytes and pixel count snapshotted TOGETHER there (until round 5 the pinned
+     * total was read here unsynchronised, possibly a frame behind, against a pixel count that could belong to another frame:
+     * bit-exact either way, but which kernel ran was timing-dependent): above 0.75 bytes per pixel — photographic content
+     * has 0.15, noise 2 — the next transform kernels evaluate all six curves in registers (modes 3, 4).  A loop that never
+     * waits between frames keeps the choice of its last wait; hydamd_forget_content clears it (a parked context reused for
+     * another image). */
     int xmode = ctx->use_luts;
     if (xmode < 2) {
         bool dense = ctx->curve_gathers == 2;
-        if (ctx->curve_gathers == 0 && ctx->published_pixels)
-            dense = (double)*ctx->h_total_pinned > 0.75 * (double)ctx->published_pixels;
+        if (ctx->curve_gathers == 0 && ctx->seen_pixels)
+            dense = (double)ctx->seen_bytes > 0.75 * (double)ctx->seen_pixels;
         if (dense)
             xmode += 3;
     }
@@ -1565,6 +1590,62 @@ int hydamd_alphabet_floor_from_peers(HydAmdContext *ctx, int npeers, HydAmdConte
     HIP_TRY(ctx, hipGetLastError());
     ctx->alpha_floor_dev = ctx->peer_floor;
     return ST_OK;
+}
+
+/* What the floor kernel read through peer access against what the peers' own devices hold: the host copies every peer's
+ * per-LF-group maxima from ITS device (no peer read involved) and the floor ctx's table kernel was given from ctx's, and
+ * compares.  Waits for ctx's and the peers' frames.  *ok = 1: the peer read saw what the owners wrote. */
+int hydamd_verify_floor(HydAmdContext *ctx, int npeers, HydAmdContext *const *peers, int *ok) {
+    if (!ctx || !ok || npeers < 1 || npeers > HYDAMD_MAX_PEERS || !peers)
+        return ctx ? fail(ctx, ST_API_ERROR, "bad peer list") : ST_API_ERROR;
+    if (!ctx->peer_floor || ctx->alpha_floor_dev != ctx->peer_floor)
+        return fail(ctx, ST_API_ERROR, "no floor from peers to verify: hydamd_alphabet_floor_from_peers first");
+    uint32_t want = 0;
+    for (int p = 0; p < npeers; p++) {
+        HydAmdContext *o = peers[p];
+        if (!o || o == ctx || o->transformed < 1)
+            return fail(ctx, ST_API_ERROR, "bad peer");
+        HIP_TRY(o, hipSetDevice(o->device));
+        const int st = wait_for_frame(o); /* (the maxima of a frame that outgrew its token arrays are rewritten by its rerun) */
+        if (st != ST_OK)
+            return st;
+        uint32_t m[HYDAMD_MAX_LF_GROUPS];
+        const int n = o->transformed < HYDAMD_MAX_LF_GROUPS ? o->transformed : HYDAMD_MAX_LF_GROUPS;
+        HIP_TRY(o, hipMemcpy(m, o->alpha_max, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++)
+            want = m[i] > want ? m[i] : want;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t got = 0;
+    HIP_TRY(ctx, hipMemcpy(&got, ctx->peer_floor, sizeof(got), hipMemcpyDeviceToHost));
+#ifdef HYD_TEST_HOOKS
+    if (const char *e = getenv("HYDAMD_TEST_CORRUPT_PEER_FLOOR")) /* test hook: the floor as a stale peer read would leave it */
+        if (*e && *e != '0')
+            got ^= 1u;
+#endif
+    *ok = got == want;
+    return ST_OK;
+}
+
+/* Run the current frame's stages again from the job descriptors the context still holds (what hydamd_sync does by itself
+ * for a frame that outgrew its buffers) — for a caller that changed an input of the closing stage after enqueuing it: the
+ * drop-in API's through-the-host fallback gives a shard its alphabet floor as a host value when the peer read of it
+ * cannot be trusted.  Waits for the stream first; hydamd_sync afterwards as for any frame. */
+int hydamd_replay_frame(HydAmdContext *ctx) {
+    if (!ctx)
+        return ST_API_ERROR;
+    if (ctx->slots_per_frame)
+        return fail(ctx, ST_API_ERROR, "a batch of frames is not replayed");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int st = join_lf(ctx, 0);
+    if (st == ST_OK)
+        st = wait_for_frame(ctx);
+    if (st != ST_OK)
+        return st;
+    if (ctx->lf_stream)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->lf_stream));
+    return replay_frame(ctx);
 }
 
 /* Can every device of the list read every other one's memory?  hyd_send_tile asks BEFORE it deals a frame out to several
@@ -2214,6 +2295,10 @@ int hydamd_sync(HydAmdContext *ctx) {
     }
     drain_timers(ctx);
     ctx->h_total = *ctx->h_total_pinned;
+    if (ctx->slots_finished > 0 && ctx->published_pixels) { /* this frame's (or batch's) pair, for the next frame's curve-gather choice */
+        ctx->seen_bytes = ctx->h_total;
+        ctx->seen_pixels = ctx->published_pixels;
+    }
     ctx->h_lf_total = *ctx->h_lf_total_pinned;
     ctx->lf_results_valid = ctx->lf_on_device && !ctx->lf_need_gather && ctx->lf_slots > 0;
     ctx->h_status = *ctx->h_status_pinned;

@@ -1071,7 +1071,8 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
  * and residue-bit totals written where the single-workgroup form leaves them.  One workgroup per group; a part moves towards
  * lower addresses only, chunk by chunk (a chunk is read by all threads before any of it is written, and never reaches into
  * the chunk after it).  grid = 64 x LF groups of the launch. */
-__global__ __launch_bounds__(kThreads) void k_join_parts(const HydkLfJob *__restrict__ jobs, const uint2 *part_info, int plog) {
+__global__ __launch_bounds__(kThreads) void k_join_parts(const HydkLfJob *__restrict__ jobs, const uint2 *part_info, int plog,
+                                                         uint32_t *status) {
     const HydkLfJob job = jobs[blockIdx.x >> 6];
     const int g = blockIdx.x & 63;
     if (g >= job.gcols * job.grows)
@@ -1080,9 +1081,21 @@ __global__ __launch_bounds__(kThreads) void k_join_parts(const HydkLfJob *__rest
      * 8-byte records by an earlier float frame (job.rec_bytes is the group PITCH's unit, not this group's record size) */
     const uint32_t parts = 1u << plog, room = job.tok_cap >> plog, wpr = job.fmt == HYDK_FMT_F32 ? 2u : 1u; /* 32-bit words per record */
     uint32_t *const base = (uint32_t *)((char *)job.tokens + (size_t)g * job.tok_cap * job.rec_bytes);
-    uint32_t total = part_info[(size_t)blockIdx.x * parts].x, rbits = part_info[(size_t)blockIdx.x * parts].y;
+    /* a part's count is a COPY LENGTH here: one that no transform workgroup wrote (the slot's descriptor named a kernel
+     * variant the launch did not contain — a host bug) or that exceeds the part's share must not move memory */
+    bool bogus = false;
+    uint2 p0 = part_info[(size_t)blockIdx.x * parts];
+    if (p0.x > room) {
+        p0 = uint2{0u, 0u};
+        bogus = true;
+    }
+    uint32_t total = p0.x, rbits = p0.y;
     for (uint32_t q = 1; q < parts; q++) {
-        const uint2 pi = part_info[(size_t)blockIdx.x * parts + q];
+        uint2 pi = part_info[(size_t)blockIdx.x * parts + q];
+        if (pi.x > room) {
+            pi = uint2{0u, 0u};
+            bogus = true;
+        }
         const uint32_t *src = base + (size_t)q * room * wpr;
         uint32_t *dst = base + (size_t)total * wpr;
         const uint32_t words = pi.x * wpr;
@@ -1108,8 +1121,10 @@ __global__ __launch_bounds__(kThreads) void k_join_parts(const HydkLfJob *__rest
         rbits += pi.y;
     }
     if (threadIdx.x == 0) {
-        job.sym_count[g] = total;
-        job.rbits_total[g] = rbits;
+        job.sym_count[g] = bogus ? 0u : total;
+        job.rbits_total[g] = bogus ? 0u : rbits;
+        if (bogus)
+            atomicOr(status, HYDK_STATUS_INCONSISTENT);
     }
 }
 
@@ -2403,7 +2418,7 @@ hipError_t launch_transform(const HydkLfJob *d_jobs, int num_slots, unsigned fmt
 #undef HYDK_LAUNCH_K1_MODES
 #undef HYDK_LAUNCH_K1
     if (plog)
-        hipLaunchKernelGGL(k_join_parts, dim3(num_slots * HYDK_GROUPS_PER_LFG), block, 0, stream, d_jobs, part_info, plog);
+        hipLaunchKernelGGL(k_join_parts, dim3(num_slots * HYDK_GROUPS_PER_LFG), block, 0, stream, d_jobs, part_info, plog, status);
     return hipGetLastError();
 }
 

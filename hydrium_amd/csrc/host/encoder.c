@@ -110,12 +110,14 @@ struct HYDEncoder {
     /* which device this encoder's single-device work runs on (taken in turn from the device list at the first tile), and,
      * for a one-frame image dealt to several devices: shard d owns the tiles sent first_slot[d] .. first_slot[d + 1] - 1 */
     int home_device;
+    int home_index; /* its place in the device list: a sharded frame's shard d runs on list entry (home_index + d) mod count */
     int have_home;
     int shards; /* 0: not decided yet; 1: everything on e->dev; > 1: multi[] */
     struct Shard {
         HydAmdContext *dev;
         size_t first_slot, slots;
         int failed;
+        int entry; /* place in the device list */
     } multi[HYD_MAX_DEVICES];
     int pipe_depth; /* 0: tile frames are coded synchronously through e->dev */
     int pipe_request; /* hydamd_set_tile_pipeline: frames in flight this encoder asks for; 0 = HYDAMD_TILE_PIPELINE, else 1 */
@@ -601,6 +603,7 @@ static HydAmdContext *ctx_acquire(int device, size_t slots, int linear, int *sta
         }
     pthread_mutex_unlock(&g_ctx_lock);
     if (c) {
+        (void)hydamd_forget_content(c); /* the density of whatever image it coded last says nothing about the next one */
         *status = HYD_OK;
         return c;
     }
@@ -1161,16 +1164,27 @@ static int finish_frame(HYDEncoder *e, const HydFrameShape *shape) {
 
 /* ---- one frame on several devices (SURVEY 8(e) behind the C boundary) ----
  * hands the shards' contexts back; e->dev was only an alias of one of them */
-/* HYDAMD_VERIFY_PEERS=1: every sharded frame's peer reads are checked (hydamd_verify_enqueue): the owning device and the
- * assembling device sum every shard's view; a difference fails the frame with the device pair named */
-static int verify_peers_on(void) {
-    static int on = -1;
-    if (on < 0) {
+/* A sharded frame's shards meet through PEER READS — the alphabet floor (hydamd_alphabet_floor_from_peers) and the blobs
+ * the assembling device reads in place — whose visibility rests on a system-scope release event and the reading GPU's L2
+ * invalidate at kernel start: reasoning until a node has run it.  So the path checks itself at first use,
+ * the way the register LUT evaluation does: the FIRST sharded frame of the process over each (assembling entry, owning
+ * entry) pair of the device list is verified — the floor against a host copy of the owners' maxima (hydamd_verify_floor),
+ * every shard's view by a checksum on the owning and on the assembling device (hydamd_verify_enqueue) — and a pair that
+ * passes is latched (cost once: ~4 ms for a 16384^2 frame).  A pair that FAILS: one line on stderr, that frame is finished
+ * through host memory instead (finish_frame_through_host: same bytes, no peer read), and from then on the process keeps
+ * every frame on one device.  HYDAMD_VERIFY_PEERS=1: every sharded frame is verified and a mismatch is an error that
+ * names the device pair; =0: never. */
+enum { VERIFY_NEVER = 0, VERIFY_ALWAYS = 1, VERIFY_FIRST_USE = 2 };
+static int verify_peers_mode(void) {
+    static int mode = -1;
+    if (mode < 0) {
         const char *v = getenv("HYDAMD_VERIFY_PEERS");
-        on = v && *v && *v != '0';
+        mode = !v || !*v ? VERIFY_FIRST_USE : *v == '0' ? VERIFY_NEVER : VERIFY_ALWAYS;
     }
-    return on;
+    return mode;
 }
+static unsigned char g_pair_ok[HYD_MAX_DEVICES][HYD_MAX_DEVICES]; /* [assembling list entry][owning list entry], under g_ctx_lock */
+static int g_peer_reads_bad;                                       /* a first-use verification failed: no more sharded frames */
 
 static void multi_release(HYDEncoder *e) {
     if (e->shards > 1) {
@@ -1185,11 +1199,103 @@ static void multi_release(HYDEncoder *e) {
     e->shards = 0;
 }
 
+/* A sharded frame finished WITHOUT a peer read (the first-use verification of this frame's peer reads failed): every shard
+ * gets its alphabet floor as a host value — the maximum over the earlier shards' per-LF-group maxima, each copied by the
+ * host from its own device — and runs its stages again (hydamd_replay_frame); every shard's tables, section sizes, LF
+ * streams and HF sections are read back from ITS device, and the frame is put together by the host's own writers
+ * (assemble_frame), the sections in one piece per shard.  One GPU's rate at best; the reference's bytes. */
+static int finish_frame_through_host(HYDEncoder *e, const HydFrameShape *shape, HydAmdContext *const *ctxs) {
+    const int N = e->shards;
+    const size_t n = shape->lfg_count;
+    int ret = 0;
+    unsigned max_alphabet = 0;
+    uint32_t floor_so_far = 0;
+    LfgResult *res = calloc(n, sizeof(LfgResult));
+    HydAmdLfInfo *lf_info = malloc(n * sizeof(HydAmdLfInfo));
+    uint8_t *lf_blob[HYD_MAX_DEVICES] = {0}, *hf[HYD_MAX_DEVICES] = {0};
+    size_t hf_len[HYD_MAX_DEVICES] = {0};
+    const uint8_t *seg_ptr[HYD_MAX_DEVICES];
+    double t0 = now_ms();
+    if (!res || !lf_info) {
+        ret = FAIL(e, HYD_NOMEM, "out of memory");
+        goto done;
+    }
+    for (int d = 0; d < N && !ret; d++) {
+        HydAmdContext *c = ctxs[d];
+        const int slots = (int)e->multi[d].slots;
+        e->dev = c;
+        if (d > 0) { /* the running maximum of entropy.c:459-460 over everything sent before this shard, as a host value */
+            if ((ret = hydamd_set_alphabet_floor_device(c, NULL)) != 0 || (ret = hydamd_set_alphabet_floor(c, floor_so_far)) != 0 ||
+                (ret = hydamd_replay_frame(c)) != 0)
+                break;
+        }
+        if ((ret = hydamd_sync(c)) != 0)
+            break;
+        for (int i = 0; i < slots && !ret; i++) {
+            uint32_t m = 0;
+            ret = hydamd_read_alphabet_max(c, i, &m);
+            floor_so_far = m > floor_so_far ? m : floor_so_far;
+        }
+        if (ret)
+            break;
+        LfgResult *r = res + e->multi[d].first_slot;
+        HydAmdLfInfo *li = lf_info + e->multi[d].first_slot;
+        const size_t lf_len = hydamd_lf_payload_size(c);
+        lf_blob[d] = malloc(lf_len ? lf_len : 1);
+        hf_len[d] = hydamd_payload_size(c);
+        hf[d] = malloc(hf_len[d] ? hf_len[d] : 1);
+        if (!lf_blob[d] || !hf[d]) {
+            ret = FAIL(e, HYD_NOMEM, "out of memory");
+            goto done;
+        }
+        if ((ret = hydamd_read_lf_streams(c, 0, slots, li)) != 0 || (ret = hydamd_read_lf_payload(c, lf_blob[d], lf_len)) != 0 ||
+            (ret = hydamd_read_payload(c, hf[d], hf_len[d])) != 0)
+            break;
+        for (int i = 0; i < slots && !ret; i++) {
+            uint32_t log_alpha = 0, running = 0;
+            if ((size_t)li[i].offset + (((size_t)li[i].bit_count + 7) >> 3) > lf_len) {
+                ret = HYD_INTERNAL_ERROR;
+                break;
+            }
+            memcpy(r[i].lf_lengths, li[i].lengths, HYD_LF_CODES);
+            r[i].lf_alphabet = li[i].alphabet;
+            r[i].lf_run_pairs = li[i].run_pairs;
+            r[i].lf_bit_count = li[i].bit_count;
+            r[i].lf_bits = lf_blob[d] + li[i].offset; /* borrowed from lf_blob[d] */
+            if ((ret = hydamd_read_tables(c, i, r[i].freq, r[i].alphabet, &log_alpha, &running)) == 0)
+                ret = hydamd_read_sections(c, i, r[i].bits, NULL);
+            if (running > max_alphabet)
+                max_alphabet = running;
+        }
+        seg_ptr[d] = hf[d];
+    }
+    if (ret) {
+        ret = ret == HYD_NOMEM ? ret : device_fail(e, ret);
+        goto done;
+    }
+    TRACE("every shard again, floors and results through the host", t0);
+    t0 = now_ms();
+    {
+        const PayloadSegments segs = {(size_t)N, seg_ptr, hf_len};
+        ret = assemble_frame(e, shape, res, max_alphabet, NULL, 0, NULL, &segs);
+    }
+    TRACE("assemble frame (host)", t0);
+done:
+    for (int d = 0; d < N; d++) {
+        free(lf_blob[d]);
+        free(hf[d]);
+    }
+    free(lf_info);
+    free(res);
+    return ret;
+}
+
 /* The closing stage of a frame whose LF groups sit on several devices' contexts (shard d: tiles first_slot[d] ... in send
  * order).  Per device what the reference does per LF group (encoder.c:928-957), with two crossings, both device-side: the
  * running alphabet maximum (hydamd_alphabet_floor_from_peers: a peer read behind the earlier shards' transform kernels)
- * and the frame itself, which the first shard's GPU assembles from every shard's blob — read in place over xGMI
- * (hydamd_wait_for + peer access); nothing of the frame passes through host memory before the finished file. */
+ * and the frame itself, which the first shard's GPU — the encoder's home device — assembles from every shard's blob, read
+ * in place over xGMI (hydamd_wait_for + peer access); nothing of the frame passes through host memory before the
+ * finished file. */
 static int finish_frame_multi(HYDEncoder *e, const HydFrameShape *shape) {
     const int N = e->shards;
     const size_t n = shape->lfg_count;
@@ -1200,6 +1306,20 @@ static int finish_frame_multi(HYDEncoder *e, const HydFrameShape *shape) {
         ctxs[d] = e->multi[d].dev;
         if (!ctxs[d])
             return FAIL(e, HYD_INTERNAL_ERROR, "a shard of this frame never received a tile");
+    }
+    /* which of this frame's peer reads are checked: all of them (HYDAMD_VERIFY_PEERS=1), or those of a (reader, owner)
+     * pair of list entries no earlier frame of the process has verified */
+    const int mode = verify_peers_mode();
+    int check_view[HYD_MAX_DEVICES] = {0}, check_floor[HYD_MAX_DEVICES] = {0}, checking = 0;
+    if (mode != VERIFY_NEVER) {
+        pthread_mutex_lock(&g_ctx_lock);
+        for (int d = 1; d < N; d++) {
+            check_view[d] = mode == VERIFY_ALWAYS || !g_pair_ok[e->multi[0].entry][e->multi[d].entry];
+            for (int p = 0; p < d; p++) /* shard d's floor kernel reads shards 0 .. d-1 */
+                check_floor[d] |= mode == VERIFY_ALWAYS || !g_pair_ok[e->multi[d].entry][e->multi[p].entry];
+            checking |= check_view[d] | check_floor[d];
+        }
+        pthread_mutex_unlock(&g_ctx_lock);
     }
     for (int d = 0; d < N; d++) { /* whatever of the transform stage the tiles' own calls did not enqueue */
         e->dev = ctxs[d];
@@ -1231,7 +1351,10 @@ static int finish_frame_multi(HYDEncoder *e, const HydFrameShape *shape) {
     size_t out_cap = 4096 * n + (256u << 10);
     for (int d = 0; d < N; d++)
         out_cap += hydamd_blob_bound(ctxs[d], (int)e->multi[d].slots);
-    for (int attempt = 0; attempt < 4; attempt++) {
+    unsigned reruns[HYD_MAX_DEVICES];
+    for (int d = 0; d < N; d++)
+        reruns[d] = hydamd_overflow_reruns(ctxs[d]);
+    for (int attempt = 0; attempt < 4 + 2 * N; attempt++) {
         const void *blob[HYD_MAX_DEVICES];
         size_t cap[HYD_MAX_DEVICES], size = 0;
         for (int d = 0; d < N; d++) {
@@ -1243,8 +1366,8 @@ static int finish_frame_multi(HYDEncoder *e, const HydFrameShape *shape) {
         for (int d = 1; d < N; d++) /* the assembling GPU's stream waits for the other shards' exports and may read their memory */
             if ((ret = hydamd_wait_for(ctxs[0], ctxs[d])) != 0)
                 return device_fail(e, ret);
-        if (verify_peers_on()) /* every shard's view summed where it was written and where it is about to be read */
-            for (int d = 1; d < N; d++) {
+        for (int d = 1; d < N; d++) /* a shard's view summed where it was written and where it is about to be read */
+            if (check_view[d]) {
                 e->dev = ctxs[d];
                 if ((ret = hydamd_verify_enqueue(ctxs[d], ctxs[d], (int)e->multi[d].slots, 0)) != 0)
                     return device_fail(e, ret);
@@ -1261,8 +1384,26 @@ static int finish_frame_multi(HYDEncoder *e, const HydFrameShape *shape) {
             if ((ret = hydamd_sync(ctxs[d])) != 0)
                 return device_fail(e, ret);
         }
+        /* a shard that reran its frame had left INCOMPLETE alphabet maxima the first time (a group that runs out of token
+         * space stops counting): the later shards read their floor from those.  They read it again and run again. */
+        int stale_from = 0;
+        for (int d = 0; d < N; d++) {
+            const unsigned now = hydamd_overflow_reruns(ctxs[d]);
+            if (now != reruns[d] && !stale_from && d + 1 < N)
+                stale_from = d + 1;
+            reruns[d] = now;
+        }
+        if (stale_from) {
+            for (int d = stale_from; d < N; d++) {
+                e->dev = ctxs[d];
+                if ((ret = hydamd_alphabet_floor_from_peers(ctxs[d], d, ctxs)) != 0 || (ret = hydamd_replay_frame(ctxs[d])) != 0)
+                    return device_fail(e, ret);
+            }
+            continue;
+        }
         TRACE("GPU hot path on every device + assembly", t0);
         t0 = now_ms();
+        int asm_failed = 0;
         ret = hydamd_assembler_result(as, &size);
         if (ret) {
             const char *m = hydamd_assembler_error(as);
@@ -1274,11 +1415,27 @@ static int finish_frame_multi(HYDEncoder *e, const HydFrameShape *shape) {
             }
             if (m && strstr(m, "NaN"))
                 return FAIL(e, HYD_API_ERROR, "Invalid NaN Float");
-            mark_device_failed(e);
-            return FAIL(e, ret < HYD_ERROR_START ? ret : HYD_INTERNAL_ERROR, "GPU frame assembly failed");
+            if (checking && mode == VERIFY_FIRST_USE) /* an assembler that read garbage through a bad peer mapping: let the checks decide */
+                asm_failed = 1;
+            else {
+                mark_device_failed(e);
+                return FAIL(e, ret < HYD_ERROR_START ? ret : HYD_INTERNAL_ERROR, "GPU frame assembly failed");
+            }
         }
-        if (verify_peers_on())
-            for (int d = 1; d < N; d++) {
+        int bad_reader = -1, bad_owner = -1, bad_shard = -1;
+        const char *bad_what = "";
+        for (int d = 1; d < N && bad_shard < 0; d++) {
+            if (check_floor[d]) {
+                int ok = 0;
+                e->dev = ctxs[d];
+                if ((ret = hydamd_verify_floor(ctxs[d], d, ctxs, &ok)) != 0)
+                    return device_fail(e, ret);
+                if (!ok) {
+                    bad_reader = d, bad_owner = 0, bad_shard = d, bad_what = "alphabet floor";
+                    break;
+                }
+            }
+            if (check_view[d]) {
                 unsigned long long written = 0, seen = 0;
                 e->dev = ctxs[d];
                 if ((ret = hydamd_verify_read(ctxs[d], 0, &written)) != 0)
@@ -1286,13 +1443,42 @@ static int finish_frame_multi(HYDEncoder *e, const HydFrameShape *shape) {
                 e->dev = ctxs[0];
                 if ((ret = hydamd_verify_read(ctxs[0], d, &seen)) != 0)
                     return device_fail(e, ret);
-                if (written != seen) {
-                    mark_device_failed(e);
-                    snprintf(e->verify_msg, sizeof(e->verify_msg), "peer read mismatch: device %d did not see what device %d wrote (shard %d)",
-                             hydamd_context_device(ctxs[0]), hydamd_context_device(ctxs[d]), d);
-                    return FAIL(e, HYD_INTERNAL_ERROR, e->verify_msg);
-                }
+                if (written != seen)
+                    bad_reader = 0, bad_owner = d, bad_shard = d, bad_what = "frame view";
             }
+        }
+        e->dev = ctxs[0];
+        if (bad_shard >= 0) {
+            snprintf(e->verify_msg, sizeof(e->verify_msg), "peer read mismatch: device %d did not see what device %d wrote (shard %d, %s)",
+                     hydamd_context_device(ctxs[bad_reader]), hydamd_context_device(ctxs[bad_owner]), bad_shard, bad_what);
+            if (mode == VERIFY_ALWAYS) {
+                mark_device_failed(e);
+                return FAIL(e, HYD_INTERNAL_ERROR, e->verify_msg);
+            }
+            pthread_mutex_lock(&g_ctx_lock);
+            const int first = !g_peer_reads_bad;
+            g_peer_reads_bad = 1;
+            pthread_mutex_unlock(&g_ctx_lock);
+            if (first || trace_on())
+                fprintf(stderr, "[hydrium] %s: this frame is finished through host memory, later frames stay on one device\n", e->verify_msg);
+            return finish_frame_through_host(e, shape, ctxs);
+        }
+        if (checking) { /* every peer read of this frame was seen to return what its owner wrote: these pairs are trusted from here on */
+            pthread_mutex_lock(&g_ctx_lock);
+            for (int d = 1; d < N; d++) {
+                if (check_view[d])
+                    g_pair_ok[e->multi[0].entry][e->multi[d].entry] = 1;
+                for (int p = 0; p < d && check_floor[d]; p++)
+                    g_pair_ok[e->multi[d].entry][e->multi[p].entry] = 1;
+            }
+            pthread_mutex_unlock(&g_ctx_lock);
+            TRACE("peer reads verified (first use of these device pairs)", t0);
+            t0 = now_ms();
+        }
+        if (asm_failed) { /* the peer reads were fine: the assembly failed for a reason of its own */
+            mark_device_failed(e);
+            return FAIL(e, HYD_INTERNAL_ERROR, "GPU frame assembly failed");
+        }
         uint8_t *dst = hb_extend(&e->stream, size);
         if (!dst)
             return FAIL(e, HYD_NOMEM, "out of memory");
@@ -1396,15 +1582,25 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
     device_list_init();
     if (!e->have_home) { /* encoders take the devices in turn */
         pthread_mutex_lock(&g_ctx_lock);
-        e->home_device = g_devices[g_encoder_seq++ % (unsigned long)g_device_count];
+        e->home_index = (int)(g_encoder_seq++ % (unsigned long)g_device_count);
+        e->home_device = g_devices[e->home_index];
         pthread_mutex_unlock(&g_ctx_lock);
         e->have_home = 1;
     }
     if (!e->shards) {
         const size_t n = e->lfg_per_frame;
         const int by_device = g_device_count, by_size = (int)(n / 2 < HYD_MAX_DEVICES ? n / 2 : HYD_MAX_DEVICES);
-        e->shards = e->one_frame && by_device > 1 && n >= (size_t)g_shard_min && !host_assembly_forced() ? (by_device < by_size ? by_device : by_size) : 1;
-        if (e->shards > 1 && !hydamd_peers_reachable(g_devices, e->shards)) {
+        pthread_mutex_lock(&g_ctx_lock);
+        const int peers_bad = g_peer_reads_bad; /* a first-use verification of the peer reads failed earlier in this process */
+        pthread_mutex_unlock(&g_ctx_lock);
+        e->shards = e->one_frame && by_device > 1 && n >= (size_t)g_shard_min && !host_assembly_forced() && !peers_bad ? (by_device < by_size ? by_device : by_size) : 1;
+        /* shard d runs on list entry (home + d) mod count: the first shard — whose GPU also assembles the frame and sends it
+         * to the host — is the encoder's home device, which encoders take in turn, so concurrent sharded encoders do not all
+         * assemble on the first GPU of the list */
+        int devs[HYD_MAX_DEVICES];
+        for (int d = 0; d < e->shards; d++)
+            devs[d] = g_devices[(e->home_index + d) % g_device_count];
+        if (e->shards > 1 && !hydamd_peers_reachable(devs, e->shards)) {
             /* a frame's shards meet through peer reads (finish_frame_multi): asked HERE, before the first tile is uploaded,
              * not when the last one arrives.  Without peer access between all of the devices the frame stays on this
              * encoder's home device (same bytes, one GPU's rate) */
@@ -1418,7 +1614,11 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
         for (int d = 0; d < e->shards && e->shards > 1; d++) {
             e->multi[d].first_slot = (size_t)d * n / (size_t)e->shards;
             e->multi[d].slots = (size_t)(d + 1) * n / (size_t)e->shards - e->multi[d].first_slot;
+            e->multi[d].entry = (e->home_index + d) % g_device_count;
         }
+        if (e->shards > 1 && trace_on())
+            fprintf(stderr, "[hydrium] frame dealt to %d shards, list entries %d.. (mod %d), assembled on entry %d = device %d\n",
+                    e->shards, e->home_index, g_device_count, e->home_index, e->home_device);
     }
     if (e->shards > 1) { /* one frame dealt to several devices: this tile goes to the shard that owns its place in send order */
         const size_t slot = e->tiles_sent;
@@ -1431,7 +1631,7 @@ HYDRIUM_EXPORT HYDStatusCode hyd_send_tile(HYDEncoder *e, const void *const buff
         if (!sh->dev) {
             int st = 0;
             const double tc = now_ms();
-            sh->dev = ctx_acquire(g_devices[d], sh->slots, e->dev_linear, &st);
+            sh->dev = ctx_acquire(g_devices[sh->entry], sh->slots, e->dev_linear, &st);
             TRACE("acquire device context (shard)", tc);
             if (!sh->dev) {
                 const char *m = hydamd_error(NULL);

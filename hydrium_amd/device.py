@@ -138,6 +138,17 @@ def dll(path: Optional[str] = None):
         d.hydamd_assembler_result.argtypes = [vp, C.POINTER(sz)]
         d.hydamd_profile.argtypes = [vp, i]
         d.hydamd_profile_read.argtypes = [vp, vp, vp]
+        d.hydamd_multi_create.restype = vp
+        d.hydamd_multi_create.argtypes = [i, C.POINTER(i), C.POINTER(api.HYDImageMetadata), C.POINTER(i)]
+        d.hydamd_multi_destroy.argtypes = [vp]
+        d.hydamd_multi_error.restype = C.c_char_p
+        d.hydamd_multi_error.argtypes = [vp]
+        d.hydamd_multi_context.restype = vp
+        d.hydamd_multi_context.argtypes = [vp, i]
+        d.hydamd_multi_shard_lf_groups.argtypes = [vp, i, C.POINTER(sz), C.POINTER(sz)]
+        d.hydamd_encode_image_multi.argtypes = [vp, C.POINTER(vp), C.c_ssize_t, C.c_ssize_t, i, i]
+        d.hydamd_multi_result.argtypes = [vp, C.POINTER(sz)]
+        d.hydamd_multi_read.argtypes = [vp, vp, sz]
         if path is not None:
             return d
         _dll = d
@@ -601,6 +612,74 @@ class Assembler:
         n = C.c_size_t(0)
         self._ck(self.d.hydamd_assembler_result(self.h, C.byref(n)))
         return int(n.value)
+
+
+class MultiFrame:
+    """One device-resident frame on N devices of this process, composed in C (hydamd_multi_*, csrc/host/multi.c):
+    LF groups dealt in raster runs, floors by peer read, the file assembled on a shard of the caller's choice."""
+
+    def __init__(self, devices: Sequence[int], width: int, height: int, linear_light: int = 0):
+        self.d = dll()
+        md = api.HYDImageMetadata(width, height, int(linear_light), -1, -1)
+        arr = (C.c_int * len(devices))(*devices)
+        st = C.c_int(0)
+        self.h = self.d.hydamd_multi_create(len(devices), arr, C.byref(md), C.byref(st))
+        if not self.h:
+            raise DeviceError(st.value, "multi-device frame could not be created")
+        self.n, self.width, self.height = len(devices), width, height
+
+    def close(self):
+        if self.h:
+            self.d.hydamd_multi_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, code: int):
+        if code != 0:
+            raise DeviceError(code, (self.d.hydamd_multi_error(self.h) or b"").decode())
+
+    def shard_lf_groups(self, shard: int):
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self._ck(self.d.hydamd_multi_shard_lf_groups(self.h, shard, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def encode(self, origins, assembling_shard: int = 0):
+        """origins[d]: an interleaved (H, W, 3) torch tensor on shard d's device holding (at least) that shard's LF
+        groups at their place in the image — or an int: the device address pixel (0, 0) would have.  Asynchronous; the
+        tensors must stay alive until result()."""
+        ptrs, isz = [], None
+        for o in origins:
+            if hasattr(o, "data_ptr"):
+                isz = o.element_size()
+                b = o.data_ptr()
+            else:
+                b = int(o)
+            ptrs.append(b)
+        isz = isz or getattr(self, "sample_bytes", 1)
+        flat = []
+        for b in ptrs:
+            flat += [b, b + isz, b + 2 * isz]
+        arr = (C.c_void_p * len(flat))(*flat)
+        self._ck(self.d.hydamd_encode_image_multi(self.h, arr, 3 * self.width, 3, {1: 0, 2: 1, 4: 2}[isz], assembling_shard))
+
+    def result(self) -> int:
+        n = C.c_size_t(0)
+        self._ck(self.d.hydamd_multi_result(self.h, C.byref(n)))
+        return int(n.value)
+
+    def read(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        size = self.result()
+        buf = out if out is not None and out.nbytes >= size else np.empty(size, np.uint8)
+        self._ck(self.d.hydamd_multi_read(self.h, buf.ctypes.data, buf.nbytes))
+        return buf[:size]
+
+    def context_overflow_reruns(self, shard: int) -> int:
+        return int(self.d.hydamd_overflow_reruns(self.d.hydamd_multi_context(self.h, shard)))
 
 
 def decode_token_records(rec: np.ndarray):

@@ -90,6 +90,10 @@ HYDAMD_EXPORT int hydamd_set_xyb_mode(HydAmdContext *ctx, int mode);
  * of the frame this context finished last (more than 0.75 bytes of HF sections per pixel: registers); 1: always gather
  * (rounds 1-4); 2: never. */
 HYDAMD_EXPORT int hydamd_set_curve_gathers(HydAmdContext *ctx, int mode);
+/* The density the default choice goes by is that of the last frame hydamd_sync waited for on this context (bytes and pixels
+ * of ONE frame, taken together); hydamd_forget_content clears it — what the drop-in API does when it takes a parked context
+ * for another image. */
+HYDAMD_EXPORT int hydamd_forget_content(HydAmdContext *ctx);
 
 /* Form of the entropy (rANS) stage.  The recurrence is serial per group, so the forms trade the
  * latency of one frame against how much of the GPU the stage occupies while it runs:
@@ -275,6 +279,15 @@ HYDAMD_EXPORT int hydamd_peers_reachable(const int *devices, int n);
 HYDAMD_EXPORT int hydamd_verify_enqueue(HydAmdContext *reader, HydAmdContext *owner, int num_slots, int index);
 HYDAMD_EXPORT int hydamd_verify_read(HydAmdContext *reader, int index, unsigned long long *sum);
 HYDAMD_EXPORT int hydamd_alphabet_floor_from_peers(HydAmdContext *ctx, int npeers, HydAmdContext *const *peers);
+/* The other peer read of a sharded frame, checked the same way: *ok = 1 when the floor hydamd_alphabet_floor_from_peers left
+ * for ctx's table kernel equals the maximum over the peers' per-LF-group maxima as the HOST copies them from each peer's own
+ * device (no peer access involved).  Waits for the frames of ctx and of the peers. */
+HYDAMD_EXPORT int hydamd_verify_floor(HydAmdContext *ctx, int npeers, HydAmdContext *const *peers, int *ok);
+/* Enqueue the current frame's stages again from the job descriptors the context still holds (pixels stay borrowed), after
+ * waiting for what was enqueued before — for a caller that changed an input of the closing stage (hydamd_set_alphabet_floor,
+ * hydamd_set_alphabet_floor_device) after hydamd_finish_frame.  hyd_send_tile's through-the-host fallback uses it when a
+ * sharded frame's peer reads fail their first-use verification.  Not for batches. */
+HYDAMD_EXPORT int hydamd_replay_frame(HydAmdContext *ctx);
 
 /*
  * One self-describing byte string with everything a frame assembler needs from this context's LF
@@ -426,6 +439,39 @@ HYDAMD_EXPORT int hydamd_get_tile_pipeline(const HYDEncoder *encoder);
 HYDAMD_EXPORT int hydamd_profile(HydAmdContext *ctx, int enable);
 /* accumulated milliseconds and launch counts per kernel class since the last call; resets the counters */
 HYDAMD_EXPORT int hydamd_profile_read(HydAmdContext *ctx, double ms[HYDAMD_K_COUNT], uint64_t launches[HYDAMD_K_COUNT]);
+
+/*
+ * ONE frame whose pixels already sit in HBM, on N devices of ONE process (csrc/host/multi.c; the composition of the calls
+ * above that hyd_send_tile's multi-device scheduler makes for host tiles — reference libhydrium.c:172-203,
+ * encoder.c:928-957 — without the uploads, which bound that path at any N).  No collective library, no process group:
+ * LF groups dealt in raster runs (shard d: groups d * total / N .. (d + 1) * total / N - 1), the alphabet floor by peer
+ * read, every shard's blob a view, the assembling shard's GPU reading all of them in place (the other devices' over xGMI)
+ * and writing the finished FILE (header included) into its own memory.
+ *   hydamd_multi_create        contexts for the image's shape, one per entry of `devices` (an index may repeat: several
+ *                              shards on one GPU); HYD_INTERNAL_ERROR in *status when the devices cannot read each other.
+ *   hydamd_encode_image_multi  enqueue one frame; returns without waiting.  `src` holds three pointers per shard
+ *                              ([shard][channel]) in THAT shard's device memory: where pixel (0, 0) of the image would sit
+ *                              in the shard's buffer — only the pixels of the shard's own LF groups are read, so a slab of
+ *                              rows [y0, y1) passes slab - y0 * row_stride.  Strides in samples, sample_fmt as
+ *                              hyd_send_tile's.  `assembling_shard` picks the GPU that builds the file (rotate it per frame:
+ *                              the file's copy to the host then leaves through another GPU's link each time).
+ *   hydamd_multi_result        wait for the frame; reruns what a shard that outgrew its buffers invalidated (its own frame
+ *                              inside hydamd_sync, the later shards' floors and frames, the assembly).  *size = bytes of
+ *                              the file.  A peer read that fails its first-use verification (see HYDAMD_VERIFY_PEERS in
+ *                              INTEGRATION.md) is HYD_INTERNAL_ERROR with the device pair in hydamd_multi_error.
+ *   hydamd_multi_read          the file to host memory, one copy from the assembling device.
+ * One frame in flight per HydAmdMulti; keep several for a queue of frames (bench.py's shard_16k_inprocess leg keeps four).
+ */
+typedef struct HydAmdMulti HydAmdMulti;
+HYDAMD_EXPORT HydAmdMulti *hydamd_multi_create(int n, const int *devices, const HYDImageMetadata *md, int *status);
+HYDAMD_EXPORT void hydamd_multi_destroy(HydAmdMulti *m);
+HYDAMD_EXPORT const char *hydamd_multi_error(HydAmdMulti *m);
+HYDAMD_EXPORT HydAmdContext *hydamd_multi_context(HydAmdMulti *m, int shard);
+HYDAMD_EXPORT int hydamd_multi_shard_lf_groups(HydAmdMulti *m, int shard, size_t *first, size_t *count);
+HYDAMD_EXPORT int hydamd_encode_image_multi(HydAmdMulti *m, const void *const *src, ptrdiff_t row_stride, ptrdiff_t pixel_stride,
+                                            int sample_fmt, int assembling_shard);
+HYDAMD_EXPORT int hydamd_multi_result(HydAmdMulti *m, size_t *size);
+HYDAMD_EXPORT int hydamd_multi_read(HydAmdMulti *m, uint8_t *dst, size_t capacity);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k(unsigned *out, int iters, unsigned seed) {
     const int lane = threadIdx.x & 63;
     unsigned a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, a4 = a0 + 9, a5 = a0 ^ 77, a6 = a0 + 123, a7 = a0 * 11;
-    if (MODE == 0 || lane < 16) {
+    if (MODE == 0 || (MODE == 1 && lane < 16) || (MODE == 2 && lane < 32) || (MODE == 3 && (lane & 3) == 0)) {
         for (int i = 0; i < iters; i++) {
             // 8 independent integer chains: issue-bound, not latency-bound
             a0 = a0 * 0x10001u + 1u; a1 = a1 * 0x10003u + 3u; a2 = a2 * 0x10005u + 5u; a3 = a3 * 0x10007u + 7u;
@@ -55,6 +55,9 @@ int main() {
     float t0 = timeit([&] { hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u); });
     float t1 = timeit([&] { hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u); });
     printf("int mad, all 64 lanes : %.3f ms\nint mad, lanes 0-15   : %.3f ms  (ratio %.2f)\n", t0, t1, t0 / t1);
+    float t2 = timeit([&] { hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u); });
+    float t3 = timeit([&] { hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u); });
+    printf("int mad, lanes 0-31   : %.3f ms  (ratio %.2f)\nint mad, every 4th lane: %.3f ms  (ratio %.2f)\n", t2, t0 / t2, t3, t0 / t3);
     float f0 = timeit([&] { hipLaunchKernelGGL(kf<0>, dim3(blocks), dim3(256), 0, 0, outf, iters, 1.0f); });
     float f1 = timeit([&] { hipLaunchKernelGGL(kf<1>, dim3(blocks), dim3(256), 0, 0, outf, iters, 1.0f); });
     const double ops = (double)blocks * 256 * iters * 16;

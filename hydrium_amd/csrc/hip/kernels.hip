@@ -71,6 +71,17 @@ constexpr int kThreads = 256;
 #ifndef HYDK_CHAIN_PROBE
 #define HYDK_CHAIN_PROBE 0
 #endif
+/*   HYDK_LANE_STEP     the lane-form chain's step: 1 = round 5's (the renormalised state kept as two pieces B | slot & mask:
+ *                      13.5 vector instructions per symbol, one of them between the slot's arrival and the multiply);
+ *                      2 = round 6's (the refill decision carried in a scalar register pair, x = decision ? state >> 16 :
+ *                      state by ONE v_cndmask_sdwa: 11.5 vector instructions per symbol, two between arrival and multiply).
+ *                      What the chains cost the pipelined loop is the vector issue time they take from the ONE SIMD they
+ *                      share with transform wavefronts, times four (a transform workgroup spans the four SIMDs and moves
+ *                      at its slowest wavefront's pace; profiles/r06_chain_probes.txt): fewer instructions, not a shorter
+ *                      dependent path, is what the loop pays for. */
+#ifndef HYDK_LANE_STEP
+#define HYDK_LANE_STEP 2
+#endif
 #ifndef HYDK_CHAIN_PRIO
 #define HYDK_CHAIN_PRIO 3
 #endif
@@ -1738,6 +1749,22 @@ struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs
     "v_addc_co_u32 %[fl], vcc, %[fl], %[fl], vcc\n\t"                                                            \
     "s_waitcnt lgkmcnt(0)"
 #define HYDK_LANE_ASM_SDWA_SELECT "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+/* round 6's step (HYDK_LANE_STEP 2).  Between two steps of a round the walk carries A = (q + fix) << 12 (the state without
+ * its slot), sl = the slot (arriving from LDS) and rf = the NEXT symbol's refill decision as a lane mask in a scalar register
+ * pair (state' > thr' looks at bits 20.. only: A decides it, entropy.c:1092).  A step: st = A | sl (the state this symbol
+ * meets: also what is filed), x = rf ? st >> 16 : st, then the request of its slot; behind the request the repaired
+ * quotient, the new A, the next decision and its flag.  v_cndmask_b32_sdwa takes its condition from VCC only, so the pair
+ * is moved there by the scalar unit (no vector issue slot); v_cmp and v_addc in their 64-bit encodings name the pair. */
+#define HYDK_LANE2_TAKE                                                                                          \
+    "s_mov_b64 vcc, %[rf]\n\t"                                                                                   \
+    "v_or_b32 %[st], %[Ai], %[sl]\n\t"                                                                           \
+    "v_cndmask_b32_sdwa %[x], %[st], %[st], vcc " HYDK_LANE_ASM_SDWA_SELECT "\n\t"
+#define HYDK_LANE2_SHADOW                                                                                        \
+    "v_addc_co_u32 %[q], vcc, 0, %[q], vcc\n\t"                                                                  \
+    "v_lshlrev_b32 %[A], 12, %[q]\n\t"                                                                           \
+    "v_cmp_gt_u32_e64 %[rfn], %[A], %[thrn]\n\t"                                                                 \
+    "v_addc_co_u32_e64 %[fl], %[junk], %[fl], %[fl], %[rfn]\n\t"                                                 \
+    "s_waitcnt lgkmcnt(0)"
 
 template <int NC> /* NC: clusters per preset of the frame's clustering scheme (9 / 3 / 2 / 1): the tables' size in LDS */
 __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
@@ -1839,6 +1866,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
         state = (VALID) ? nstate : state;                                                                        \
     } while (0)
 
+#if HYDK_LANE_STEP == 1
 /* a round's first symbol (position 15): the state arrives in one piece */
 #define HYDK_LANE_STEP_HEAD(o, on)                                                                               \
     do {                                                                                                         \
@@ -1900,6 +1928,67 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
                      : "vcc");                                                                                   \
     } while (0)
 
+#else
+/* a round's first symbol (position 15): the state arrives in one piece */
+#define HYDK_LANE_STEP_HEAD(o, on)                                                                               \
+    do {                                                                                                         \
+        uint32_t x, q, t0, t1, sln;                                                                              \
+        unsigned long long rfn, junk;                                                                            \
+        asm volatile("v_cmp_gt_u32 vcc, %[st], %[thr]\n\t"                                                       \
+                     "v_cndmask_b32_sdwa %[x], %[st], %[st], vcc " HYDK_LANE_ASM_SDWA_SELECT "\n\t"              \
+                     "v_addc_co_u32 %[fl], vcc, %[fl], %[fl], vcc\n\t" HYDK_LANE_ASM_CORE HYDK_LANE2_SHADOW      \
+                     : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [A] "=&v"(A), \
+                       [rfn] "=&s"(rfn), [junk] "=&s"(junk), [fl] "+v"(fl)                                       \
+                     : [st] "v"(state), [thr] "v"(o.x), [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w), [thrn] "v"(on.x) \
+                     : "vcc");                                                                                   \
+        so = state; /* position 15 is odd: filed together with position 14's */                                  \
+        sl = sln;                                                                                                \
+        rf = rfn;                                                                                                \
+    } while (0)
+/* a symbol in the middle of a round */
+#define HYDK_LANE_STEP_BODY(o, on, pos)                                                                          \
+    do {                                                                                                         \
+        uint32_t x, q, t0, t1, sln, st, An;                                                                      \
+        unsigned long long rfn, junk;                                                                            \
+        if ((pos) & 1) {                                                                                         \
+            asm volatile(HYDK_LANE2_TAKE HYDK_LANE_ASM_CORE HYDK_LANE2_SHADOW                                    \
+                         : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
+                           [A] "=&v"(An), [rfn] "=&s"(rfn), [junk] "=&s"(junk), [fl] "+v"(fl)                    \
+                         : [sl] "v"(sl), [Ai] "v"(A), [rf] "s"(rf), [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w), \
+                           [thrn] "v"(on.x)                                                                      \
+                         : "vcc");                                                                               \
+            so = st;                                                                                             \
+        } else {                                                                                                 \
+            asm volatile(HYDK_LANE2_TAKE HYDK_LANE_ASM_CORE                                                      \
+                         "v_perm_b32 %[w], %[so], %[st], %[ksel]\n\t" HYDK_LANE2_SHADOW                          \
+                         : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
+                           [w] "=&v"(w16[(pos) >> 1]), [A] "=&v"(An), [rfn] "=&s"(rfn), [junk] "=&s"(junk), [fl] "+v"(fl) \
+                         : [sl] "v"(sl), [Ai] "v"(A), [rf] "s"(rf), [so] "v"(so), [ksel] "v"(ksel), [mg] "v"(o.y), \
+                           [nf] "v"(o.z), [tab] "v"(o.w), [thrn] "v"(on.x)                                       \
+                         : "vcc");                                                                               \
+        }                                                                                                        \
+        A = An;                                                                                                  \
+        rf = rfn;                                                                                                \
+        sl = sln;                                                                                                \
+    } while (0)
+/* a round's last symbol (position 0): the round ends with the state in one piece */
+#define HYDK_LANE_STEP_TAIL(o)                                                                                   \
+    do {                                                                                                         \
+        uint32_t x, q, t0, t1, sln, st, An;                                                                      \
+        asm volatile(HYDK_LANE2_TAKE HYDK_LANE_ASM_CORE                                                          \
+                     "v_perm_b32 %[w], %[so], %[st], %[ksel]\n\t"                                                \
+                     "v_addc_co_u32 %[q], vcc, 0, %[q], vcc\n\t"                                                 \
+                     "v_lshlrev_b32 %[A], 12, %[q]\n\t"                                                          \
+                     "s_waitcnt lgkmcnt(0)\n\t"                                                                  \
+                     "v_or_b32 %[state], %[A], %[sln]"                                                           \
+                     : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
+                       [w] "=&v"(w16[0]), [A] "=&v"(An), [state] "=&v"(state)                                    \
+                     : [sl] "v"(sl), [Ai] "v"(A), [rf] "s"(rf), [so] "v"(so), [ksel] "v"(ksel), [mg] "v"(o.y),    \
+                       [nf] "v"(o.z), [tab] "v"(o.w)                                                             \
+                     : "vcc");                                                                                   \
+    } while (0)
+#endif /* HYDK_LANE_STEP */
+
 /* one round = the 16 symbols of one 64-byte line of records.  The first round of a lane is the partial one (FIRST: only
  * positions below first_count count); it is peeled out of the loop and walks the plain way */
 #define HYDK_LANE_ROUND(FIRST)                                                                                   \
@@ -1929,6 +2018,8 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
             }                                                                                                    \
             __builtin_amdgcn_sched_barrier(0); /* (the scheduler would sink the requests back into the steps) */ \
             uint32_t A = 0, B = 0, sm = 0, sl = 0, so = 0; /* the walk's state between two steps of a round */   \
+            unsigned long long rf = 0; /* (HYDK_LANE_STEP 2) the next symbol's refill decision, a lane mask */   \
+            (void)B; (void)sm; (void)rf;                                                                         \
             if (FIRST) {                                                                                         \
                 _Pragma("unroll") for (int pos = 15; pos >= 8; pos--)                                            \
                     HYDK_LANE_STEP_COLD(ov[pos], pos, pos < first_count);                                        \

@@ -73,6 +73,8 @@ def one(name, frames=6, pipe=False):
         prof = ctx.profile_read()
         ms, n = prof["transform_tokenize"]
         res["k1_ms"] = round(ms / max(n, 1), 4)
+        ms, n = prof["rans_encode"]
+        res["chain_ms"] = round(ms / max(n, 1), 4)
         ctx.profile(False)
         lds, regs = ctx.transform_footprint(1)
         res["lds"], res["vgpr"] = lds, regs
@@ -99,7 +101,7 @@ def run(names, rounds, pipe):
                 continue
             d = json.loads(line[7:])
             rows[n].append(d)
-            print(f"round {r} {n:14s} K1 {d['k1_ms']:.4f} ms  md5 {d['md5']}  lds {d['lds']} vgpr {d['vgpr']}"
+            print(f"round {r} {n:14s} K1 {d['k1_ms']:.4f} ms  chains {d.get('chain_ms', 0):.4f} ms  md5 {d['md5']}  lds {d['lds']} vgpr {d['vgpr']}"
                   + (f"  pipelined {d['pipe_gpx']} Gpixel/s" if pipe else ""), flush=True)
     print("\nsummary (K1 alone, ms: min / mean over rounds)")
     ref = rows[names[0]][0]["md5"] if rows[names[0]] else None
@@ -107,7 +109,8 @@ def run(names, rounds, pipe):
         if not rows[n]:
             continue
         v = [d["k1_ms"] for d in rows[n]]
-        line = f"  {n:14s} {min(v):.4f} / {sum(v) / len(v):.4f}   bytes {'same' if rows[n][0]['md5'] == ref else 'DIFFER'}"
+        c = [d.get("chain_ms", 0.0) for d in rows[n]]
+        line = f"  {n:14s} {min(v):.4f} / {sum(v) / len(v):.4f}   chains {min(c):.4f}   bytes {'same' if rows[n][0]['md5'] == ref else 'DIFFER'}"
         if pipe:
             pv = [d["pipe_gpx"] for d in rows[n] if isinstance(d["pipe_gpx"], float)]
             if pv:

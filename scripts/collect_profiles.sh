@@ -136,6 +136,12 @@ run priorities txt bash -c '
 '
 fi
 
+# round 6's chain step against round 5's (kernels.hip HYDK_LANE_STEP): kernels alone, bytes, and the loop, alternating on one box
+#   python scripts/k1_variants.py --build ls1=-DHYDK_LANE_STEP=1 ls2=-DHYDK_LANE_STEP=2     (before the gpurun call)
+if want lane_step; then
+run lane_step txt bash -c 'echo "# HYDK_LANE_STEP 1 (round 5: 13.5 vector instructions per symbol) against 2 (round 6: 11.5); commit $(cat .commit 2>/dev/null)"; python scripts/k1_variants.py --run --rounds 3 --pipe ls1 ls2'
+fi
+
 # instruction cache: the transform kernel is 29.6 KB of code, the chain kernel 17 KB, the table kernel 23 KB (llvm-readelf -s)
 if want icache; then
 mkdir -p /tmp/pmc_ic

@@ -677,13 +677,19 @@ def content_row(args, kind, local):
     try:
         ext = [torch.cuda.ExternalStream(c.get_stream()) for c in ctxs]
         groups = [[img] * FPL for _ in ctxs]
-        for c in ctxs:
+        for k, c in enumerate(ctxs):
             c.set_rans_waves(args.rans_waves)
             c.set_lf_coder(2)
             c.encode_image_batch([img] * FPL) if FPL > 1 else c.encode_image_tensor(img)
+            if k == 0:
+                # the first context finds out what kind of content this queue holds: a frame that outgrows the default
+                # buffers (noise: 2.9 symbols per pixel) is rerun inside this wait; the others — idle so far — take the
+                # hint at their first frame (hydamd_begin_frame, round 6) instead of each finding out by itself
+                c.sync()
         for c in ctxs:
-            c.sync()  # (a frame that outgrows the default buffers — noise: 2.9 symbols per pixel — is rerun in here, once)
+            c.sync()
         row["overflow_reruns_first_frame"] = int(sum(c.overflow_reruns() for c in ctxs))
+        row["contexts_enlarged_ahead_of_their_first_frame"] = int(sum(c.grown_ahead() for c in ctxs))
         rate = loop_rate(ctxs, groups, ext, W, H, FPL, 4, 6)
         row["Mpixel/s"] = round(rate, 1)
         row["ms_per_frame_in_the_loop"] = round(W * H / rate / 1e3, 4)

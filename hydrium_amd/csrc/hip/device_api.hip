@@ -124,6 +124,8 @@ struct HydAmdContext {
     int register_luts_ok = 0;
     int rans_lanes = 0;             /* entropy-stage form: 0 wave per group (form 4), non-zero lane per group (form 5, also what 6 asks for; float frames still take form 4) */
     uint32_t tok_cap = HYDK_DEFAULT_TOKEN_CAP; /* token records per group the arrays below hold */
+    bool caps_forced = false;       /* HYDAMD_TOKEN_CAP / HYDAMD_PAYLOAD_CAP sized the arrays (tests): no growing ahead */
+    unsigned grown_ahead = 0;       /* times the arrays were enlarged before a frame because another context had outgrown the defaults */
     uint32_t rec_bytes = 4;         /* their record size: 4 until a float LF group is recorded, then 8 */
     uint32_t bit_pitch_words = 0;   /* words per group in bitbuf (0: not allocated yet) */
     int want_transform = 0, want_entropy = 0; /* what the caller asked for this frame: replayed if a buffer was too small */
@@ -732,6 +734,10 @@ void hydamd_destroy(HydAmdContext *ctx) {
 
 /* hard upper bound of a frame's packed sections for the current token capacity: per symbol one 16-bit
  * refill + the longest residue (30 bits float, 13 integer), per group state + preset + padding */
+/* HYDK_STATUS_TOKENS / _PAYLOAD: some context of this process ran a frame twice because that array's default size was too
+ * small (resolve_overflow); hydamd_begin_frame lets idle contexts enlarge theirs ahead of their next frame */
+static std::atomic<uint32_t> g_outgrown{0};
+
 static size_t payload_bound(const HydAmdContext *ctx) {
     const size_t per_group = ((size_t)ctx->tok_cap * (ctx->rec_bytes == 8 ? 46 : 29) + 64 + 7) / 8;
     return (size_t)ctx->max_slots * HYDK_GROUPS_PER_LFG * per_group;
@@ -854,13 +860,16 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
         const long v = atol(env);
         if (v >= 16 && v <= HYDK_TOKENS_PER_GROUP)
             ctx->tok_cap = (uint32_t)v & ~15u;
+        ctx->caps_forced = true;
     }
     {
         /* one byte per pixel of packed sections is 5 to 10 times what photographic content needs */
         size_t cap = slots * (size_t)2048 * 2048;
         if (const char *env = getenv("HYDAMD_PAYLOAD_CAP"))
-            if (atol(env) > 0)
+            if (atol(env) > 0) {
                 cap = (size_t)atol(env);
+                ctx->caps_forced = true;
+            }
         const size_t bound = payload_bound(ctx);
         const int st = alloc_frame_arrays(ctx, cap < bound ? cap : bound);
         if (st != ST_OK)
@@ -1086,6 +1095,25 @@ int hydamd_begin_frame(HydAmdContext *ctx, unsigned num_presets) {
     while ((1u << bits) < num_presets)
         bits++;
     ctx->preset_bits = bits; /* hyd_cllog2(num_presets), encoder.c:940 */
+    {
+        /* Another context of this process met content that outgrew the default arrays (noise: 2.9 symbols and 1.8 section
+         * bytes per pixel) and had to run its frame twice.  A queue of frames is of one kind as a rule: a context whose
+         * stream is idle right now takes the hard maxima BEFORE its frame instead of finding out by itself (busy: it keeps
+         * what it has — never a wait here; sizes forced through HYDAMD_TOKEN_CAP / HYDAMD_PAYLOAD_CAP stay as forced). */
+        const uint32_t seen = g_outgrown.load(std::memory_order_relaxed);
+        const bool tok = (seen & HYDK_STATUS_TOKENS) && ctx->tok_cap < HYDK_TOKENS_PER_GROUP;
+        const bool pay = (seen & HYDK_STATUS_PAYLOAD) && ctx->payload_cap < payload_bound(ctx);
+        if ((tok || pay) && !ctx->caps_forced && hipStreamQuery(ctx->stream) == hipSuccess &&
+            (!ctx->lf_stream || hipStreamQuery(ctx->lf_stream) == hipSuccess)) {
+            if (tok)
+                ctx->tok_cap = HYDK_TOKENS_PER_GROUP;
+            const int st = alloc_frame_arrays(ctx, pay ? payload_bound(ctx) : ctx->payload_cap);
+            if (st != ST_OK)
+                return st;
+            ctx->grown_ahead++;
+        }
+        (void)hipGetLastError(); /* (hipErrorNotReady of a busy stream is not an error) */
+    }
     ctx->results_valid = false;
     ctx->slots_finished = 0;
     ctx->slots_per_frame = 0;
@@ -1421,6 +1449,8 @@ static int resolve_overflow(HydAmdContext *ctx, uint32_t status, bool *again) {
     if (st != ST_OK)
         return st;
     ctx->overflow_reruns++;
+    if (!ctx->caps_forced) /* the process's other contexts take the hint at their next frame (hydamd_begin_frame) */
+        g_outgrown.fetch_or(status & (HYDK_STATUS_TOKENS | HYDK_STATUS_PAYLOAD), std::memory_order_relaxed);
     st = replay_frame(ctx);
     *again = st == ST_OK;
     return st;
@@ -2318,6 +2348,8 @@ size_t hydamd_payload_capacity(HydAmdContext *ctx) { return ctx ? ctx->payload_c
 unsigned hydamd_token_capacity(HydAmdContext *ctx) { return ctx ? ctx->tok_cap : 0; }
 
 unsigned hydamd_overflow_reruns(HydAmdContext *ctx) { return ctx ? ctx->overflow_reruns : 0; }
+
+unsigned hydamd_grown_ahead(HydAmdContext *ctx) { return ctx ? ctx->grown_ahead : 0; }
 
 const uint8_t *hydamd_payload_device(HydAmdContext *ctx) { return ctx ? ctx->payload : nullptr; }
 

@@ -1277,7 +1277,10 @@ static int finish_frame_through_host(HYDEncoder *e, const HydFrameShape *shape, 
     t0 = now_ms();
     {
         const PayloadSegments segs = {(size_t)N, seg_ptr, hf_len};
-        ret = assemble_frame(e, shape, res, max_alphabet, NULL, 0, NULL, &segs);
+        size_t hf_total = 0;
+        for (int d = 0; d < N; d++)
+            hf_total += hf_len[d];
+        ret = assemble_frame(e, shape, res, max_alphabet, NULL, hf_total, NULL, &segs);
     }
     TRACE("assemble frame (host)", t0);
 done:

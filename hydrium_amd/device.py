@@ -103,6 +103,8 @@ def dll(path: Optional[str] = None):
         d.hydamd_token_capacity.argtypes = [vp]
         d.hydamd_overflow_reruns.restype = u
         d.hydamd_overflow_reruns.argtypes = [vp]
+        d.hydamd_grown_ahead.restype = u
+        d.hydamd_grown_ahead.argtypes = [vp]
         d.hydamd_payload_device.restype = vp
         d.hydamd_payload_device.argtypes = [vp]
         d.hydamd_read_payload.argtypes = [vp, vp, sz]
@@ -356,6 +358,9 @@ class DeviceContext:
 
     def token_capacity(self) -> int:
         return int(self.d.hydamd_token_capacity(self.h))
+
+    def grown_ahead(self) -> int:
+        return int(self.d.hydamd_grown_ahead(self.h))
 
     def overflow_reruns(self) -> int:
         return int(self.d.hydamd_overflow_reruns(self.h))

@@ -183,6 +183,10 @@ HYDAMD_EXPORT const uint8_t *hydamd_payload_device(HydAmdContext *ctx);
 HYDAMD_EXPORT size_t hydamd_payload_capacity(HydAmdContext *ctx);
 HYDAMD_EXPORT unsigned hydamd_token_capacity(HydAmdContext *ctx);
 HYDAMD_EXPORT unsigned hydamd_overflow_reruns(HydAmdContext *ctx);
+/* Once any context of the process has rerun a frame for that reason, the others take the hint: hydamd_begin_frame enlarges
+ * an IDLE context's arrays ahead of its next frame (a queue of frames is of one kind as a rule); a busy context keeps what
+ * it has and finds out by itself.  How often that happened for this context: */
+HYDAMD_EXPORT unsigned hydamd_grown_ahead(HydAmdContext *ctx);
 HYDAMD_EXPORT int hydamd_read_payload(HydAmdContext *ctx, uint8_t *dst, size_t capacity);
 /* bits[g] = exact bit length of group g's section (0 for absent groups), offsets[g] = byte offset in the payload */
 HYDAMD_EXPORT int hydamd_read_sections(HydAmdContext *ctx, int slot, uint32_t bits[HYDAMD_GROUPS_PER_LFG],

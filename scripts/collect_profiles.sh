@@ -142,6 +142,18 @@ if want lane_step; then
 run lane_step txt bash -c 'echo "# HYDK_LANE_STEP 1 (round 5: 13.5 vector instructions per symbol) against 2 (round 6: 11.5); commit $(cat .commit 2>/dev/null)"; python scripts/k1_variants.py --run --rounds 3 --pipe ls1 ls2'
 fi
 
+# how long the stages last INSIDE the loop (event timers around every stage of context 0: costs the loop ~4 %), real chain and variants
+if want loop_stage_times; then
+run loop_stage_times txt bash -c '
+  echo "# stage durations inside the pipelined loop (scripts/pipe_probe.py --profile 1: library event timers, context 0), one box; commit $(cat .commit 2>/dev/null)"
+  for n in ls1 ls2 p1 p4 p5; do
+    echo "== chain variant $n (ls1 / ls2: round 5 / round 6 step; p1: operand rows from one address; p4: no global traffic; p5: both)"
+    HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$n.so python scripts/pipe_probe.py --streams 16 --batch 2 --frames 256 --rans 5 --reps 1 --profile 1 2>&1 | grep -E "SUSTAINED|stage times|rror"
+  done
+  echo "== product library, alone (one frame at a time)"; python scripts/one_frame.py 2 5 2 t 2>&1 | grep -E "transform|rans|pack|tables|lf_"
+'
+fi
+
 # instruction cache: the transform kernel is 29.6 KB of code, the chain kernel 17 KB, the table kernel 23 KB (llvm-readelf -s)
 if want icache; then
 mkdir -p /tmp/pmc_ic

@@ -80,7 +80,13 @@ constexpr int kThreads = 256;
  *                      at its slowest wavefront's pace; profiles/r06_chain_probes.txt): fewer instructions, not a shorter
  *                      dependent path, is what the loop pays for. */
 #ifndef HYDK_LANE_STEP
-#define HYDK_LANE_STEP 2
+#define HYDK_LANE_STEP 1
+#endif
+/*   HYDK_LANE_PIPE     how the lane-form chain's record lines travel: 0 = round 5's (one buffer copied into another at every
+ *                      round's start, the line one round ahead, stores in the middle of the walk); 1 / 2 = two / three
+ *                      buffers taking turns, the line 1 / 2 rounds ahead, stores at the round's start (see HYDK_LANE_ROUND) */
+#ifndef HYDK_LANE_PIPE
+#define HYDK_LANE_PIPE 2
 #endif
 #ifndef HYDK_CHAIN_PRIO
 #define HYDK_CHAIN_PRIO 3
@@ -1989,6 +1995,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     } while (0)
 #endif /* HYDK_LANE_STEP */
 
+#if HYDK_LANE_PIPE == 0
 /* one round = the 16 symbols of one 64-byte line of records.  The first round of a lane is the partial one (FIRST: only
  * positions below first_count count); it is peeled out of the loop and walks the plain way */
 #define HYDK_LANE_ROUND(FIRST)                                                                                   \
@@ -2070,6 +2077,127 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
         aux[prj * 2 + 1] = uint4{pw[4], pw[5], pw[6], pw[7]};
         flags[prj] = (uint16_t)pfl;
     }
+#else
+/* one round = the 16 symbols of one 64-byte line of records.  The first round of a lane is the partial one (FIRST: only
+ * positions below first_count count); it is peeled out of the loop and walks the plain way.
+ * Round 6 (HYDK_LANE_PIPE 1 / 2): the lines travel in two / three register buffers that take turns (the loop is unrolled
+ * by that many rounds) instead of one buffer copied into another at every round's start — sixteen v_mov a round, one
+ * vector issue slot per symbol, gone; the line requested in a round is the one DIST rounds ahead (inside the pipelined loop
+ * a request that left one round = 2 us ago has often not returned: the transform kernels of fifteen other frames keep the
+ * memory system at 2-3 TB/s; profiles/r06_loop_stage_times.txt: without global traffic a chain lasts 2.6 ms in the loop
+ * instead of 4.4); and the PREVIOUS round's refill words and flags are stored at the round's start, right behind that
+ * request, so that they have the whole walk to complete before the next wait for records (vmcnt counts stores too: round 5
+ * stored them in the middle of the walk, eight steps before that wait). */
+#define HYDK_LANE_STORE_PREV()                                                                                   \
+    do {                                                                                                         \
+        if (prj >= 0 && !(HYDK_CHAIN_PROBE & 4)) {                                                               \
+            aux[prj * 2] = uint4{pw[0], pw[1], pw[2], pw[3]};                                                    \
+            aux[prj * 2 + 1] = uint4{pw[4], pw[5], pw[6], pw[7]};                                                \
+            flags[prj] = (uint16_t)pfl; /* bit (p mod 16): symbol p refills */                                   \
+        }                                                                                                        \
+    } while (0)
+#define HYDK_LANE_ROUND(FIRST, CUR, AFTER_REQUESTS)                                                              \
+    do {                                                                                                         \
+        if (rj >= 0) {                                                                                           \
+            uint32_t fl = 0;                                                                                     \
+            uint32_t w16[8];                                                                                     \
+            const uint32_t recs[16] = {CUR[0].x, CUR[0].y, CUR[0].z, CUR[0].w, CUR[1].x, CUR[1].y, CUR[1].z, CUR[1].w, \
+                                       CUR[2].x, CUR[2].y, CUR[2].z, CUR[2].w, CUR[3].x, CUR[3].y, CUR[3].z, CUR[3].w}; \
+            /* bits 4-14 of a record are its operand row's byte offset (beyond the stream's end: stale bytes; an LDS \
+             * read past the table returns 0).  All sixteen rows are requested before the walk: a row requested  \
+             * inside its step returns behind the step's slot lookup and lengthens every wait */                 \
+            uint4 ov[16];                                                                                        \
+            _Pragma("unroll") for (int pos = 15; pos >= 0; pos--) {                                              \
+                uint32_t row = (FIRST) && !(pos < first_count) ? 0u : recs[pos] & 0x7FF0u;                       \
+                if (HYDK_CHAIN_PROBE & 1) { /* one address for all lanes, sixteen requests all the same */       \
+                    row = 1920u;                                                                                 \
+                    asm volatile("" : "+v"(row));                                                                \
+                }                                                                                                \
+                ov[pos] = *(const uint4 *)(s_mem + row);                                                         \
+            }                                                                                                    \
+            __builtin_amdgcn_sched_barrier(0); /* (the scheduler would sink the requests back into the steps) */ \
+            /* memory operations go out HERE, behind the wait the row requests needed for this round's records (the \
+             * compiler drains the whole counter there): whatever is requested now has until the next such wait */ \
+            AFTER_REQUESTS;                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            uint32_t A = 0, B = 0, sm = 0, sl = 0, so = 0; /* the walk's state between two steps of a round */   \
+            unsigned long long rf = 0; /* (HYDK_LANE_STEP 2) the next symbol's refill decision, a lane mask */   \
+            (void)B; (void)sm; (void)rf;                                                                         \
+            if (FIRST) {                                                                                         \
+                _Pragma("unroll") for (int pos = 15; pos >= 0; pos--)                                            \
+                    HYDK_LANE_STEP_COLD(ov[pos], pos, pos < first_count);                                        \
+            } else {                                                                                             \
+                HYDK_LANE_STEP_HEAD(ov[15], ov[14]);                                                             \
+                _Pragma("unroll") for (int pos = 14; pos >= 1; pos--)                                            \
+                    HYDK_LANE_STEP_BODY(ov[pos], ov[pos - 1], pos);                                              \
+                HYDK_LANE_STEP_TAIL(ov[0]);                                                                      \
+            }                                                                                                    \
+            _Pragma("unroll") for (int q = 0; q < 8; q++) pw[q] = w16[q];                                        \
+            pfl = fl;                                                                                            \
+            refills += (uint32_t)__popc(fl);                                                                     \
+        } else {                                                                                                 \
+            HYDK_LANE_STORE_PREV(); /* this lane's last round */                                                 \
+        }                                                                                                        \
+        prj = rj; /* (negative: nothing to store) */                                                             \
+        rj = rj - 1;                                                                                             \
+    } while (0)
+/* the lines AHEAD .. AHEAD + COUNT - 1 rounds ahead of the current one, into F0 (and F1) */
+#define HYDK_LANE_FETCH(F, AHEAD)                                                                                \
+    do {                                                                                                         \
+        if (rj - (AHEAD) >= 0 && !(HYDK_CHAIN_PROBE & 4)) {                                                      \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) F[q] = load_records4(tok, (rj - (AHEAD)) * 4 + q);     \
+        }                                                                                                        \
+    } while (0)
+
+    uint32_t pw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pfl = 0;
+    int prj = -1; /* the round whose results are still in registers */
+    int it = 0;   /* rounds walked (wave-uniform, like `rounds`) */
+#if HYDK_LANE_PIPE == 1
+    /* two buffers: the next round's line is requested behind this round's wait (one round = sixteen steps of slack) */
+    uint4 nb[4] = {};
+#define HYDK_LANE_TURN(FIRST, C, F)                                                                              \
+    if (it < rounds) {                                                                                           \
+        __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0), for every lane */                                       \
+        HYDK_LANE_ROUND(FIRST, C, HYDK_LANE_FETCH(F, 1); HYDK_LANE_STORE_PREV());                                \
+        it++;                                                                                                    \
+    }
+    HYDK_LANE_TURN(true, nx, nb)
+    while (it < rounds) {
+        HYDK_LANE_TURN(false, nb, nx)
+        HYDK_LANE_TURN(false, nx, nb)
+    }
+#else
+    /* four buffers in two pairs: a pair of rounds walks one pair while the other pair's two lines travel (two rounds =
+     * thirty-two steps of slack between a request and the wait that needs it) */
+    uint4 ny[4], nb[4] = {}, nc[4] = {};
+#pragma unroll
+    for (int q = 0; q < 4; q++) /* the second line travels with the first */
+        ny[q] = rj >= 1 && !(HYDK_CHAIN_PROBE & 4) ? load_records4(tok, (rj - 1) * 4 + q) : uint4{0, 0, 0, 0};
+#define HYDK_LANE_TURN(FIRST, C0, C1, F0, F1)                                                                    \
+    if (it < rounds) {                                                                                           \
+        /* the ONE wait of the pair, for every lane (a lane that has finished takes the other branch of the round: \
+         * left to the compiler, that path would leave the lines "pending" and the pair's second round would drain \
+         * the counter again, the lines just requested included) */                                              \
+        __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */                                                       \
+        HYDK_LANE_ROUND(FIRST, C0, HYDK_LANE_FETCH(F0, 2); HYDK_LANE_FETCH(F1, 3); HYDK_LANE_STORE_PREV());      \
+        it++;                                                                                                    \
+        if (it < rounds) {                                                                                       \
+            HYDK_LANE_ROUND(false, C1, HYDK_LANE_STORE_PREV());                                                  \
+            it++;                                                                                                \
+        }                                                                                                        \
+    }
+    HYDK_LANE_TURN(true, nx, ny, nb, nc)
+    while (it < rounds) {
+        HYDK_LANE_TURN(false, nb, nc, nx, ny)
+        HYDK_LANE_TURN(false, nx, ny, nb, nc)
+    }
+#endif
+#undef HYDK_LANE_TURN
+#undef HYDK_LANE_FETCH
+#undef HYDK_LANE_ROUND
+    HYDK_LANE_STORE_PREV();
+#undef HYDK_LANE_STORE_PREV
+#endif /* HYDK_LANE_PIPE */
 #undef HYDK_LANE_STEP_TAIL
 #undef HYDK_LANE_STEP_BODY
 #undef HYDK_LANE_STEP_HEAD

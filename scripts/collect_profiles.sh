@@ -154,6 +154,12 @@ run loop_stage_times txt bash -c '
 '
 fi
 
+# how the chain's record lines travel (kernels.hip HYDK_LANE_PIPE 0 = round 5, 1 = two buffers, 2 = two pairs) and the step (HYDK_LANE_STEP)
+#   python scripts/k1_variants.py --build r5=-DHYDK_LANE_PIPE=0,-DHYDK_LANE_STEP=1 pp1=-DHYDK_LANE_PIPE=1 pp2=-DHYDK_LANE_PIPE=2 pp2s2=-DHYDK_LANE_PIPE=2,-DHYDK_LANE_STEP=2
+if want lane_pipe; then
+run lane_pipe txt bash -c 'echo "# the lane-form chain: round 5 (r5) against two buffers taking turns (pp1), two pairs with the lines two rounds ahead (pp2; pp2s2: with the 11.5-instruction step); kernels alone, bytes, the photo loop and the noise loop, alternating on one box; commit $(cat .commit 2>/dev/null)"; K1V_NOISE=1 python scripts/k1_variants.py --run --rounds 3 --pipe r5 pp1 pp2 pp2s2'
+fi
+
 # instruction cache: the transform kernel is 29.6 KB of code, the chain kernel 17 KB, the table kernel 23 KB (llvm-readelf -s)
 if want icache; then
 mkdir -p /tmp/pmc_ic

@@ -86,6 +86,13 @@ def one(name, frames=6, pipe=False):
             res["pipe_gpx"] = round(d["value"] / 1e3, 1)
         except Exception as e:  # noqa: BLE001
             res["pipe_gpx"] = f"failed: {e}: {r.stderr[-300:]}"
+        if os.environ.get("K1V_NOISE"):  # the chain-bound loop: 2.9 symbols per pixel
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "48", "--kind", "noise", "--no-cpu-baseline", "--no-api",
+                                "--no-legs", "--no-content"], capture_output=True, text=True, env=dict(os.environ))
+            try:
+                res["noise_gpx"] = round(json.loads(r.stdout.strip().splitlines()[-1])["value"] / 1e3, 1)
+            except Exception as e:  # noqa: BLE001
+                res["noise_gpx"] = f"failed: {e}: {r.stderr[-300:]}"
     print("RESULT " + json.dumps(res), flush=True)
 
 
@@ -102,7 +109,7 @@ def run(names, rounds, pipe):
             d = json.loads(line[7:])
             rows[n].append(d)
             print(f"round {r} {n:14s} K1 {d['k1_ms']:.4f} ms  chains {d.get('chain_ms', 0):.4f} ms  md5 {d['md5']}  lds {d['lds']} vgpr {d['vgpr']}"
-                  + (f"  pipelined {d['pipe_gpx']} Gpixel/s" if pipe else ""), flush=True)
+                  + (f"  pipelined {d['pipe_gpx']} Gpixel/s" if pipe else "") + (f"  noise loop {d['noise_gpx']}" if "noise_gpx" in d else ""), flush=True)
     print("\nsummary (K1 alone, ms: min / mean over rounds)")
     ref = rows[names[0]][0]["md5"] if rows[names[0]] else None
     for n in names:

@@ -2218,6 +2218,9 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
  * per lane: two aligned 16-byte record loads, one 16-byte load of refill words); inside a batch the
  * stream order [refill_p][residue_p][refill_p+1].. is plain ascending (lane, symbol) order.
  * grid = 16 x LF groups, block = 256. */
+#ifndef HYDK_EMIT_SHARE_DEFAULT
+#define HYDK_EMIT_SHARE_DEFAULT 1
+#endif
 constexpr int kEmitPer = 8;                  /* symbols per lane and batch */
 constexpr int kEmitBatch = 64 * kEmitPer;    /* 512 */
 constexpr int kEmitWin = kEmitBatch + 4;     /* 512 symbols x at most 32 bits = 512 words + alignment slack */
@@ -2226,12 +2229,17 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
                                                         const uint16_t *aux_all, const uint16_t *flags_all, uint32_t aux_pitch,
                                                         const uint32_t *final_state_all, const uint32_t *group_bits_all,
                                                         const uint64_t *offsets_all, uint8_t *payload, int preset_bits,
-                                                        const uint32_t *status) {
+                                                        const uint32_t *status, int vblocks) {
     __shared__ uint32_t s_win[4][kEmitWin];
     HYDK_URGENT();
+    /* a workgroup takes the virtual blocks blockIdx.x, blockIdx.x + gridDim.x, ... (four groups each, one per wavefront):
+     * inside the pipelined loop a workgroup WAITS for its place — the transform kernels of fifteen other frames take
+     * whatever a compute unit frees, and this kernel's queue gets its turn among theirs — far longer than it runs, so
+     * fewer workgroups with more to do each finish sooner (launch_rans_emit, HYDAMD_EMIT_SHARE) */
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int slot = blockIdx.x >> 4;
-    const int g = ((blockIdx.x & 15) << 2) + wave;
+    auto one_block = [&](const int vb) {
+    const int slot = vb >> 4;
+    const int g = ((vb & 15) << 2) + wave;
     const int ngroups = jobs[slot].gcols * jobs[slot].grows;
     const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + g;
     if (g >= ngroups || (*status & HYDK_STATUS_OVERFLOW))
@@ -2386,6 +2394,9 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
     }
     if (lane == 0 && (cur & 31u))
         put(cur >> 5, carry);
+    }; /* one_block */
+    for (int vb = blockIdx.x; vb < vblocks; vb += gridDim.x)
+        one_block(vb);
 }
 
 /* ==========================================================================================
@@ -2726,8 +2737,15 @@ hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count,
 hipError_t launch_rans_emit(const HydkLfJob *d_jobs, const uint32_t *sym_count, const uint16_t *aux, const uint16_t *flags,
                             uint32_t aux_pitch, const uint32_t *final_state, const uint32_t *group_bits, const uint64_t *offsets,
                             uint8_t *payload, int preset_bits, int num_slots, const uint32_t *status, hipStream_t stream) {
-    hipLaunchKernelGGL(k_rans_emit, dim3(num_slots * 16), dim3(kThreads), 0, stream, d_jobs, sym_count, aux, flags, aux_pitch,
-                       final_state, group_bits, offsets, payload, preset_bits, status);
+    /* virtual blocks per workgroup: HYDAMD_EMIT_SHARE (A/B; 1 = one workgroup per four groups, as until round 5) */
+    static const int share = [] {
+        const char *v = getenv("HYDAMD_EMIT_SHARE");
+        const int n = v && *v ? atoi(v) : HYDK_EMIT_SHARE_DEFAULT;
+        return n < 1 ? 1 : n > 16 ? 16 : n;
+    }();
+    const int vblocks = num_slots * 16;
+    hipLaunchKernelGGL(k_rans_emit, dim3((vblocks + share - 1) / share), dim3(kThreads), 0, stream, d_jobs, sym_count, aux, flags,
+                       aux_pitch, final_state, group_bits, offsets, payload, preset_bits, status, vblocks);
     return hipGetLastError();
 }
 

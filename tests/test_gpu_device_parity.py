@@ -346,3 +346,31 @@ def test_integer_frame_in_a_context_an_earlier_float_frame_widened(image, form):
         ctx.encode_image_tensor(t_f)      # and a float frame again
         ctx.sync()
         assert ctx.read_payload() == want_f.stream
+
+
+def test_contexts_take_the_hint_when_another_one_outgrew_its_buffers():
+    """round 6: once a context of the process has rerun a frame because the default arrays were too small (noise: 2.9
+    symbols per pixel), an IDLE context enlarges its arrays ahead of its next frame (hydamd_begin_frame) instead of
+    finding out by itself; the bytes are the same either way.  A process of its own: the hint is process-wide."""
+    import subprocess
+    import sys
+
+    code = """
+import torch
+from hydrium_amd import device, synth
+img = synth.make_image("noise", 2048, 2048, 8, device="cuda")
+with device.DeviceContext(0, 1, 0) as a, device.DeviceContext(0, 1, 0) as b:
+    a.encode_image_tensor(img); a.sync()
+    assert a.overflow_reruns() >= 1 and a.grown_ahead() == 0, (a.overflow_reruns(), a.grown_ahead())
+    want = a.read_payload()
+    b.encode_image_tensor(img); b.sync()
+    assert b.overflow_reruns() == 0 and b.grown_ahead() == 1, (b.overflow_reruns(), b.grown_ahead())
+    assert b.token_capacity() == a.token_capacity() == 196608
+    assert b.read_payload() == want
+print("ok")
+"""
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env.pop("HYDAMD_TOKEN_CAP", None)
+    env.pop("HYDAMD_PAYLOAD_CAP", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

@@ -65,7 +65,7 @@ constexpr int kThreads = 256;
  * chain kernel (wrong bytes; scripts/k1_variants.py builds them, scripts/pipe_probe.py runs them with the emit stage off):
  *   HYDK_CHAIN_PROBE   1: every operand row from ONE address (no bank conflicts among the 64 lanes' ds_read_b128);
  *                      4: no global traffic after the first round (a lane walks its first 16 records again and again and
- *                         stores nothing)
+ *                         stores nothing); 8: no stores only; 16: no loads only
  *   HYDK_CHAIN_PRIO    issue priority of the chain wavefronts (product: 3)
  *   HYDK_K1_PRIO       issue priority of the transform kernel's wavefronts (product: none set = 0) */
 #ifndef HYDK_CHAIN_PROBE
@@ -2090,7 +2090,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
  * stored them in the middle of the walk, eight steps before that wait). */
 #define HYDK_LANE_STORE_PREV()                                                                                   \
     do {                                                                                                         \
-        if (prj >= 0 && !(HYDK_CHAIN_PROBE & 4)) {                                                               \
+        if (prj >= 0 && !(HYDK_CHAIN_PROBE & (4 | 8))) {                                                         \
             aux[prj * 2] = uint4{pw[0], pw[1], pw[2], pw[3]};                                                    \
             aux[prj * 2 + 1] = uint4{pw[4], pw[5], pw[6], pw[7]};                                                \
             flags[prj] = (uint16_t)pfl; /* bit (p mod 16): symbol p refills */                                   \
@@ -2144,7 +2144,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
 /* the lines AHEAD .. AHEAD + COUNT - 1 rounds ahead of the current one, into F0 (and F1) */
 #define HYDK_LANE_FETCH(F, AHEAD)                                                                                \
     do {                                                                                                         \
-        if (rj - (AHEAD) >= 0 && !(HYDK_CHAIN_PROBE & 4)) {                                                      \
+        if (rj - (AHEAD) >= 0 && !(HYDK_CHAIN_PROBE & (4 | 16))) {                                               \
             _Pragma("unroll") for (int q = 0; q < 4; q++) F[q] = load_records4(tok, (rj - (AHEAD)) * 4 + q);     \
         }                                                                                                        \
     } while (0)

@@ -8,13 +8,14 @@
 # usage: bash scripts/collect_profiles.sh <tag> [target ...]      e.g. r06            (every target)
 #                                                                     r06 chain_probes pmc
 # One target per file under profiles/ (the name after the tag): bench_default, kernel_stats (single, single_form4, pipe, shard,
-# api + api_timeline), tile_mode, k1_content, pipeline_bounds, chain_probes, priorities, icache, pmc_8k_photo, fuzz.
+# api + api_timeline), tile_mode, k1_content, pipeline_bounds, chain_probes, priorities, lane_step, lane_pipe, loop_stage_times,
+# emit_share, icache, pmc_8k_photo, fuzz.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
 # The probes that skip stages or run stand-in kernels load hydrium_amd/lib/libhydrium_probe.so (HYD_TEST_HOOKS flavour;
 # scripts/pipe_probe.py selects it) or a variant built by `python scripts/k1_variants.py --build ...` (chain_probes and
 # priorities build theirs HERE, before the gpurun call: hipcc cross-compiles, the .so files travel with the snapshot).
 set -u
 tag=$1; shift
-targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities icache pmc_8k_photo} "
+targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share icache pmc_8k_photo} "
 want() { [[ "$targets" == *" $1 "* ]]; }
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -116,12 +117,12 @@ run chain_probes txt bash -c '
   echo -n "stand-in: the VALU load on FOUR wavefronts, a quarter each:   "; env $S HYDAMD_DEBUG_STANDIN=valu4 bash -c "$PIPE_PROBE; p"
   echo -n "stand-in: VALU, 80 KB of LDS:                                 "; env HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=81408 HYDAMD_DEBUG_STANDIN=valu bash -c "$PIPE_PROBE; p"
   echo -n "stand-in: VALU, no LDS held:                                  "; env HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=0 HYDAMD_DEBUG_STANDIN=valu bash -c "$PIPE_PROBE; p"
-  for n in base p1 p4 p5; do
-    echo -n "real chain variant $n (HYDK_CHAIN_PROBE: 1 rows from one address, 4 no global traffic, 5 both), skip 4: "; HYDAMD_DEBUG_SKIP=4 v $n p
+  for n in base q1 q4 q8 q16; do
+    echo -n "real chain variant $n (HYDK_CHAIN_PROBE: q1 operand rows from one address, q4 no global traffic, q8 no stores, q16 no loads), skip 4: "; HYDAMD_DEBUG_SKIP=4 v $n p
   done
   echo "# the stand-ins and variants ALONE (one frame at a time, ms per chain launch by the library s event timers)"
   for k in valu lds both valu4; do echo -n "stand-in $k alone: "; HYDAMD_LIB=$PWD/hydrium_amd/lib/libhydrium_probe.so HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=65536 HYDAMD_DEBUG_STANDIN=$k python scripts/one_frame.py 2 5 2 t 2>&1 | grep rans_encode; done
-  for n in base p1 p4 p5; do echo -n "variant $n alone: "; HYDAMD_DEBUG_SKIP=4 v $n python scripts/one_frame.py 2 5 2 t 2>&1 | grep rans_encode; done
+  for n in base q1 q4 q8 q16; do echo -n "variant $n alone: "; HYDAMD_DEBUG_SKIP=4 v $n python scripts/one_frame.py 2 5 2 t 2>&1 | grep rans_encode; done
 '
 fi
 
@@ -146,9 +147,9 @@ fi
 if want loop_stage_times; then
 run loop_stage_times txt bash -c '
   echo "# stage durations inside the pipelined loop (scripts/pipe_probe.py --profile 1: library event timers, context 0), one box; commit $(cat .commit 2>/dev/null)"
-  for n in ls1 ls2 p1 p4 p5; do
-    echo "== chain variant $n (ls1 / ls2: round 5 / round 6 step; p1: operand rows from one address; p4: no global traffic; p5: both)"
-    HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$n.so python scripts/pipe_probe.py --streams 16 --batch 2 --frames 256 --rans 5 --reps 1 --profile 1 2>&1 | grep -E "SUSTAINED|stage times|rror"
+  for n in r5 base q4; do
+    echo "== chain variant $n (r5: round 5 s chain, HYDK_LANE_PIPE 0; base: the product s; q4: no global traffic, timing only)"
+    HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$n.so python scripts/pipe_probe.py --streams 16 --batch 2 --frames 256 --rans 5 --reps 2 --profile 1 2>&1 | grep -E "SUSTAINED|stage times|rror"
   done
   echo "== product library, alone (one frame at a time)"; python scripts/one_frame.py 2 5 2 t 2>&1 | grep -E "transform|rans|pack|tables|lf_"
 '
@@ -158,6 +159,16 @@ fi
 #   python scripts/k1_variants.py --build r5=-DHYDK_LANE_PIPE=0,-DHYDK_LANE_STEP=1 pp1=-DHYDK_LANE_PIPE=1 pp2=-DHYDK_LANE_PIPE=2 pp2s2=-DHYDK_LANE_PIPE=2,-DHYDK_LANE_STEP=2
 if want lane_pipe; then
 run lane_pipe txt bash -c 'echo "# the lane-form chain: round 5 (r5) against two buffers taking turns (pp1), two pairs with the lines two rounds ahead (pp2; pp2s2: with the 11.5-instruction step); kernels alone, bytes, the photo loop and the noise loop, alternating on one box; commit $(cat .commit 2>/dev/null)"; K1V_NOISE=1 python scripts/k1_variants.py --run --rounds 3 --pipe r5 pp1 pp2 pp2s2'
+fi
+
+# the emit kernel as fewer, fatter workgroups (HYDAMD_EMIT_SHARE virtual blocks per workgroup): does a small kernel wait for its
+# workgroups turns among the transform kernels of fifteen other queues?
+if want emit_share; then
+run emit_share txt bash -c '
+  eval "$PIPE_PROBE"
+  echo "# HYDAMD_EMIT_SHARE (virtual blocks of four groups per emit workgroup), the pipelined loop, sustained Gpixel/s, alternating; commit $(cat .commit 2>/dev/null)"
+  for rep in 1 2; do for sh in 1 2 4 8; do echo -n "share $sh: "; HYDAMD_EMIT_SHARE=$sh p; done; done
+'
 fi
 
 # instruction cache: the transform kernel is 29.6 KB of code, the chain kernel 17 KB, the table kernel 23 KB (llvm-readelf -s)

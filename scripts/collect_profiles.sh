@@ -115,6 +115,9 @@ run chain_probes txt bash -c '
   echo -n "stand-in: its LDS reads only (random rows, conflicts):        "; env $S HYDAMD_DEBUG_STANDIN=lds bash -c "$PIPE_PROBE; p"
   echo -n "stand-in: both:                                               "; env $S HYDAMD_DEBUG_STANDIN=both bash -c "$PIPE_PROBE; p"
   echo -n "stand-in: the VALU load on FOUR wavefronts, a quarter each:   "; env $S HYDAMD_DEBUG_STANDIN=valu4 bash -c "$PIPE_PROBE; p"
+  echo "#   control: equal durations (one wavefront: 18 200 steps last what four wavefronts need for 30 000 — 3.4 ms; four: 49 400 steps last what one needs for 30 000 — 5.6 ms)"
+  echo -n "stand-in: VALU, one wavefront, 18200 steps (3.4 ms):          "; env $S HYDAMD_DEBUG_STANDIN=valu HYDAMD_DEBUG_STANDIN_STEPS=18200 bash -c "$PIPE_PROBE; p"
+  echo -n "stand-in: VALU, four wavefronts, 49400 steps (5.6 ms):        "; env $S HYDAMD_DEBUG_STANDIN=valu4 HYDAMD_DEBUG_STANDIN_STEPS=49400 bash -c "$PIPE_PROBE; p"
   echo -n "stand-in: VALU, 80 KB of LDS:                                 "; env HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=81408 HYDAMD_DEBUG_STANDIN=valu bash -c "$PIPE_PROBE; p"
   echo -n "stand-in: VALU, no LDS held:                                  "; env HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=0 HYDAMD_DEBUG_STANDIN=valu bash -c "$PIPE_PROBE; p"
   for n in base q1 q4 q8 q16; do

@@ -65,7 +65,8 @@ constexpr int kThreads = 256;
  * chain kernel (wrong bytes; scripts/k1_variants.py builds them, scripts/pipe_probe.py runs them with the emit stage off):
  *   HYDK_CHAIN_PROBE   1: every operand row from ONE address (no bank conflicts among the 64 lanes' ds_read_b128);
  *                      4: no global traffic after the first round (a lane walks its first 16 records again and again and
- *                         stores nothing); 8: no stores only; 16: no loads only
+ *                         stores nothing); 8: no stores only; 16: no loads only; 32: every chain wavefront leaves its start and end time
+ *                         where the section sizes go (scripts/pipe_probe.py --chain-clock)
  *   HYDK_CHAIN_PRIO    issue priority of the chain wavefronts (product: 3)
  *   HYDK_K1_PRIO       issue priority of the transform kernel's wavefronts (product: none set = 0) */
 #ifndef HYDK_CHAIN_PROBE
@@ -90,6 +91,12 @@ constexpr int kThreads = 256;
 #endif
 #ifndef HYDK_CHAIN_PRIO
 #define HYDK_CHAIN_PRIO 3
+#endif
+/*   HYDK_CHAIN_HOG     1: a chain wavefront names accumulation register a255, so that it is allocated 256 of them on top of its
+ *                      vector registers and no transform wavefront (120) fits beside it on its SIMD: the chain keeps its
+ *                      SIMD's issue port to itself, the transform workgroups of its compute unit live on the other three */
+#ifndef HYDK_CHAIN_HOG
+#define HYDK_CHAIN_HOG 0
 #endif
 #ifndef HYDK_K1_PRIO
 #define HYDK_K1_PRIO 0
@@ -1790,6 +1797,12 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     uint4 *const s_ops = (uint4 *)s_mem;
     unsigned char *const s_tab = s_mem + kOpsBytes; /* uint16_t[NC * 4096] */
     __builtin_amdgcn_s_setprio(HYDK_CHAIN_PRIO);
+#if HYDK_CHAIN_PROBE & 32
+    const uint32_t probe_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+#if HYDK_CHAIN_HOG
+    asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
+#endif
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= num_slots) {
         /* passengers: workgroup num_slots + s builds the prefix code of LF group s's coefficient stream
@@ -2209,6 +2222,15 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     } else {
         group_bits_all[G] = 0;
     }
+#if HYDK_CHAIN_PROBE & 32
+    /* timing only: when this wavefront started and ended (100 MHz ticks), where hydamd_read_sections finds them (lanes 0 and
+     * 1 of the slot): were the chains of a launch RUNNING for the stage's duration in the loop, or WAITING for a compute unit
+     * with 80 KB of LDS free (scripts/pipe_probe.py --chain-clock) */
+    if (lane == 0)
+        group_bits_all[G] = probe_t0;
+    if (lane == 1)
+        group_bits_all[G] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 /* one wave per group: records + the chain's refill words -> bits, written straight to the section's

@@ -154,6 +154,11 @@ run loop_stage_times txt bash -c '
     echo "== chain variant $n (r5: round 5 s chain, HYDK_LANE_PIPE 0; base: the product s; q4: no global traffic, timing only)"
     HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$n.so python scripts/pipe_probe.py --streams 16 --batch 2 --frames 256 --rans 5 --reps 2 --profile 1 2>&1 | grep -E "SUSTAINED|stage times|rror"
   done
+  echo "== when do the chain wavefronts of a launch start and end? (HYDK_CHAIN_PROBE 32, scan + emit off; last line: alone)"
+  for i in 1 2 3; do HYDAMD_DEBUG_SKIP=4 HYDAMD_LIB=$PWD/scripts/probe_build/k1v_q32.so python scripts/pipe_probe.py --streams 16 --batch 2 --frames 256 --rans 5 --reps 1 --chain-clock --profile 1 2>&1 | grep -E "SUSTAINED|chain wavefronts|stage times|rror"; done
+  HYDAMD_DEBUG_SKIP=4 HYDAMD_LIB=$PWD/scripts/probe_build/k1v_q32.so python scripts/pipe_probe.py --streams 1 --batch 2 --frames 8 --rans 5 --reps 1 --chain-clock 2>&1 | grep -E "chain wavefronts|rror"
+  echo "== a chain wavefront that owns its SIMD (HYDK_CHAIN_HOG)"
+  for n in base hog; do echo -n "$n: "; HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$n.so python scripts/pipe_probe.py --streams 16 --batch 2 --frames 384 --rans 5 --reps 2 --profile 1 2>&1 | grep -E "SUSTAINED|stage times|rror" | sed "s/^ *//" | tr "\n" " "; echo; done
   echo "== product library, alone (one frame at a time)"; python scripts/one_frame.py 2 5 2 t 2>&1 | grep -E "transform|rans|pack|tables|lf_"
 '
 fi

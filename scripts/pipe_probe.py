@@ -34,6 +34,7 @@ ap.add_argument("--only-transform", action="store_true", help="enqueue the trans
 ap.add_argument("--batch", type=int, default=1, help="frames per launch group (hydamd_encode_image_batch)")
 ap.add_argument("--cohort", type=int, default=0, help="> 0: drain every context after this many launch groups (does a restart bring the fast first phase back?)")
 ap.add_argument("--clock", type=int, default=0, help="> 0: sample the shader clock (hydamd_debug_shader_clock_mhz) every this many launch groups")
+ap.add_argument("--chain-clock", action="store_true", help="with a library built under -DHYDK_CHAIN_PROBE=32 (and HYDAMD_DEBUG_SKIP=4): when did the chain wavefronts of context 0's last launch group start and end?")
 ap.add_argument("--lanes", type=int, default=0, help="> 0: this many HIP streams, contexts dealt to them in turn (several contexts per stream)")
 a = ap.parse_args()
 if not a.no_bind:
@@ -109,5 +110,12 @@ for rep in range(a.reps):
     print(f"batch {a.batch} lanes {a.lanes} streams {S} profile {a.profile} lf {a.lf} rans {a.rans}: {ms:.4f} ms/frame = {a.size * H / ms / 1e6:.1f} Gpixel/s; "
           f"host enqueue {host / n * 1e3:.3f} ms/frame (first 3 per stream, unblocked: {first * 1e3:.3f}), issue loop {t_issue / n * 1e3:.3f} ms/frame, wall {wall / n * 1e3:.3f} ms/frame",
           flush=True)
+    if a.chain_clock:  # 100 MHz ticks, wrapped to 32 bits: differences only
+        import numpy as np
+        t = np.array([[int(ctxs[0].read_sections(sl)[0][k]) for k in (0, 1)] for sl in range(lfg * a.batch)], dtype=np.int64)
+        s0 = (t[:, 0] - t[:, 0].min()) / 100.0  # us after the first wavefront's start
+        run = ((t[:, 1] - t[:, 0]) % (1 << 32)) / 100.0
+        print(f"   chain wavefronts of context 0's last launch group ({len(t)}): started over {s0.max():.0f} us (median {np.median(s0):.0f}), "
+              f"each ran {run.min():.0f} .. {run.max():.0f} us (median {np.median(run):.0f}); first start -> last end {((t[:, 1].max() - t[:, 0].min()) % (1 << 32)) / 100.0:.0f} us", flush=True)
     if a.profile:  # every stage's duration as it runs INSIDE the loop, sharing the chip (event timers, context 0)
         print("   stage times in the loop: " + ", ".join(f"{k} {ms / n:.3f} ms" for k, (ms, n) in ctxs[0].profile_read().items() if n), flush=True)

@@ -807,7 +807,7 @@ from hydrium_amd import device, synth
 ndev, size, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 devices = list(range(ndev)) if ndev > 1 else [0, 0, 0, 0]
 n = len(devices)
-D = 5 if ndev <= 1 else 8                       # frames in flight: one HydAmdMulti each (n contexts, n streams)
+D = 4 if ndev <= 1 else 8                       # frames in flight: one HydAmdMulti each (n contexts, n streams)
 pics = {d: synth.make_image("photo", size, size, 8, device=torch.device("cuda", d)) for d in sorted(set(devices))}
 for d in pics:
     torch.cuda.synchronize(d)

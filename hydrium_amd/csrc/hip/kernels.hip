@@ -61,6 +61,11 @@ constexpr int kThreads = 256;
 #ifndef HYDK_K1_ILP
 #define HYDK_K1_ILP 2
 #endif
+/*   HYDK_K1_TRIM       round 6: the token walk's 64-bit multiply-add (cluster * 40 + token) as a 24-bit one, and the record
+ *                      store's address as scalar base + 32-bit offset */
+#ifndef HYDK_K1_TRIM
+#define HYDK_K1_TRIM 0
+#endif
 /* Round 6 (VERDICT r5 task 1): what of a lane-form chain's work costs the pipelined loop?  Timing-only variants of the
  * chain kernel (wrong bytes; scripts/k1_variants.py builds them, scripts/pipe_probe.py runs them with the emit stage off):
  *   HYDK_CHAIN_PROBE   1: every operand row from ONE address (no bank conflicts among the 64 lanes' ds_read_b128);
@@ -540,8 +545,16 @@ __device__ __forceinline__ void store_record(void *tok, uint32_t at, uint32_t to
                                              uint32_t rbits, uint32_t residue) {
     if (FMT == HYDK_FMT_F32)
         ((uint64_t *)tok)[at] = ((uint64_t)residue << 32) | HYDK_REC_LO(token, cluster, rbits);
-    else
+    else {
+#if HYDK_K1_TRIM
+        /* a 32-bit byte offset from the (wave-uniform) array base: the store takes the base from scalar registers and the
+         * offset from one vector register, no 64-bit address arithmetic per symbol */
+        const uint32_t off = at * 4u;
+        *(HYDK_GLOBAL(uint32_t, (char *)tok + off)) = HYDK_REC32(symbol, rbits, residue);
+#else
         HYDK_GLOBAL(uint32_t, tok)[at] = HYDK_REC32(symbol, rbits, residue);
+#endif
+    }
 }
 
 #define HYDK_K1_OCCUPANCY __launch_bounds__(kThreads, HYDK_K1_WAVES)
@@ -921,11 +934,40 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                 for (int c = 0; c < 3; c++)
                     HYDK_GLOBAL(int32_t, job.dc)[(size_t)c * HYDK_DC_PITCH * HYDK_DC_PITCH + (size_t)((py0 >> 3) + s) * HYDK_DC_PITCH + (px0 >> 3) + cb] = lf_int[c];
             }
+#if HYDK_K1_TRIM & 2
+            /* the block's bitmap = OR over its eight threads, taken through LDS instead of three DPP steps per word (eighteen
+             * vector instructions per thread and strip): the block's eight threads are eight neighbouring lanes of ONE
+             * wavefront, whose LDS operations execute in order — thread kh = 0 clears the words, all eight OR into them, thread
+             * kh = 0 reads the result back (only it needs it) */
+            {
+                typedef unsigned long long u64;
+                u64 *const cell = (u64 *)&s_seg[cb * 3]; /* .x/.y of the three descriptors: visit order Y, X, B = channel 1, 0, 2 */
+                if (kh == 0) {
+                    cell[0] = 0;
+                    cell[2] = 0;
+                    cell[4] = 0;
+                }
+                __builtin_amdgcn_wave_barrier();
+                constexpr int at[3] = {2, 0, 4}; /* channel c -> u64 index (descriptor visit * 2) */
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    __hip_atomic_fetch_or((uint32_t *)&cell[at[c]], (uint32_t)msk[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or((uint32_t *)&cell[at[c]] + 1, (uint32_t)(msk[c] >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (kh == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        msk[c] = cell[at[c]];
+                }
+            }
+#else
 #pragma unroll
             for (int c = 0; c < 3 && !(HYDK_K1_SKIP & 4); c++) { /* the block's bitmap = OR over its eight threads */
                 const uint32_t lo = or_reduce8((uint32_t)msk[c]), hi = or_reduce8((uint32_t)(msk[c] >> 32));
                 msk[c] = ((unsigned long long)hi << 32) | lo;
             }
+#endif
         }
         /* symbols per channel: the count symbol + coefficients up to the last non-zero one; visit order
          * Y, X, B (encoder.c:712) */
@@ -1027,7 +1069,11 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                         residue = value & ((1u << nb) - 1u);
                         token = 16u + (((uint32_t)(nb - 3) << 1) | ((value >> nb) & 1u));
                     }
+#if HYDK_K1_TRIM
+                    const uint32_t bin = umad24(cluster, (uint32_t)kHistW, FMT == HYDK_FMT_F32 ? min(token, (uint32_t)kHistW - 1u) : token);
+#else
                     const uint32_t bin = cluster * kHistW + (FMT == HYDK_FMT_F32 ? min(token, (uint32_t)kHistW - 1u) : token);
+#endif
                     store_record<FMT>(tok, goff + p, token, cluster, bin, rbits, residue);
                     rb_sum += rbits;
                     /* every token straight into the LDS histogram (until round 3 zero tokens were counted in packed per-thread

@@ -204,7 +204,7 @@ fi
 
 # seeded fuzz of the drop-in API against the reference (scripts/fuzz_api_parity.py); not part of the default set
 if want fuzz; then
-run fuzz txt bash -c 'echo "# commit $(cat .commit 2>/dev/null)"; for seed in 61 62 63; do FUZZ_BUDGET_S=${FUZZ_BUDGET_S:-600} python scripts/fuzz_api_parity.py 4000 $seed 2>&1 | tail -3; done; FUZZ_BUDGET_S=${FUZZ_BUDGET_S:-600} python scripts/fuzz_api_parity.py 400 64 large 2>&1 | tail -3'
+run fuzz txt bash -c 'echo "# commit $(cat .commit 2>/dev/null)"; for seed in 61 62 63; do FUZZ_BUDGET_S=${FUZZ_BUDGET_S:-600} python scripts/fuzz_api_parity.py 4000 $seed 2>&1 | tail -3; done; FUZZ_BUDGET_S=${FUZZ_BUDGET_S:-600} python scripts/fuzz_api_parity.py 400 64 large 2>&1 | tail -3; echo "# large cases with the device list aliased (HYDAMD_DEVICES=0,0,0: frames of 8 and more LF groups are dealt to three contexts, the home entry rotating, peer reads verified at first use)"; HYDAMD_DEVICES=0,0,0 FUZZ_BUDGET_S=${FUZZ_BUDGET_S:-600} python scripts/fuzz_api_parity.py 400 65 large 2>&1 | tail -3'
 fi
 ls -la "$out"
 exit $failed

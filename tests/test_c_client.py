@@ -46,3 +46,46 @@ def test_c_client_same_bytes_as_with_the_reference(tmp_path, w, h):
     _build(theirs, os.path.dirname(ref_path), os.path.basename(ref_path))
     want = subprocess.run([theirs, str(w), str(h)], check=True, capture_output=True, text=True, timeout=300).stdout
     assert got == want
+
+
+MULTI_SRC = os.path.join(ROOT, "tests", "c", "multi_client.c")
+
+
+def _build_multi(exe):
+    libdir = os.path.dirname(hbuild.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", f"-I{os.path.join(ROOT, 'include')}", "-I/opt/rocm/include", MULTI_SRC,
+           "-o", exe, f"-L{libdir}", f"-l:{os.path.basename(hbuild.LIB_PATH)}", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+
+
+def test_c_client_of_the_multi_device_call_compiles_and_links(tmp_path):
+    """tests/c/multi_client.c: C99 + the HIP runtime's C API + include/hydrium_amd.h, nothing else"""
+    hbuild.build()
+    exe = str(tmp_path / "multi_client")
+    _build_multi(exe)
+    syms = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+    for name in ("hydamd_multi_create", "hydamd_encode_image_multi", "hydamd_multi_result", "hydamd_multi_read"):
+        assert name in syms
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+@pytest.mark.parametrize("w,h,shards", [(4296, 4168, 2), (6200, 4200, 4)])
+def test_c_client_of_the_multi_device_call_gives_the_reference_s_file(tmp_path, w, h, shards):
+    """device-resident pixels, one C call per frame, an aliased device list — against the REFERENCE's bytes for the same
+    picture through hyd_send_tile (tests/c/api_client.c linked with the reference)"""
+    from oracle import refprobe
+
+    hbuild.build()
+    exe = str(tmp_path / "multi_client")
+    _build_multi(exe)
+    got = subprocess.run([exe, str(w), str(h), str(shards)], capture_output=True, text=True, timeout=600)
+    assert got.returncode == 0, got.stdout + got.stderr
+    if not refprobe.available():
+        pytest.skip("prebuilt reference absent")
+    ref_path = refprobe.reference_library().path
+    theirs = str(tmp_path / "client_ref")
+    _build(theirs, os.path.dirname(ref_path), os.path.basename(ref_path))
+    want = subprocess.run([theirs, str(w), str(h)], check=True, capture_output=True, text=True, timeout=900).stdout
+    assert got.stdout == want

@@ -61,6 +61,9 @@ trace single -- python "$root/scripts/one_frame.py" 5 5 2
 trace single_form4 -- python "$root/scripts/one_frame.py" 5 4 2
 trace pipe -- python "$root/bench.py" --steps 256 --no-cpu-baseline --no-api --no-legs
 grep "^{" /tmp/kt_pipe.log | tail -1 > "$out/${tag}_bench_under_rocprof.json"; [ -s "$out/${tag}_bench_under_rocprof.json" ] || fail bench_under_rocprof /tmp/kt_pipe.log
+# the same trace per hardware queue: how long every kernel of the loop WAITS behind its predecessor on its queue, and how long it runs
+db=$(find /tmp/kt_pipe -name "*.db" 2>/dev/null | head -1)
+if [ -n "$db" ]; then run stream_gaps txt bash -c "echo '# the pipelined loop under rocprofv3 --kernel-trace, per hardware queue: mean wait between the end of the previous kernel on the same queue and a kernel s start, and its mean duration (us); commit $(cat .commit 2>/dev/null)'; python scripts/rocpd_gaps.py $db 60 | grep -v '^columns\|^queues'"; else fail stream_gaps /tmp/kt_pipe.log; fi
 trace shard -- python "$root/bench.py" --mode shard --steps 30
 grep "^{" /tmp/kt_shard.log | tail -1 > "$out/${tag}_shard_under_rocprof.json"; [ -s "$out/${tag}_shard_under_rocprof.json" ] || fail shard_under_rocprof /tmp/kt_shard.log
 trace api --memory-copy-trace -- python "$root/scripts/api_frame_times.py"

@@ -912,14 +912,22 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
     /* lf_stream: created on first use (ensure_lf_stream).  A stream takes a place in the runtime's rotation over the
      * hardware queues whether it ever carries work or not: thirty-two contexts that code their LF groups in their own
      * stream would put their main streams on every second queue only */
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->frame_fence, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_fork, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_join, hipEventDisableTiming));
+    /* Events that only ORDER work on this device — the staging fence, the LF side stream's fork and join, the descriptor
+     * ring's "this slot has been read" — release at DEVICE scope: what the host does behind them needs no data the GPU
+     * wrote.  (HYDAMD_EVENT_SCOPE=system: the runtime's default, as until round 5, for A/B.)  lf_ready stays at the default:
+     * the host reads the pinned LF total behind it. */
+    static const unsigned order_only = [] {
+        const char *v = getenv("HYDAMD_EVENT_SCOPE");
+        return v && !strcmp(v, "system") ? 0u : (unsigned)hipEventReleaseToDevice;
+    }();
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->frame_fence, hipEventDisableTiming | order_only));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_fork, hipEventDisableTiming | order_only));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_join, hipEventDisableTiming | order_only));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_ready, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) {
         HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_jobs_ring[i], slots * sizeof(HydkLfJob), hipHostMallocDefault));
         memset(ctx->h_jobs_ring[i], 0, slots * sizeof(HydkLfJob));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->jobs_uploaded[i], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->jobs_uploaded[i], hipEventDisableTiming | order_only));
     }
     ctx->h_jobs = ctx->h_jobs_ring[0];
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_total_pinned, sizeof(uint64_t), hipHostMallocDefault));

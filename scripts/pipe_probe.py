@@ -34,6 +34,9 @@ ap.add_argument("--only-transform", action="store_true", help="enqueue the trans
 ap.add_argument("--batch", type=int, default=1, help="frames per launch group (hydamd_encode_image_batch)")
 ap.add_argument("--cohort", type=int, default=0, help="> 0: drain every context after this many launch groups (does a restart bring the fast first phase back?)")
 ap.add_argument("--clock", type=int, default=0, help="> 0: sample the shader clock (hydamd_debug_shader_clock_mhz) every this many launch groups")
+ap.add_argument("--events", default="torch", choices=("torch", "device", "none"),
+                help="the probe's own event per launch group: torch (timing events, system-scope release: the default until now), "
+                     "device (HIP events created with hipEventReleaseToDevice), none (the rate is the run's wall clock)")
 ap.add_argument("--chain-clock", action="store_true", help="with a library built under -DHYDK_CHAIN_PROBE=32 (and HYDAMD_DEBUG_SKIP=4): when did the chain wavefronts of context 0's last launch group start and end?")
 ap.add_argument("--lanes", type=int, default=0, help="> 0: this many HIP streams, contexts dealt to them in turn (several contexts per stream)")
 a = ap.parse_args()
@@ -59,6 +62,27 @@ for c in ctxs:
     c.sync()
     c.profile(bool(a.profile))
 S = a.streams
+import ctypes as _C
+try:
+    _hip = _C.CDLL("libamdhip64.so.7")  # by soname: the runtime torch already loaded
+except OSError:
+    _hip = _C.CDLL("libamdhip64.so")
+
+
+class DevEvent:
+    """a HIP event with timing whose record releases at DEVICE scope (hipEventReleaseToDevice = 0x40000000)"""
+
+    def __init__(self, stream):
+        self.h = _C.c_void_p()
+        assert _hip.hipEventCreateWithFlags(_C.byref(self.h), _C.c_uint(0x40000000)) == 0
+        assert _hip.hipEventRecord(self.h, _C.c_void_p(stream)) == 0
+
+    def elapsed_time(self, other):
+        ms = _C.c_float()
+        assert _hip.hipEventElapsedTime(_C.byref(ms), self.h, other.h) == 0
+        return ms.value
+
+
 for rep in range(a.reps):
     torch.cuda.synchronize()
     host = 0.0
@@ -77,9 +101,12 @@ for rep in range(a.reps):
         host += time.perf_counter() - th
         if i == 3 * S - 1:
             first = host / (3 * S)  # no context has more than three frames queued yet: nothing can have blocked
-        e = torch.cuda.Event(enable_timing=True)
-        e.record(ext[i % S])
-        evs.append(e)
+        if a.events == "torch":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(ext[i % S])
+            evs.append(e)
+        elif a.events == "device":
+            evs.append(DevEvent(ctxs[i % S].get_stream()))
         if a.cohort and i % a.cohort == a.cohort - 1:
             for c in ctxs:
                 c.sync()
@@ -90,6 +117,10 @@ for rep in range(a.reps):
         c.sync()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    if a.events == "none":
+        print(f"batch {a.batch} streams {S} rans {a.rans}, no events: wall clock {a.size * H * a.batch * n / wall / 1e9:.1f} Gpixel/s over the whole run "
+              f"({n} launch groups, fill and drain included), host enqueue {host / n * 1e3:.3f} ms per group (unblocked: {first * 1e3:.3f})", flush=True)
+        continue
     w = min(S, a.frames)
     base = evs[0]
     t_start = sum(base.elapsed_time(e) for e in evs[4 * S - w:4 * S]) / w

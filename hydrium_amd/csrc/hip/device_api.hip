@@ -913,12 +913,13 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
      * hardware queues whether it ever carries work or not: thirty-two contexts that code their LF groups in their own
      * stream would put their main streams on every second queue only */
     /* Events that only ORDER work on this device — the staging fence, the LF side stream's fork and join, the descriptor
-     * ring's "this slot has been read" — release at DEVICE scope: what the host does behind them needs no data the GPU
-     * wrote.  (HYDAMD_EVENT_SCOPE=system: the runtime's default, as until round 5, for A/B.)  lf_ready stays at the default:
-     * the host reads the pinned LF total behind it. */
+     * ring's "this slot has been read" — could release at DEVICE scope (what the host does behind them needs no data the
+     * GPU wrote): HYDAMD_EVENT_SCOPE=device, an A/B switch.  Measured equal in the pipelined loop (153.1 / 153.6 against
+     * 153.1 / 153.6, profiles/r06_launch_boundaries.txt), so the runtime's default stays.  lf_ready is never touched: the
+     * host reads the pinned LF total behind it. */
     static const unsigned order_only = [] {
         const char *v = getenv("HYDAMD_EVENT_SCOPE");
-        return v && !strcmp(v, "system") ? 0u : (unsigned)hipEventReleaseToDevice;
+        return v && !strcmp(v, "device") ? (unsigned)hipEventReleaseToDevice : 0u;
     }();
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->frame_fence, hipEventDisableTiming | order_only));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_fork, hipEventDisableTiming | order_only));
@@ -2240,6 +2241,15 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
     }
     HIP_TRY(ctx, hydk::launch_publish(ctx->total, ctx->h_total_pinned, ctx->lf_total_unpublished ? ctx->lf_total : nullptr,
                                       ctx->h_lf_total_pinned, ctx->status, ctx->h_status_pinned, ctx->stream));
+#ifdef HYD_TEST_HOOKS
+    {
+        /* HYDAMD_DEBUG_EXTRA_LAUNCHES=n: n more single-wavefront kernels that do nothing, at the end of the closing sequence —
+         * what does a kernel BOUNDARY cost a stream inside the pipelined loop, whatever the kernel does? */
+        static const int extra = env_int("HYDAMD_DEBUG_EXTRA_LAUNCHES", 0);
+        for (int i = 0; i < extra; i++)
+            HIP_TRY(ctx, hydk::launch_publish(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->stream));
+    }
+#endif
     if (ctx->lf_total_unpublished) /* hydamd_sync_lf waits for this event and then reads the LF total */
         HIP_TRY(ctx, hipEventRecord(ctx->lf_ready, ctx->stream));
     ctx->lf_total_unpublished = false;

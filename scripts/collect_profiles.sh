@@ -15,7 +15,7 @@
 # priorities build theirs HERE, before the gpurun call: hipcc cross-compiles, the .so files travel with the snapshot).
 set -u
 tag=$1; shift
-targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share icache pmc_8k_photo} "
+targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo} "
 want() { [[ "$targets" == *" $1 "* ]]; }
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -179,6 +179,19 @@ run emit_share txt bash -c '
   eval "$PIPE_PROBE"
   echo "# HYDAMD_EMIT_SHARE (virtual blocks of four groups per emit workgroup), the pipelined loop, sustained Gpixel/s, alternating; commit $(cat .commit 2>/dev/null)"
   for rep in 1 2; do for sh in 1 2 4 8; do echo -n "share $sh: "; HYDAMD_EMIT_SHARE=$sh p; done; done
+'
+fi
+
+# what does a kernel BOUNDARY cost a stream in the loop (empty kernels appended to every launch group), do the runtime's
+# system-scope event releases matter, and one hardware queue's timeline kernel by kernel
+if want launch_boundaries; then
+run launch_boundaries txt bash -c '
+  eval "$PIPE_PROBE"
+  echo "# the pipelined loop, sustained Gpixel/s; commit $(cat .commit 2>/dev/null)"
+  for rep in 1 2; do for n in 0 2 4 8 16; do echo -n "extra empty single-wavefront kernels per launch group (HYDAMD_DEBUG_EXTRA_LAUNCHES) $n: "; HYDAMD_DEBUG_EXTRA_LAUNCHES=$n p; done; done
+  for rep in 1 2; do for sc in system device; do for ev in torch device; do echo -n "order-only events of the library release at $sc scope, the probe s own events: $ev: "; HYDAMD_EVENT_SCOPE=$sc p --events $ev; done; done; done
+  rm -rf /tmp/kt_q; (cd /tmp && rocprofv3 --kernel-trace -d /tmp/kt_q -o kt -- python '"$root"'/scripts/pipe_probe.py --streams 16 --batch 2 --frames 256 --rans 5 --reps 1 > /tmp/kt_q.log 2>&1)
+  python scripts/rocpd_queue_timeline.py $(find /tmp/kt_q -name "*.db" | head -1) 36 3
 '
 fi
 

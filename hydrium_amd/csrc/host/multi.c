@@ -306,9 +306,13 @@ HYDRIUM_EXPORT int hydamd_multi_result(HydAmdMulti *m, size_t *size) {
                 }
                 continue;
             }
+            if (e && strstr(e, "NaN")) { /* the caller's input, whatever the peer reads did */
+                m->in_flight = 0;
+                return fail(m, HYD_API_ERROR, "Invalid NaN Float", NULL);
+            }
             if (!m->checking) {
                 m->in_flight = 0;
-                return fail(m, e && strstr(e, "NaN") ? HYD_API_ERROR : st < HYD_ERROR_START ? st : HYD_INTERNAL_ERROR, e ? e : "GPU frame assembly failed", NULL);
+                return fail(m, st < HYD_ERROR_START ? st : HYD_INTERNAL_ERROR, e ? e : "GPU frame assembly failed", NULL);
             }
             asm_failed = 1; /* an assembler that read garbage through a bad peer mapping: the checks name the pair */
             snprintf(m->err, sizeof(m->err), "%s", e ? e : "GPU frame assembly failed");

@@ -107,3 +107,17 @@ def test_argument_and_protocol_errors():
         assert m.result() > 0
         with pytest.raises(device.DeviceError):
             m.encode([t, t], assembling_shard=2)
+
+
+def test_nan_sample_is_an_api_error_also_on_the_first_frame_whose_peer_reads_are_being_verified():
+    import torch
+    from hydrium_amd import device, synth
+
+    host = synth.make_image_f32("photo", 4100, 4100).copy()
+    host[2050, 2050, 1] = np.nan
+    t = torch.from_numpy(host).cuda()
+    with device.MultiFrame([0, 0, 0], 4100, 4100) as m:
+        m.encode([t, t, t], assembling_shard=0)
+        with pytest.raises(device.DeviceError, match="NaN") as ei:
+            m.result()
+        assert ei.value.code == -13 or "NaN" in str(ei.value)

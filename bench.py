@@ -785,7 +785,7 @@ def api_multi_device_leg(ndev, size=16384):
         env = dict(os.environ, PYTHONPATH=ROOT, HYDAMD_DEVICES=devices, HYDAMD_VERIFY_PEERS=str(verify))
         for k in ("HYDAMD_DEVICE", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
             env.pop(k, None)
-        r = subprocess.run([sys.executable, "-c", _MULTI_DEVICE_CLIENT, str(size), str(verify)], capture_output=True, text=True, env=env, timeout=600)
+        r = subprocess.run([sys.executable, "-c", _MULTI_DEVICE_CLIENT, str(size), str(verify)], capture_output=True, text=True, env=env, timeout=300)
         line = next((l for l in r.stdout.splitlines() if l.startswith("RESULT ")), None)
         if r.returncode or not line:
             out["error" if not verify else "verify_error"] = (r.stderr or r.stdout)[-400:]
@@ -851,7 +851,7 @@ def shard_inprocess_leg(ndev, size=16384, steps=40):
     env = dict(os.environ, PYTHONPATH=ROOT)
     for k in ("HYDAMD_DEVICE", "HYDAMD_DEVICES", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, "-c", _INPROCESS_CLIENT, str(ndev), str(size), str(steps)], capture_output=True, text=True, env=env, timeout=900)
+    r = subprocess.run([sys.executable, "-c", _INPROCESS_CLIENT, str(ndev), str(size), str(steps)], capture_output=True, text=True, env=env, timeout=300)
     line = next((l for l in r.stdout.splitlines() if l.startswith("RESULT ")), None)
     if r.returncode or not line:
         return {"error": (r.stderr or r.stdout)[-400:]}
@@ -1467,6 +1467,22 @@ def main():
                     out["content"][kind] = content_row(args, kind, local)
                 except Exception as exc:
                     out["content"][kind] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host_img)
+            if "api_end_to_end" in out and "md5" in out["cpu_baseline"]:
+                out["api_end_to_end"]["identical_to_cpu_reference"] = out["cpu_baseline"]["md5"] == out["api_end_to_end"]["md5"]
+            if timed_files and "md5" in out["cpu_baseline"]:
+                timed_files["identical_to_cpu_reference"] = timed_files["md5"] == out["cpu_baseline"]["md5"]
+    # tear down first, print last: RCCL writes its version banner to stdout when the process group goes away,
+    # and the line the driver parses should be the final one
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    # Rank 0's two multi-device legs run in processes of their own over EVERY GPU of the job.  They come after the process group is
+    # gone: the other ranks are not held in a collective meanwhile (a leg that hangs on hardware it has never met would run the
+    # group's watchdog out and take the headline with it), and at --gpus N their GPUs are idle when rank 0's subprocess takes them.
+    if rank == 0:
         if not args.no_legs and not args.no_api:
             # the C library's own multi-device scheduler, over every GPU of the job (one GPU: an aliased list), once, on rank 0
             try:
@@ -1483,19 +1499,8 @@ def main():
                     out["shard_16k_inprocess"]["same_file_as_shard_16k"] = out["shard_16k_inprocess"]["frame_md5"] == out["shard_16k"]["frame_md5"]
             except Exception as exc:
                 out["shard_16k_inprocess"] = {"error": f"{type(exc).__name__}: {exc}"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host_img)
-            if "api_end_to_end" in out and "md5" in out["cpu_baseline"]:
-                out["api_end_to_end"]["identical_to_cpu_reference"] = out["cpu_baseline"]["md5"] == out["api_end_to_end"]["md5"]
-            if timed_files and "md5" in out["cpu_baseline"]:
-                timed_files["identical_to_cpu_reference"] = timed_files["md5"] == out["cpu_baseline"]["md5"]
-    # tear down first, print last: RCCL writes its version banner to stdout when the process group goes away,
-    # and the line the driver parses should be the final one
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
+        if "cpu_baseline" in out:  # (the reported baseline stays the line's last object)
+            out["cpu_baseline"] = out.pop("cpu_baseline")
         emit(out)
 
 

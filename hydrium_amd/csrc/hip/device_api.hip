@@ -101,6 +101,17 @@ namespace {
 
 constexpr int kStaging = 2;
 constexpr int kSplitSlots = 2; /* transform launches of at most this many LF groups split every group over four workgroups */
+/* HYDAMD_K1_SPLIT_SLOTS=n (A/B knob, bytes unchanged): launches of up to n LF groups are split instead — n = 32 makes the
+ * pipelined loop's transform workgroups last a quarter as long (round 6: does a chain workgroup that waits for 80 KB of one
+ * compute unit's LDS start sooner when the transform workgroups around it retire four times as often?) */
+int split_slots() {
+    static const int n = [] {
+        const char *e = getenv("HYDAMD_K1_SPLIT_SLOTS");
+        const int v = e ? atoi(e) : kSplitSlots;
+        return v < 0 ? 0 : v > 256 ? 256 : v;
+    }();
+    return n;
+}
 constexpr size_t kDbgPlane = (size_t)2048 * 2048;
 
 char g_global_error[256] = "";
@@ -894,7 +905,7 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
         ctx->lf_hist = ctx->accum + hist_words + head_words;
     }
     HIP_TRY(ctx, hipMalloc(&ctx->sym_count, slots * G * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->part_info, (size_t)kSplitSlots * G * 4 * sizeof(uint2)));
+    HIP_TRY(ctx, hipMalloc(&ctx->part_info, (size_t)(split_slots() > kSplitSlots ? split_slots() : kSplitSlots) * G * 4 * sizeof(uint2)));
     HIP_TRY(ctx, hipMalloc(&ctx->group_bits, slots * G * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->offsets, slots * G * sizeof(uint64_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->total, sizeof(uint64_t)));
@@ -1318,7 +1329,8 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
      * Such launches split every group over four workgroups (eight strips each; k_join_parts closes the token array up):
      * HYDAMD_K1_SPLIT=0 for A/B */
     static const bool split_on = !(getenv("HYDAMD_K1_SPLIT") && atoi(getenv("HYDAMD_K1_SPLIT")) == 0);
-    const int plog = split_on && count <= kSplitSlots && ctx->tok_cap % 64 == 0 ? 2 : 0;
+    static const int split_log = getenv("HYDAMD_K1_SPLIT_LOG") && atoi(getenv("HYDAMD_K1_SPLIT_LOG")) == 1 ? 1 : 2;
+    const int plog = split_on && count <= split_slots() && ctx->tok_cap % 64 == 0 ? split_log : 0;
     HIP_TRY(ctx, hydk::launch_transform(ctx->d_jobs + first, count, mask, xmode, ctx->status, ctx->part_info, plog, ctx->stream));
     return ST_OK;
 }

@@ -97,6 +97,14 @@ constexpr int kThreads = 256;
 #ifndef HYDK_CHAIN_PRIO
 #define HYDK_CHAIN_PRIO 3
 #endif
+/*   HYDK_LANE_TAB_GLOBAL  1: the lane-form chain looks its slots up in the table kernel's output where it lies (global memory,
+ *                      L2-resident: 72 KB per LF group) instead of a copy in LDS: the workgroup holds 6 KB of LDS (operand rows)
+ *                      where it held 80, a step waits for an L2 round trip where it waited for LDS.  Round 6: the stand-in
+ *                      that issues a chain's instructions and holds NO LDS costs the pipelined loop 8 % where the chains
+ *                      cost 20 (profiles/r06_chain_probes.txt) — what is that worth when the step is the real one, 2-3 x slower? */
+#ifndef HYDK_LANE_TAB_GLOBAL
+#define HYDK_LANE_TAB_GLOBAL 0
+#endif
 /*   HYDK_CHAIN_HOG     1: a chain wavefront names accumulation register a255, so that it is allocated 256 of them on top of its
  *                      vector registers and no transform wavefront (120) fits beside it on its SIMD: the chain keeps its
  *                      SIMD's issue port to itself, the transform workgroups of its compute unit live on the other three */
@@ -1790,6 +1798,19 @@ struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs
     uint32_t tab;   /* LDS byte address of the symbol's slot list (u16 per remainder) */
 };
 
+/* the slot table: in LDS (ds_read_u16, the step's wait is for the LDS counter) or where the table kernel left it
+ * (HYDK_LANE_TAB_GLOBAL: global_load_ushort with the table's base in a scalar pair and the row's byte offset in tab; the
+ * step's wait is for the vector-memory counter — loads return in order, so it also waits for whatever line of records was
+ * requested before the lookup) */
+#if HYDK_LANE_TAB_GLOBAL
+#define HYDK_LANE_LOOKUP "global_load_ushort %[sln], %[t1], %[gb]\n\t"
+#define HYDK_LANE_WAIT "s_waitcnt vmcnt(0)"
+#define HYDK_LANE_GB , [gb] "s"(gtab)
+#else
+#define HYDK_LANE_LOOKUP "ds_read_u16 %[sln], %[t1]\n\t"
+#define HYDK_LANE_WAIT "s_waitcnt lgkmcnt(0)"
+#define HYDK_LANE_GB
+#endif
 /* request of the slot of (symbol with operands mg / nf / tab, renormalised state x) */
 #define HYDK_LANE_ASM_CORE                                                                                       \
     "v_mul_hi_u32 %[q], %[x], %[mg]\n\t"                                                                         \
@@ -1797,7 +1818,7 @@ struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs
     "v_add_co_u32 %[t1], vcc, %[t0], %[nf]\n\t"  /* r0 - f; carry: r0 >= f, the quotient is one short */          \
     "v_min_u32 %[t0], %[t0], %[t1]\n\t"          /* x mod f */                                                    \
     "v_lshl_add_u32 %[t1], %[t0], 1, %[tab]\n\t"                                                                 \
-    "ds_read_u16 %[sln], %[t1]\n\t"
+    HYDK_LANE_LOOKUP
 /* behind the request: the repaired quotient, the new state without its slot, the NEXT symbol's refill test on it */
 #define HYDK_LANE_ASM_SHADOW                                                                                     \
     "v_addc_co_u32 %[q], vcc, 0, %[q], vcc\n\t"                                                                  \
@@ -1806,7 +1827,7 @@ struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs
     "v_cndmask_b32_sdwa %[B], %[A], %[A], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t" \
     "v_cndmask_b32_e64 %[sm], %[k0fff], 0, vcc\n\t"                                                              \
     "v_addc_co_u32 %[fl], vcc, %[fl], %[fl], vcc\n\t"                                                            \
-    "s_waitcnt lgkmcnt(0)"
+    HYDK_LANE_WAIT
 #define HYDK_LANE_ASM_SDWA_SELECT "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
 /* round 6's step (HYDK_LANE_STEP 2).  Between two steps of a round the walk carries A = (q + fix) << 12 (the state without
  * its slot), sl = the slot (arriving from LDS) and rf = the NEXT symbol's refill decision as a lane mask in a scalar register
@@ -1823,7 +1844,7 @@ struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs
     "v_lshlrev_b32 %[A], 12, %[q]\n\t"                                                                           \
     "v_cmp_gt_u32_e64 %[rfn], %[A], %[thrn]\n\t"                                                                 \
     "v_addc_co_u32_e64 %[fl], %[junk], %[fl], %[fl], %[rfn]\n\t"                                                 \
-    "s_waitcnt lgkmcnt(0)"
+    HYDK_LANE_WAIT
 
 template <int NC> /* NC: clusters per preset of the frame's clustering scheme (9 / 3 / 2 / 1): the tables' size in LDS */
 __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
@@ -1837,7 +1858,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
      * (profiles/r04_pipeline_bounds.txt, r05_pipeline_bounds.txt).  The tables are sized by the frame's clustering scheme
      * (a 16384^2 frame has 3 clusters per preset: 26 KB, not 80). */
     constexpr int kOpsBytes = NC * kLaneTokens * (int)sizeof(uint4);
-    constexpr int kTabBytes = 2 * NC * HYDK_ANS_SLOTS;
+    constexpr int kTabBytes = HYDK_LANE_TAB_GLOBAL ? 0 : 2 * NC * HYDK_ANS_SLOTS;
     constexpr int kLdsBytes = kOpsBytes + kTabBytes > (int)sizeof(LfHuffScratch) ? kOpsBytes + kTabBytes : (int)sizeof(LfHuffScratch);
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kLdsBytes];
     uint4 *const s_ops = (uint4 *)s_mem;
@@ -1864,10 +1885,14 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
         return; /* the transform stage ran out of token space: the host reruns the frame */
     typedef __attribute__((address_space(3))) const uint16_t LdsU16;
     {
+#if HYDK_LANE_TAB_GLOBAL
+        const uint32_t tab_lds = 0; /* a row's byte offset from the table's base, which the lookups take from a scalar pair */
+#else
         const uint4 *src = (const uint4 *)&tab->inv1[0][0];
         for (int i = lane; i < NC * HYDK_ANS_SLOTS / 8; i += 64)
             ((uint4 *)s_tab)[i] = src[i];
         const uint32_t tab_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_tab;
+#endif
         for (int i = lane; i < NC * kLaneTokens; i += 64) {
             const int c = i / kLaneTokens, at = c * HYDK_ALPHABET + i % kLaneTokens;
             const uint32_t fbv = (&tab->fb[0][0])[at], f = fbv & 0xFFFFu;
@@ -1880,6 +1905,11 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
         }
     }
     __syncthreads();
+#if HYDK_LANE_TAB_GLOBAL
+    /* wave-uniform: lives in a scalar register pair */
+    const unsigned long long gtab = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&tab->inv1[0][0]) |
+                                    (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)&tab->inv1[0][0] >> 32)) << 32;
+#endif
     const size_t G = (size_t)slot * HYDK_GROUPS_PER_LFG + lane;
     const int n = lane < ngroups ? (int)sym_count_all[G] : 0;
     /* 4-byte records, 4 per uint4 (tok_cap is a multiple of 16: rounds never straddle a group's array) */
@@ -1904,6 +1934,13 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
     for (int q = 0; q < 4; q++)
         nx[q] = rj >= 0 ? load_records4(tok, rj * 4 + q) : uint4{0, 0, 0, 0};
 
+/* a position beyond the stream's end walks with row 0's operands, whose symbol may never have occurred (f = 0: the "remainder"
+ * is the state itself): an LDS read past the end returns 0, a global one must not be made */
+#if HYDK_LANE_TAB_GLOBAL
+#define HYDK_LANE_COLD_SLOT(off, VALID) ((uint32_t) * HYDK_GLOBAL(const uint16_t, (const char *)(uintptr_t)gtab + ((VALID) ? (off) : 0u)))
+#else
+#define HYDK_LANE_COLD_SLOT(off, VALID) ((uint32_t) * (LdsU16 *)(uintptr_t)(off))
+#endif
 /* one symbol the plain way (the first, partial round of a lane): the step only counts if VALID */
 #define HYDK_LANE_STEP_COLD(o, pos, VALID)                                                                       \
     do {                                                                                                         \
@@ -1927,7 +1964,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
             : "=&v"(r1), "=v"(q1)                                                                                \
             : "v"(r0), "v"(o.z), "v"(q)                                                                          \
             : "vcc");                                                                                            \
-        const uint32_t nstate = (q1 << 12) | (uint32_t) * (LdsU16 *)(uintptr_t)(o.w + 2u * min(r0, r1));        \
+        const uint32_t nstate = (q1 << 12) | HYDK_LANE_COLD_SLOT(o.w + 2u * min(r0, r1), VALID);                \
         state = (VALID) ? nstate : state;                                                                        \
     } while (0)
 
@@ -1941,7 +1978,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
                      "v_addc_co_u32 %[fl], vcc, %[fl], %[fl], vcc\n\t" HYDK_LANE_ASM_CORE HYDK_LANE_ASM_SHADOW   \
                      : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [A] "=&v"(A), \
                        [B] "=&v"(B), [sm] "=&v"(sm), [fl] "+v"(fl)                                               \
-                     : [st] "v"(state), [thr] "v"(o.x), [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w), [thrn] "v"(on.x), \
+                     : [st] "v"(state), [thr] "v"(o.x), [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w) HYDK_LANE_GB, [thrn] "v"(on.x), \
                        [k0fff] "v"(k0fff)                                                                        \
                      : "vcc");                                                                                   \
         so = state; /* position 15 is odd: filed together with position 14's */                                  \
@@ -1957,7 +1994,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
                          : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
                            [A] "=&v"(An), [B] "=&v"(Bn), [sm] "=&v"(smn), [fl] "+v"(fl)                          \
                          : [sl] "v"(sl), [smi] "v"(sm), [Bi] "v"(B), [Ai] "v"(A), [mg] "v"(o.y), [nf] "v"(o.z),   \
-                           [tab] "v"(o.w), [thrn] "v"(on.x), [k0fff] "v"(k0fff)                                  \
+                           [tab] "v"(o.w) HYDK_LANE_GB, [thrn] "v"(on.x), [k0fff] "v"(k0fff)                                  \
                          : "vcc");                                                                               \
             so = st;                                                                                             \
         } else {                                                                                                 \
@@ -1967,7 +2004,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
                          : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
                            [w] "=&v"(w16[(pos) >> 1]), [A] "=&v"(An), [B] "=&v"(Bn), [sm] "=&v"(smn), [fl] "+v"(fl) \
                          : [sl] "v"(sl), [smi] "v"(sm), [Bi] "v"(B), [Ai] "v"(A), [so] "v"(so), [ksel] "v"(ksel), \
-                           [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w), [thrn] "v"(on.x), [k0fff] "v"(k0fff)    \
+                           [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w) HYDK_LANE_GB, [thrn] "v"(on.x), [k0fff] "v"(k0fff)    \
                          : "vcc");                                                                               \
         }                                                                                                        \
         A = An;                                                                                                  \
@@ -1984,12 +2021,12 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
                      "v_perm_b32 %[w], %[so], %[st], %[ksel]\n\t"                                                \
                      "v_addc_co_u32 %[q], vcc, 0, %[q], vcc\n\t"                                                 \
                      "v_lshlrev_b32 %[A], 12, %[q]\n\t"                                                          \
-                     "s_waitcnt lgkmcnt(0)\n\t"                                                                  \
+                     HYDK_LANE_WAIT "\n\t"                                                                       \
                      "v_or_b32 %[state], %[A], %[sln]"                                                           \
                      : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
                        [w] "=&v"(w16[0]), [A] "=&v"(An), [state] "=&v"(state)                                    \
                      : [sl] "v"(sl), [smi] "v"(sm), [Bi] "v"(B), [Ai] "v"(A), [so] "v"(so), [ksel] "v"(ksel),     \
-                       [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w)                                              \
+                       [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w) HYDK_LANE_GB                                              \
                      : "vcc");                                                                                   \
     } while (0)
 
@@ -2004,7 +2041,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
                      "v_addc_co_u32 %[fl], vcc, %[fl], %[fl], vcc\n\t" HYDK_LANE_ASM_CORE HYDK_LANE2_SHADOW      \
                      : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [A] "=&v"(A), \
                        [rfn] "=&s"(rfn), [junk] "=&s"(junk), [fl] "+v"(fl)                                       \
-                     : [st] "v"(state), [thr] "v"(o.x), [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w), [thrn] "v"(on.x) \
+                     : [st] "v"(state), [thr] "v"(o.x), [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w) HYDK_LANE_GB, [thrn] "v"(on.x) \
                      : "vcc");                                                                                   \
         so = state; /* position 15 is odd: filed together with position 14's */                                  \
         sl = sln;                                                                                                \
@@ -2019,7 +2056,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
             asm volatile(HYDK_LANE2_TAKE HYDK_LANE_ASM_CORE HYDK_LANE2_SHADOW                                    \
                          : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
                            [A] "=&v"(An), [rfn] "=&s"(rfn), [junk] "=&s"(junk), [fl] "+v"(fl)                    \
-                         : [sl] "v"(sl), [Ai] "v"(A), [rf] "s"(rf), [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w), \
+                         : [sl] "v"(sl), [Ai] "v"(A), [rf] "s"(rf), [mg] "v"(o.y), [nf] "v"(o.z), [tab] "v"(o.w) HYDK_LANE_GB, \
                            [thrn] "v"(on.x)                                                                      \
                          : "vcc");                                                                               \
             so = st;                                                                                             \
@@ -2029,7 +2066,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
                          : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
                            [w] "=&v"(w16[(pos) >> 1]), [A] "=&v"(An), [rfn] "=&s"(rfn), [junk] "=&s"(junk), [fl] "+v"(fl) \
                          : [sl] "v"(sl), [Ai] "v"(A), [rf] "s"(rf), [so] "v"(so), [ksel] "v"(ksel), [mg] "v"(o.y), \
-                           [nf] "v"(o.z), [tab] "v"(o.w), [thrn] "v"(on.x)                                       \
+                           [nf] "v"(o.z), [tab] "v"(o.w) HYDK_LANE_GB, [thrn] "v"(on.x)                                       \
                          : "vcc");                                                                               \
         }                                                                                                        \
         A = An;                                                                                                  \
@@ -2044,12 +2081,12 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
                      "v_perm_b32 %[w], %[so], %[st], %[ksel]\n\t"                                                \
                      "v_addc_co_u32 %[q], vcc, 0, %[q], vcc\n\t"                                                 \
                      "v_lshlrev_b32 %[A], 12, %[q]\n\t"                                                          \
-                     "s_waitcnt lgkmcnt(0)\n\t"                                                                  \
+                     HYDK_LANE_WAIT "\n\t"                                                                       \
                      "v_or_b32 %[state], %[A], %[sln]"                                                           \
                      : [x] "=&v"(x), [q] "=&v"(q), [t0] "=&v"(t0), [t1] "=&v"(t1), [sln] "=&v"(sln), [st] "=&v"(st), \
                        [w] "=&v"(w16[0]), [A] "=&v"(An), [state] "=&v"(state)                                    \
                      : [sl] "v"(sl), [Ai] "v"(A), [rf] "s"(rf), [so] "v"(so), [ksel] "v"(ksel), [mg] "v"(o.y),    \
-                       [nf] "v"(o.z), [tab] "v"(o.w)                                                             \
+                       [nf] "v"(o.z), [tab] "v"(o.w) HYDK_LANE_GB                                                             \
                      : "vcc");                                                                                   \
     } while (0)
 #endif /* HYDK_LANE_STEP */
@@ -2261,6 +2298,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__
 #undef HYDK_LANE_STEP_BODY
 #undef HYDK_LANE_STEP_HEAD
 #undef HYDK_LANE_STEP_COLD
+#undef HYDK_LANE_COLD_SLOT
     if (lane < ngroups) {
         final_state_all[G] = state;
         /* [preset id][final state][per symbol: refill word, residue bits] (encoder.c:945, entropy.c:1127-1147) */

@@ -8,4 +8,5 @@ python scripts/k1_variants.py --build base= \
   k1c0=-DHYDK_K1_PRIO=1,-DHYDK_CHAIN_PRIO=0 k2c0=-DHYDK_K1_PRIO=2,-DHYDK_CHAIN_PRIO=0 k3c0=-DHYDK_K1_PRIO=3,-DHYDK_CHAIN_PRIO=0 k3c2=-DHYDK_K1_PRIO=3,-DHYDK_CHAIN_PRIO=2 \
   ls1=-DHYDK_LANE_STEP=1 ls2=-DHYDK_LANE_STEP=2 \
   q32=-DHYDK_CHAIN_PROBE=32 hog=-DHYDK_CHAIN_HOG=1 \
-  r5=-DHYDK_LANE_PIPE=0,-DHYDK_LANE_STEP=1 pp1=-DHYDK_LANE_PIPE=1 pp2=-DHYDK_LANE_PIPE=2 pp2s2=-DHYDK_LANE_PIPE=2,-DHYDK_LANE_STEP=2
+  r5=-DHYDK_LANE_PIPE=0,-DHYDK_LANE_STEP=1 pp1=-DHYDK_LANE_PIPE=1 pp2=-DHYDK_LANE_PIPE=2 pp2s2=-DHYDK_LANE_PIPE=2,-DHYDK_LANE_STEP=2 \
+  gt=-DHYDK_LANE_TAB_GLOBAL=1 gt1=-DHYDK_LANE_TAB_GLOBAL=1,-DHYDK_LANE_PIPE=1

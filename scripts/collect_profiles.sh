@@ -9,13 +9,13 @@
 #                                                                     r06 chain_probes pmc
 # One target per file under profiles/ (the name after the tag): bench_default, kernel_stats (single, single_form4, pipe, shard,
 # api + api_timeline), tile_mode, k1_content, pipeline_bounds, chain_probes, priorities, lane_step, lane_pipe, loop_stage_times,
-# emit_share, icache, pmc_8k_photo, fuzz.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
+# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
 # The probes that skip stages or run stand-in kernels load hydrium_amd/lib/libhydrium_probe.so (HYD_TEST_HOOKS flavour;
 # scripts/pipe_probe.py selects it) or a variant built by `python scripts/k1_variants.py --build ...` (chain_probes and
 # priorities build theirs HERE, before the gpurun call: hipcc cross-compiles, the .so files travel with the snapshot).
 set -u
 tag=$1; shift
-targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo} "
+targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain} "
 want() { [[ "$targets" == *" $1 "* ]]; }
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -170,6 +170,45 @@ fi
 #   python scripts/k1_variants.py --build r5=-DHYDK_LANE_PIPE=0,-DHYDK_LANE_STEP=1 pp1=-DHYDK_LANE_PIPE=1 pp2=-DHYDK_LANE_PIPE=2 pp2s2=-DHYDK_LANE_PIPE=2,-DHYDK_LANE_STEP=2
 if want lane_pipe; then
 run lane_pipe txt bash -c 'echo "# the lane-form chain: round 5 (r5) against two buffers taking turns (pp1), two pairs with the lines two rounds ahead (pp2; pp2s2: with the 11.5-instruction step); kernels alone, bytes, the photo loop and the noise loop, alternating on one box; commit $(cat .commit 2>/dev/null)"; K1V_NOISE=1 python scripts/k1_variants.py --run --rounds 3 --pipe r5 pp1 pp2 pp2s2'
+fi
+
+# transform workgroups that last a quarter / half as long in the pipelined loop (HYDAMD_K1_SPLIT_SLOTS=32: every launch of the loop is
+# split as the one- and two-LF-group launches are, k_join_parts behind it): does a chain workgroup find its 80 KB sooner?
+if want split_loop; then
+run split_loop txt bash -c '
+  eval "$PIPE_PROBE"
+  echo "# HYDAMD_K1_SPLIT_SLOTS=32 (every transform launch of the loop split over 4 or 2 workgroups per group + k_join_parts), the pipelined loop, sustained Gpixel/s, alternating; commit $(cat .commit 2>/dev/null)"
+  for i in 1 2 3; do
+    echo -n "default:            "; p
+    echo -n "split 32, 4 parts:  "; HYDAMD_K1_SPLIT_SLOTS=32 p
+    echo -n "split 32, 2 parts:  "; HYDAMD_K1_SPLIT_SLOTS=32 HYDAMD_K1_SPLIT_LOG=1 p
+  done
+'
+fi
+
+# the lane-form chain with its slot tables read where the table kernel leaves them (L2) instead of a copy in LDS (kernels.hip
+# HYDK_LANE_TAB_GLOBAL: 6 KB of LDS per chain workgroup instead of 80)
+#   python scripts/k1_variants.py --build base= gt=-DHYDK_LANE_TAB_GLOBAL=1 gt1=-DHYDK_LANE_TAB_GLOBAL=1,-DHYDK_LANE_PIPE=1
+if want gt_chain; then
+run gt_chain txt bash -c '
+  V=$PWD/scripts/probe_build
+  pp() { python scripts/pipe_probe.py --frames 512 --rans 5 --reps 2 "$@" 2>&1 | grep -E "SUSTAINED|stage times|rror" | sed "s/.*: //" | tr "\n" " "; echo; }
+  echo "# the lane-form chain with slot tables in L2 (gt; gt1: with HYDK_LANE_PIPE 1) against the product chain (base): kernels alone, bytes, the loop; commit $(cat .commit 2>/dev/null)"
+  python scripts/k1_variants.py --run --rounds 2 --pipe base gt gt1
+  echo "# the loop by frames per launch group and streams (scripts/pipe_probe.py, sustained Gpixel/s)"
+  for b in 2 4 8; do for s in 16 22; do
+    echo -n "base streams $s batch $b: "; HYDAMD_LIB=$V/k1v_base.so pp --streams $s --batch $b
+    echo -n "gt   streams $s batch $b: "; HYDAMD_LIB=$V/k1v_gt.so pp --streams $s --batch $b
+  done; done
+  echo "# stage times in the loop (library event timers, context 0), four frames per launch group"
+  for n in base gt; do echo "$n:"; HYDAMD_LIB=$V/k1v_$n.so python scripts/pipe_probe.py --streams 16 --batch 4 --frames 256 --rans 5 --reps 1 --profile 1 2>&1 | grep -E "SUSTAINED|stage times|rror"; done
+  echo "# the same with the transform kernel s curve gather off (HYDAMD_CURVE_GATHERS=2: the texture path left to the chains)"
+  export HYDAMD_CURVE_GATHERS=2
+  for b in 2 4; do
+    echo -n "base streams 16 batch $b: "; HYDAMD_LIB=$V/k1v_base.so pp --streams 16 --batch $b
+    echo -n "gt   streams 16 batch $b: "; HYDAMD_LIB=$V/k1v_gt.so pp --streams 16 --batch $b
+  done
+'
 fi
 
 # the emit kernel as fewer, fatter workgroups (HYDAMD_EMIT_SHARE virtual blocks per workgroup): does a small kernel wait for its

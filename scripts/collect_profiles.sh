@@ -9,13 +9,13 @@
 #                                                                     r06 chain_probes pmc
 # One target per file under profiles/ (the name after the tag): bench_default, kernel_stats (single, single_form4, pipe, shard,
 # api + api_timeline), tile_mode, k1_content, pipeline_bounds, chain_probes, priorities, lane_step, lane_pipe, loop_stage_times,
-# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
+# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
 # The probes that skip stages or run stand-in kernels load hydrium_amd/lib/libhydrium_probe.so (HYD_TEST_HOOKS flavour;
 # scripts/pipe_probe.py selects it) or a variant built by `python scripts/k1_variants.py --build ...` (chain_probes and
 # priorities build theirs HERE, before the gpurun call: hipcc cross-compiles, the .so files travel with the snapshot).
 set -u
 tag=$1; shift
-targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain} "
+targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms} "
 want() { [[ "$targets" == *" $1 "* ]]; }
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -207,6 +207,20 @@ run gt_chain txt bash -c '
   for b in 2 4; do
     echo -n "base streams 16 batch $b: "; HYDAMD_LIB=$V/k1v_base.so pp --streams 16 --batch $b
     echo -n "gt   streams 16 batch $b: "; HYDAMD_LIB=$V/k1v_gt.so pp --streams 16 --batch $b
+  done
+'
+fi
+
+# the noise loop by entropy-stage form (VERDICT r5 task 7: would the wave form, faster alone on long groups, serve a chain-bound loop?)
+if want noise_forms; then
+run noise_forms txt bash -c '
+  n() { python bench.py --kind noise --steps 48 --no-cpu-baseline --no-api --no-legs --no-content "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d[\"value\"]/1e3,1), \"Gpixel/s\", d[\"timing\"][\"Mpixel/s_each_window\"])"; }
+  echo "# the noise loop (8192^2 RGB16 random pixels, 2.86 symbols per pixel) by entropy-stage form: 5 = one lane per group (79.5 KB of LDS per LF group), 4 = one wave per group (144 KB per workgroup of four groups); bench.py --kind noise; commit $(cat .commit 2>/dev/null)"
+  for i in 1 2; do
+    echo -n "lane form, 16 streams x 2: "; n --rans-waves 5
+    echo -n "wave form, 16 streams x 2: "; n --rans-waves 4
+    echo -n "wave form, 16 streams x 1: "; n --rans-waves 4 --frames-per-launch 1
+    echo -n "wave form,  8 streams x 2: "; n --rans-waves 4 --streams 8
   done
 '
 fi

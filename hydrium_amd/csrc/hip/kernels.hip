@@ -105,6 +105,12 @@ constexpr int kThreads = 256;
 #ifndef HYDK_LANE_TAB_GLOBAL
 #define HYDK_LANE_TAB_GLOBAL 0
 #endif
+/*   HYDK_LANE_NC9_PROBE  timing only (wrong bytes; run with the emit stage off): a nine-cluster frame's chains run the instance
+ *                      that holds tables for this many clusters — 7: 61.8 KB, 6: 53 KB, 4: 35 KB instead of 79.5 — : what would a
+ *                      chain be worth beside which THREE transform workgroups fit (160 KB - 3 x 31.25 = 66 KB)? */
+#ifndef HYDK_LANE_NC9_PROBE
+#define HYDK_LANE_NC9_PROBE 9
+#endif
 /*   HYDK_CHAIN_HOG     1: a chain wavefront names accumulation register a255, so that it is allocated 256 of them on top of its
  *                      vector registers and no transform wavefront (120) fits beside it on its SIMD: the chain keeps its
  *                      SIMD's issue port to itself, the transform workgroups of its compute unit live on the other three */
@@ -2827,7 +2833,7 @@ hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count,
                        group_bits, preset_bits, status, num_slots, lf_hist, lf_streams, lf_work)
     /* the tables in LDS are sized by the clustering scheme (encoder.c:862-901: 9 / 3 / 2 / 1 clusters per preset) */
     if (nclusters == 9)
-        HYDK_LAUNCH_LANES(9);
+        HYDK_LAUNCH_LANES(HYDK_LANE_NC9_PROBE);
     else if (nclusters == 3)
         HYDK_LAUNCH_LANES(3);
     else if (nclusters == 2)

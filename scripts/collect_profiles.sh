@@ -9,13 +9,13 @@
 #                                                                     r06 chain_probes pmc
 # One target per file under profiles/ (the name after the tag): bench_default, kernel_stats (single, single_form4, pipe, shard,
 # api + api_timeline), tile_mode, k1_content, pipeline_bounds, chain_probes, priorities, lane_step, lane_pipe, loop_stage_times,
-# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
+# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms, nc_probe.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
 # The probes that skip stages or run stand-in kernels load hydrium_amd/lib/libhydrium_probe.so (HYD_TEST_HOOKS flavour;
 # scripts/pipe_probe.py selects it) or a variant built by `python scripts/k1_variants.py --build ...` (chain_probes and
 # priorities build theirs HERE, before the gpurun call: hipcc cross-compiles, the .so files travel with the snapshot).
 set -u
 tag=$1; shift
-targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms} "
+targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms nc_probe} "
 want() { [[ "$targets" == *" $1 "* ]]; }
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -222,6 +222,19 @@ run noise_forms txt bash -c '
     echo -n "wave form, 16 streams x 1: "; n --rans-waves 4 --frames-per-launch 1
     echo -n "wave form,  8 streams x 2: "; n --rans-waves 4 --streams 8
   done
+'
+fi
+
+# timing only: what would a chain holding fewer kilobytes be worth (kernels.hip HYDK_LANE_NC9_PROBE)?
+#   python scripts/k1_variants.py --build base= pp1=-DHYDK_LANE_PIPE=1 pp1n7=-DHYDK_LANE_PIPE=1,-DHYDK_LANE_NC9_PROBE=7 pp1n4=-DHYDK_LANE_PIPE=1,-DHYDK_LANE_NC9_PROBE=4 pp2n7=-DHYDK_LANE_NC9_PROBE=7 pp2n4=-DHYDK_LANE_NC9_PROBE=4
+if want nc_probe; then
+run nc_probe txt bash -c '
+  eval "$PIPE_PROBE"
+  v() { HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$1.so; export HYDAMD_LIB; shift; "$@"; unset HYDAMD_LIB; }
+  echo "# timing only: a nine-cluster frame s chains holding tables for 7 / 4 clusters (61.8 / 35 KB instead of 79.5), with the chain at 128 registers (HYDK_LANE_PIPE 1: three transform wavefronts fit beside it on its SIMD) and at 164 (PIPE 2: two); the pipelined loop without scan + emit (HYDAMD_DEBUG_SKIP=4), sustained Gpixel/s; commit $(cat .commit 2>/dev/null)"
+  for i in 1 2; do for n in base pp1 pp1n7 pp1n4 pp2n7 pp2n4; do echo -n "$n (skip 4): "; HYDAMD_DEBUG_SKIP=4 v $n p; done; done
+  echo "# the chain kernels alone"
+  python scripts/k1_variants.py --run --rounds 1 base pp1 pp1n7 pp1n4 pp2n7 pp2n4 | grep -v "^$"
 '
 fi
 

@@ -374,3 +374,35 @@ print("ok")
     env.pop("HYDAMD_PAYLOAD_CAP", None)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("split_log", [2, 1])
+def test_splitting_every_transform_launch_never_changes_a_byte(split_log):
+    """HYDAMD_K1_SPLIT_SLOTS=n splits the transform launches of up to n LF groups over four (HYDAMD_K1_SPLIT_LOG=1: two)
+    workgroups per group, as one- and two-LF-group launches always are (k_join_parts closes the token arrays up): an A/B knob
+    of the pipelined loop (profiles/r06_split_loop.txt).  A frame of four LF groups, ragged edges, both sample depths: sections
+    and coded LF streams equal to the unsplit launch's, which equals the oracle's (every other test of this file)."""
+    import subprocess
+    import sys
+
+    code = """
+import hashlib, sys, torch
+from hydrium_amd import device, synth
+out = []
+for depth in (8, 16):
+    img = synth.make_image("photo", 2300, 2100, depth)
+    t = torch.from_numpy(img.view("int16").copy() if depth == 16 else img).cuda()
+    with device.DeviceContext(0, 4, 0) as ctx:
+        ctx.set_rans_waves(5)
+        ctx.encode_image_tensor(t); ctx.sync()
+        out.append(hashlib.md5(ctx.read_payload()).hexdigest())
+        assert ctx.overflow_reruns() == 0
+print("MD5 " + " ".join(out))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, extra in (("plain", {"HYDAMD_K1_SPLIT_SLOTS": "0"}), ("split", {"HYDAMD_K1_SPLIT_SLOTS": "32", "HYDAMD_K1_SPLIT_LOG": str(split_log)})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=root, **extra), timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got[name] = next(l for l in r.stdout.splitlines() if l.startswith("MD5 "))
+    assert got["plain"] == got["split"]

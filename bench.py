@@ -155,6 +155,49 @@ def check_world(args, dist, device=None):
     return ranks
 
 
+# what a leg's result keeps in the frame-mode line
+LEG_KEYS = ("value", "unit", "ms_per_step", "frames_per_s", "n_gpus", "rccl_ranks", "steps", "scaling", "config", "frame_bytes", "frame_md5",
+            "frames_checked", "assembled_frames_identical_to_host_assembly", "host_ms_per_frame", "frac_of_hbm_read_roofline",
+            "frame0_identical_to_reference", "threads_agree_with_single_thread_run", "frames_per_s_each_round", "leg_wall_s", "error",
+            "sections_identical_to_single_context_run", "frames_per_s_one_frame_per_launch_group")
+_RANK_ENV = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+             "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+             "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_ERROR_FILE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "HYDAMD_BENCH_SELF_LAUNCHED",
+             "HYDAMD_DEVICE", "HYDAMD_DEVICES", "HYDAMD_BENCH_FORCE_PG")
+
+
+def child_job(gpus, argv, timeout=300):
+    """A leg of an N-rank job as a JOB OF ITS OWN: `bench.py --gpus N <argv>` started from rank 0 once the main process group
+    is gone, outside any rank environment (it launches its N ranks itself), under a time limit.  A leg that needs every rank —
+    the sharded 16K frame, the 4K batch — must not run inside the job whose headline it accompanies: a rank that fails there
+    leaves the others in a collective, the group's watchdog ends the job, and the line is lost.  -> the child's result line as
+    a dict, or {"error": ...}."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in _RANK_ENV}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(gpus)] + list(argv)
+    import signal
+
+    # a session of its own: on overrun the launcher, torch.distributed.run and every rank go together
+    pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        stdout, stderr = pr.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        pr.communicate()
+        return {"error": f"no result within {timeout} s: {' '.join(cmd)}"}
+    line = next((l for l in reversed(stdout.splitlines()) if l.startswith("{")), None)
+    if line is None:
+        return {"error": f"exit status {pr.returncode}: {(stderr or stdout)[-400:]}"}
+    try:
+        return json.loads(line)
+    except ValueError as exc:
+        return {"error": f"unparsable result line ({exc}): {line[:200]}"}
+
+
 def dry_run_launch(args):
     import torch
     import torch.distributed as dist
@@ -883,7 +926,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     exchange = args.exchange  # per-frame blob export + RCCL gather (also in a world of one, as a self-test)
-    use_dist = world > 1 or exchange  # a process group exists: barriers and the slowest rank's clock
+    # (HYDAMD_BENCH_FORCE_PG=1: a lone rank forms the RCCL group too — what does the group's mere presence, its streams and
+    # their hardware queues, cost the loop?  profiles/r06_pg_presence.txt)
+    use_dist = world > 1 or exchange or os.environ.get("HYDAMD_BENCH_FORCE_PG") == "1"  # a process group exists: barriers and the slowest rank's clock
     FPL = 1 if exchange else max(1, args.frames_per_launch)  # frames per launch group (a batch is not exported as one blob)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP extension has no CPU fallback")
@@ -1397,7 +1442,7 @@ def main():
     # ---- the other two BASELINE workloads, a few hundred milliseconds each, in the same line: configs[3] (one 16K frame
     # sharded over the GPUs, assembled on the device) and configs[4] (a batch of 4K frames through the drop-in API) ----
     legs = {}
-    if not args.no_legs:
+    if not args.no_legs and world == 1:  # (N > 1: as jobs of their own once the group is gone, see child_job)
         def shard_16k():
             if not dist.is_initialized():  # a lone rank needs the process group for this leg only: it comes last
                 for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
@@ -1426,11 +1471,7 @@ def main():
         for name, r in legs.items():
             if r is None:
                 continue
-            keep = ("value", "unit", "ms_per_step", "frames_per_s", "n_gpus", "steps", "scaling", "config", "frame_bytes", "frame_md5",
-                    "frames_checked", "assembled_frames_identical_to_host_assembly", "host_ms_per_frame", "frac_of_hbm_read_roofline",
-                    "frame0_identical_to_reference", "threads_agree_with_single_thread_run", "frames_per_s_each_round", "leg_wall_s", "error",
-                    "sections_identical_to_single_context_run", "frames_per_s_one_frame_per_launch_group")
-            out[name] = {k: r[k] for k in keep if k in r}
+            out[name] = {k: r[k] for k in LEG_KEYS if k in r}
         if world == 1 and not args.no_api:
             # API end-to-end through the drop-in hyd_send_tile (host pixels: includes PCIe, read-back, assembly)
             lib = api.Library()
@@ -1483,6 +1524,15 @@ def main():
     # gone: the other ranks are not held in a collective meanwhile (a leg that hangs on hardware it has never met would run the
     # group's watchdog out and take the headline with it), and at --gpus N their GPUs are idle when rank 0's subprocess takes them.
     if rank == 0:
+        if world > 1 and not args.no_legs:
+            # configs[3] and configs[4] over all N GPUs, each a job of its own (in a world of one they ran in-process above)
+            for name, argv in (("shard_16k", ["--mode", "shard", "--steps", "40", "--warmup", "4"]),
+                               ("batch_4k", ["--mode", "batch", "--frames", str(8 * args.frames), "--threads", str(args.threads)])):
+                t_leg = time.perf_counter()
+                r = child_job(world, argv + (["--no-bind"] if args.no_bind else []))
+                r["leg_wall_s"] = round(time.perf_counter() - t_leg, 2)
+                out[name] = {k: r[k] for k in LEG_KEYS if k in r}
+                out[name]["ran_as"] = f"a job of its own after the frame loop's process group was gone: bench.py --gpus {world} " + " ".join(argv)
         if not args.no_legs and not args.no_api:
             # the C library's own multi-device scheduler, over every GPU of the job (one GPU: an aliased list), once, on rank 0
             try:

@@ -50,3 +50,22 @@ def test_one_gpu_is_one_process_and_needs_no_launcher():
     out = _line(r)
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and "single process" in out["launched_by"]
     assert "starting" not in r.stderr
+
+
+def test_a_leg_of_an_n_rank_job_runs_as_a_job_of_its_own_outside_the_rank_environment(monkeypatch):
+    """Round 6: at --gpus N the legs that need every rank (shard_16k, batch_4k) run from rank 0 AFTER the frame loop's process
+    group is gone, each as `bench.py --gpus N ...` under a time limit (bench.child_job): a rank that fails in a leg can no
+    longer leave the others in a collective and take the headline with it.  Here: from inside a (faked) rank environment the
+    child still forms a fresh world of two; a child that prints no line or overruns its limit yields an error entry."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for k, v in (("RANK", "0"), ("WORLD_SIZE", "8"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "1"),
+                 ("TORCHELASTIC_RUN_ID", "x"), ("HYDAMD_DEVICE", "5")):
+        monkeypatch.setenv(k, v)
+    out = bench.child_job(2, ["--dry-run-launch"])
+    assert out.get("n_gpus") == 2 and out.get("rccl_ranks") == 2 and out.get("launched_by") == "bench.py itself", out
+    out = bench.child_job(1, ["--no-such-flag"])
+    assert "error" in out and "exit status" in out["error"]
+    out = bench.child_job(2, ["--dry-run-launch"], timeout=0.05)
+    assert "error" in out and "no result within" in out["error"]

@@ -865,7 +865,17 @@ static int acquire_shared_luts(HydAmdContext *ctx) {
 static int create_impl(HydAmdContext *ctx, int debug_planes) {
     const size_t slots = (size_t)ctx->max_slots, G = HYDK_GROUPS_PER_LFG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    {
+        /* HYDAMD_STREAM_HIGH=n (A/B knob): the first n contexts a process creates get their stream at the device's highest
+         * priority — a staggered mix of stages instead of sixteen streams progressing alike (round 6; same bytes) */
+        static std::atomic<int> created{0};
+        static const int high = getenv("HYDAMD_STREAM_HIGH") ? atoi(getenv("HYDAMD_STREAM_HIGH")) : 0;
+        int lo = 0, hi = 0;
+        if (created.fetch_add(1) < high && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, hi));
+        else
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    }
     ctx->stream = ctx->own_stream;
     if (const char *env = getenv("HYDAMD_TOKEN_CAP")) { /* records per group before the overflow path kicks in (tests) */
         const long v = atol(env);

@@ -9,13 +9,13 @@
 #                                                                     r06 chain_probes pmc
 # One target per file under profiles/ (the name after the tag): bench_default, kernel_stats (single, single_form4, pipe, shard,
 # api + api_timeline), tile_mode, k1_content, pipeline_bounds, chain_probes, priorities, lane_step, lane_pipe, loop_stage_times,
-# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms, nc_probe, pg_presence.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
+# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms, nc_probe, pg_presence, stream_priorities.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
 # The probes that skip stages or run stand-in kernels load hydrium_amd/lib/libhydrium_probe.so (HYD_TEST_HOOKS flavour;
 # scripts/pipe_probe.py selects it) or a variant built by `python scripts/k1_variants.py --build ...` (chain_probes and
 # priorities build theirs HERE, before the gpurun call: hipcc cross-compiles, the .so files travel with the snapshot).
 set -u
 tag=$1; shift
-targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms nc_probe pg_presence} "
+targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms nc_probe pg_presence stream_priorities} "
 want() { [[ "$targets" == *" $1 "* ]]; }
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -244,6 +244,15 @@ run pg_presence txt bash -c '
   b() { python bench.py --steps 256 --no-cpu-baseline --no-api --no-legs --no-content "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d[\"value\"]/1e3,1), \"Gpixel/s\", d[\"timing\"][\"Mpixel/s_each_window\"], \"rccl_ranks\", d.get(\"rccl_ranks\"))"; }
   echo "# the frame loop on one GPU without and with an RCCL process group in the process (HYDAMD_BENCH_FORCE_PG=1: what every rank of a --gpus N job carries); commit $(cat .commit 2>/dev/null)"
   for i in 1 2 3; do echo -n "no process group:   "; b; echo -n "RCCL group present: "; HYDAMD_BENCH_FORCE_PG=1 b; done
+'
+fi
+
+# a staggered mix of stages: some of the contexts' streams at the device's highest priority (HYDAMD_STREAM_HIGH)
+if want stream_priorities; then
+run stream_priorities txt bash -c '
+  eval "$PIPE_PROBE"
+  echo "# the pipelined loop with the first n of the sixteen contexts own streams created at the device s highest priority (HYDAMD_STREAM_HIGH=n), sustained Gpixel/s; commit $(cat .commit 2>/dev/null)"
+  for i in 1 2; do for n in 0 2 4 8 16; do echo -n "high $n of 16:    "; HYDAMD_STREAM_HIGH=$n p; done; done
 '
 fi
 

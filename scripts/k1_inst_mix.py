@@ -43,7 +43,8 @@ def main():
                         f"-I{ROOT}/include", "-S", "--cuda-device-only", f"{ROOT}/hydrium_amd/csrc/hip/kernels.hip", "-o", out],
                        check=True, capture_output=True)
         text = open(out).read().splitlines()
-    start = next(i for i, l in enumerate(text) if l.startswith("_Z20k_transform_tokenizeILi1ELi0EEvPK9HydkLfJobPj:"))
+    # k_transform_tokenize<u16, XMODE 0> (the parameter list grew with round 5's split launches: match the instance, not the signature)
+    start = next(i for i, l in enumerate(text) if l.startswith("_Z20k_transform_tokenizeILi1ELi0EEvPK9HydkLfJob") and l.rstrip().split()[0].endswith(":"))
     end = next(i for i in range(start, len(text)) if ".end_amdhsa_kernel" in text[i])
     body = text[start:end]
     # straight-line regions = maximal runs of instructions without a label or a branch

@@ -39,6 +39,8 @@ ap.add_argument("--events", default="torch", choices=("torch", "device", "none")
                      "device (HIP events created with hipEventReleaseToDevice), none (the rate is the run's wall clock)")
 ap.add_argument("--chain-clock", action="store_true", help="with a library built under -DHYDK_CHAIN_PROBE=32 (and HYDAMD_DEBUG_SKIP=4): when did the chain wavefronts of context 0's last launch group start and end?")
 ap.add_argument("--lanes", type=int, default=0, help="> 0: this many HIP streams, contexts dealt to them in turn (several contexts per stream)")
+ap.add_argument("--high", type=int, default=-1, help=">= 0: every context on a torch stream of its own, the first this many of them created with HIGH "
+                                                    "priority (does a staggered mix of stages beat sixteen streams progressing alike?)")
 a = ap.parse_args()
 if not a.no_bind:
     placement.bind_near_gpu(0)
@@ -53,6 +55,10 @@ if a.lanes:
     lanes = [torch.cuda.Stream() for _ in range(a.lanes)]
     for i, c in enumerate(ctxs):
         c.set_stream(lanes[i % a.lanes].cuda_stream)
+if a.high >= 0:
+    prio = [torch.cuda.Stream(priority=-1 if i < a.high else 0) for i in range(len(ctxs))]
+    for c, st in zip(ctxs, prio):
+        c.set_stream(st.cuda_stream)
 ext = [torch.cuda.ExternalStream(c.get_stream()) for c in ctxs]
 for c in ctxs:
     c.set_rans_waves(a.rans)

@@ -9,13 +9,13 @@
 #                                                                     r06 chain_probes pmc
 # One target per file under profiles/ (the name after the tag): bench_default, kernel_stats (single, single_form4, pipe, shard,
 # api + api_timeline), tile_mode, k1_content, pipeline_bounds, chain_probes, priorities, lane_step, lane_pipe, loop_stage_times,
-# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms, nc_probe, pg_presence, stream_priorities.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
+# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms, nc_probe, pg_presence, stream_priorities, k1_waves5.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
 # The probes that skip stages or run stand-in kernels load hydrium_amd/lib/libhydrium_probe.so (HYD_TEST_HOOKS flavour;
 # scripts/pipe_probe.py selects it) or a variant built by `python scripts/k1_variants.py --build ...` (chain_probes and
 # priorities build theirs HERE, before the gpurun call: hipcc cross-compiles, the .so files travel with the snapshot).
 set -u
 tag=$1; shift
-targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms nc_probe pg_presence stream_priorities} "
+targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms nc_probe pg_presence stream_priorities k1_waves5} "
 want() { [[ "$targets" == *" $1 "* ]]; }
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -254,6 +254,11 @@ run stream_priorities txt bash -c '
   echo "# the pipelined loop with the first n of the sixteen contexts own streams created at the device s highest priority (HYDAMD_STREAM_HIGH=n), sustained Gpixel/s; commit $(cat .commit 2>/dev/null)"
   for i in 1 2; do for n in 0 2 4 8 16; do echo -n "high $n of 16:    "; HYDAMD_STREAM_HIGH=$n p; done; done
 '
+fi
+
+# the transform kernel compiled for five wavefronts per SIMD (python scripts/k1_variants.py --build base= w5=-DHYDK_K1_WAVES=5 w5i1=-DHYDK_K1_WAVES=5,-DHYDK_K1_ILP=1 i1=-DHYDK_K1_ILP=1)
+if want k1_waves5; then
+run k1_waves5 txt bash -c 'echo "# the transform kernel compiled for five wavefronts per SIMD (96 registers, 14 / 7 spilled) with two pixels / one pixel in lock step; alone, bytes, the bench loop; commit $(cat .commit 2>/dev/null)"; python scripts/k1_variants.py --run --rounds 2 --pipe base w5 w5i1 i1 | grep -v "^$"'
 fi
 
 # the emit kernel as fewer, fatter workgroups (HYDAMD_EMIT_SHARE virtual blocks per workgroup): does a small kernel wait for its

@@ -66,6 +66,15 @@ constexpr int kThreads = 256;
 #ifndef HYDK_K1_TRIM
 #define HYDK_K1_TRIM 0
 #endif
+/*   HYDK_K1_CHANSEQ    round 6: the three channels take the row-pass buffer IN TURN (row DCT of channel c -> LDS -> column DCT,
+ *                      quantiser of channel c, then the next channel; a wavefront reads only what it wrote itself, no barrier)
+ *                      and the quantised coefficients live as 16-bit values in an array of their own, a thread's eight in one
+ *                      16-byte store ([block][kh][kv]): 9.0 + 12.0 KB of LDS where all three channels' row passes took 27.0 —
+ *                      25 712 bytes = 21 granules per workgroup instead of 25, so that THREE transform workgroups fit beside a
+ *                      chain workgroup's 63 granules instead of two (profiles/r06_nc_probe.txt: that occupancy is worth +4 %) */
+#ifndef HYDK_K1_CHANSEQ
+#define HYDK_K1_CHANSEQ 0
+#endif
 /* Round 6 (VERDICT r5 task 1): what of a lane-form chain's work costs the pipelined loop?  Timing-only variants of the
  * chain kernel (wrong bytes; scripts/k1_variants.py builds them, scripts/pipe_probe.py runs them with the emit stage off):
  *   HYDK_CHAIN_PROBE   1: every operand row from ONE address (no bank conflicts among the 64 lanes' ds_read_b128);
@@ -108,6 +117,16 @@ constexpr int kThreads = 256;
 /*   HYDK_LANE_NC9_PROBE  timing only (wrong bytes; run with the emit stage off): a nine-cluster frame's chains run the instance
  *                      that holds tables for this many clusters — 7: 61.8 KB, 6: 53 KB, 4: 35 KB instead of 79.5 — : what would a
  *                      chain be worth beside which THREE transform workgroups fit (160 KB - 3 x 31.25 = 66 KB)? */
+/*   HYDK_CHAIN_NUM_VGPR  a register budget for the lane-form chain (0: the compiler's choice, 164 with HYDK_LANE_PIPE 2): at <= 152 three
+ *                      transform wavefronts (120 each) fit beside a chain on its SIMD */
+#ifndef HYDK_CHAIN_NUM_VGPR
+#define HYDK_CHAIN_NUM_VGPR 0
+#endif
+#if HYDK_CHAIN_NUM_VGPR
+#define HYDK_CHAIN_VGPR_ATTR __attribute__((amdgpu_num_vgpr(HYDK_CHAIN_NUM_VGPR)))
+#else
+#define HYDK_CHAIN_VGPR_ATTR
+#endif
 #ifndef HYDK_LANE_NC9_PROBE
 #define HYDK_LANE_NC9_PROBE 9
 #endif
@@ -603,8 +622,18 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
         return;
     }
 
+#if HYDK_K1_CHANSEQ
+    static_assert(HYDK_K1_WAVELOCAL, "the channels share one row-pass buffer: a wavefront must read only what it wrote");
+    /* [block][kv][kh]: ONE channel's row-pass output at a time, 9.0 KiB; [c][block][kh][kv]: quantised coefficients, 12.0 KiB
+     * (integer input: |q| < 2^13, see store_record; float input keeps 32-bit coefficients) */
+    typedef typename std::conditional<FMT == HYDK_FMT_F32, int32_t, int16_t>::type coef_t;
+    constexpr int kQBlock = 64;
+    __shared__ float s_rowpass[kS0Chan];
+    __shared__ __attribute__((aligned(16))) coef_t s_q[3 * 32 * kQBlock];
+#else
     /* [c][block][kv][kh]: row-pass output, overwritten in place by the quantised coefficients, 27.0 KiB */
     __shared__ float s_rowpass[3 * kS0Chan];
+#endif
     /* exclusive prefix sums of the blocks' symbol counts + strip total.  Every wave computes and writes the same
      * 33 values (no barrier needed before it reads them back: its own stores are ordered before its loads) */
     __shared__ uint32_t s_boff[33];
@@ -642,7 +671,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
         const int j = t;
         s_nnz3[t] = kNnzCtx[t] % 3;
         /* two threads write the two bytes of an entry: kept apart as bytes here, read as one u16 */
-        ((uint8_t *)s_jinfo)[2 * kZigzag[t >> 3][t & 7]] = (uint8_t)t;
+        ((uint8_t *)s_jinfo)[2 * kZigzag[t >> 3][t & 7]] = HYDK_K1_CHANSEQ ? (uint8_t)(((t & 7) << 3) | (t >> 3)) : (uint8_t)t; /* (CHANSEQ: coefficients sit [kh][kv]) */
         ((uint8_t *)s_jinfo)[2 * t + 1] = (uint8_t)((j < 2 ? 0 : j < 16 ? j - 1 : j < 32 ? 15 + ((j - 16) >> 1) : 23 + ((j - 32) >> 2)) % 3);
     }
     if (t < 192) /* t = (c, kh, kv) */
@@ -700,8 +729,8 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
 
     for (int s = s_first; s < s_end; s++) {
         /* ---------------- phase A: 8 px of one block row -> XYB -> row DCT ---------------- */
+        float xv[8], yv[8], bv[8]; /* (declared out here: HYDK_K1_CHANSEQ transforms them channel by channel further down) */
         if (ab < gbw) {
-            float xv[8], yv[8], bv[8];
             const int y = py0 + s * 8 + ar; /* row inside the LF group */
             const int x0 = px0 + ab * 8;
             const bool row_ok = s * 8 + ar < gh;
@@ -864,6 +893,7 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                     d[(size_t)2 * kDbgPitch * kDbgPitch + i] = bv[i];
                 }
             }
+#if !HYDK_K1_CHANSEQ
             float o[8];
             float *dst = s_rowpass + ab * kS0Block + ar * 8;
             dct8(xv, o);
@@ -878,12 +908,19 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 dst[2 * kS0Chan + k] = o[k];
+#endif
         }
-#if HYDK_K1_WAVELOCAL
         /* LDS operations of one wavefront execute in order: its own stores are visible to its loads */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#define HYDK_K1_WAVE_SYNC()                                                                                      \
+    do {                                                                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                   \
+        __builtin_amdgcn_wave_barrier();                                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                   \
+    } while (0)
+#if HYDK_K1_CHANSEQ
+        /* (the row passes come channel by channel, inside phase B) */
+#elif HYDK_K1_WAVELOCAL
+        HYDK_K1_WAVE_SYNC();
 #else
         __syncthreads();
 #endif
@@ -891,11 +928,9 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
         /* ---------------- phase B: column DCT, quantise (in place in LDS), LF ints, non-zero bitmaps ---------------- */
         unsigned long long msk[3] = {0, 0, 0}; /* per channel X, Y, B: non-zero coefficients by zig-zag position */
         int32_t lf_int[3] = {0, 0, 0};
-        if (!(HYDK_K1_SKIP & 8) && cb < gbw) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
+        auto column_pass = [&](const int c) __attribute__((always_inline)) {
                 float col[8], v[8];
-                float *src = s_rowpass + c * kS0Chan + cb * kS0Block + kh;
+                float *src = s_rowpass + (HYDK_K1_CHANSEQ ? 0 : c * kS0Chan) + cb * kS0Block + kh;
 #pragma unroll
                 for (int n = 0; n < 8; n++)
                     col[n] = src[n * 8];
@@ -926,9 +961,24 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                         nlo |= nz ? 8u << kv : 0u;
                     else
                         nhi |= nz ? 8u << (kv - 4) : 0u;
+#if !HYDK_K1_CHANSEQ
                     /* the thread's own column: nobody else reads or writes these eight words */
                     ((int *)src)[kv * 8] = qq;
+#endif
                 }
+#if HYDK_K1_CHANSEQ
+                {   /* the thread's eight coefficients [kh][kv = 0..7] in one piece: the wavefront's 64 stores are 1 KiB in a row */
+                    coef_t *const dq = s_q + (c * 32 + cb) * kQBlock + kh * 8;
+                    if (FMT == HYDK_FMT_F32) {
+                        *(int4 *)dq = int4{q[0], q[1], q[2], q[3]};
+                        *(int4 *)(dq + 4) = int4{q[4], q[5], q[6], q[7]};
+                    } else {
+                        const uint32_t k0 = 0x05040100u; /* v_perm_b32: {low half of source 1, low half of source 0} */
+                        *(uint4 *)dq = uint4{__builtin_amdgcn_perm((uint32_t)q[1], (uint32_t)q[0], k0), __builtin_amdgcn_perm((uint32_t)q[3], (uint32_t)q[2], k0),
+                                             __builtin_amdgcn_perm((uint32_t)q[5], (uint32_t)q[4], k0), __builtin_amdgcn_perm((uint32_t)q[7], (uint32_t)q[6], k0)};
+                    }
+                }
+#endif
                 if (job.dbg_quant) {
                     int32_t *d = job.dbg_quant + (size_t)c * kDbgPitch * kDbgPitch +
                                  (size_t)(py0 + s * 8 + kh) * kDbgPitch + px0 + cb * 8;
@@ -942,7 +992,37 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                 if (!(HYDK_K1_SKIP & 4))
                 msk[c] = *(const unsigned long long *)(nib + (nib_row | nlo)) | *(const unsigned long long *)(nib + (nib_row | 128u | nhi));
                 lf_int[c] = (int32_t)(v[0] * kLfShift[c]); /* LF int: trunc(dc * shift[c]) (encoder.c:573,582) */
+        };
+#if HYDK_K1_CHANSEQ
+        {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (ab < gbw) { /* phase A's role: row ar of block ab */
+                    float o[8];
+                    float *dst = s_rowpass + ab * kS0Block + ar * 8;
+                    if (c == 0)
+                        dct8(xv, o);
+                    else if (c == 1)
+                        dct8(yv, o);
+                    else
+                        dct8(bv, o);
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        dst[k] = o[k];
+                }
+                HYDK_K1_WAVE_SYNC();
+                if (!(HYDK_K1_SKIP & 8) && cb < gbw)
+                    column_pass(c);
+                HYDK_K1_WAVE_SYNC(); /* the next channel's rows go where this channel's columns were just read */
             }
+        }
+#endif
+        if (!(HYDK_K1_SKIP & 8) && cb < gbw) {
+#if !HYDK_K1_CHANSEQ
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                column_pass(c);
+#endif
             if (kh == 0) {
 #pragma unroll
                 for (int c = 0; c < 3; c++)
@@ -990,10 +1070,14 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
         const uint32_t nB = 1u + (msk[2] ? 63u - (uint32_t)__clzll(msk[2]) : 0u);
         if (kh == 0) {
             s_blen[cb] = cb < gbw ? nY | (nX << 8) | (nB << 16) : 0u;
-            const uint32_t base = (uint32_t)(cb * kS0Block);
-            s_seg[cb * 3 + 0] = make_uint4((uint32_t)msk[1], (uint32_t)(msk[1] >> 32), nY | ((uint32_t)__popcll(msk[1]) << 8), base + kS0Chan);
+#if HYDK_K1_CHANSEQ
+            const uint32_t base = (uint32_t)(cb * kQBlock), chan_pitch = 32u * kQBlock; /* element offsets into s_q */
+#else
+            const uint32_t base = (uint32_t)(cb * kS0Block), chan_pitch = (uint32_t)kS0Chan; /* word offsets into s_rowpass */
+#endif
+            s_seg[cb * 3 + 0] = make_uint4((uint32_t)msk[1], (uint32_t)(msk[1] >> 32), nY | ((uint32_t)__popcll(msk[1]) << 8), base + chan_pitch);
             s_seg[cb * 3 + 1] = make_uint4((uint32_t)msk[0], (uint32_t)(msk[0] >> 32), nX | ((uint32_t)__popcll(msk[0]) << 8), base);
-            s_seg[cb * 3 + 2] = make_uint4((uint32_t)msk[2], (uint32_t)(msk[2] >> 32), nB | ((uint32_t)__popcll(msk[2]) << 8), base + 2 * kS0Chan);
+            s_seg[cb * 3 + 2] = make_uint4((uint32_t)msk[2], (uint32_t)(msk[2] >> 32), nB | ((uint32_t)__popcll(msk[2]) << 8), base + 2 * chan_pitch);
         }
         __syncthreads();
 
@@ -1054,7 +1138,11 @@ __global__ HYDK_K1_OCCUPANCY void k_transform_tokenize(const HydkLfJob *__restri
                 const uint32_t count_mask = job.scheme == 0 ? 3u : 0u;
                 for (; p < pend; p++) {
                     const uint32_t ji = s_jinfo[j];
+#if HYDK_K1_CHANSEQ
+                    const int coef = (int)s_q[seg.w + (ji & 0xffu)];
+#else
                     const int coef = ((const int *)s_rowpass)[seg.w + (ji & 0xffu)];
+#endif
                     const bool is_count = j == 0u;
                     const uint32_t value = is_count ? nz_total : pack_signed(coef);
                     /* context - 111 = 458*visit + prev + 2*(nnz_ctx[remaining] + freq_ctx[j]) (encoder.c:724,731-732);
@@ -1853,7 +1941,7 @@ struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs
     HYDK_LANE_WAIT
 
 template <int NC> /* NC: clusters per preset of the frame's clustering scheme (9 / 3 / 2 / 1): the tables' size in LDS */
-__global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
+__global__ __launch_bounds__(64) HYDK_CHAIN_VGPR_ATTR void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
                                                    const HydkTables *tabs, uint16_t *aux_all, uint16_t *flags_all,
                                                    uint32_t aux_pitch /* symbols per group in aux / flags */,
                                                    uint32_t *final_state_all, uint32_t *group_bits_all,

@@ -11,4 +11,5 @@ python scripts/k1_variants.py --build base= \
   r5=-DHYDK_LANE_PIPE=0,-DHYDK_LANE_STEP=1 pp1=-DHYDK_LANE_PIPE=1 pp2=-DHYDK_LANE_PIPE=2 pp2s2=-DHYDK_LANE_PIPE=2,-DHYDK_LANE_STEP=2 \
   gt=-DHYDK_LANE_TAB_GLOBAL=1 gt1=-DHYDK_LANE_TAB_GLOBAL=1,-DHYDK_LANE_PIPE=1 \
   pp1n7=-DHYDK_LANE_PIPE=1,-DHYDK_LANE_NC9_PROBE=7 pp1n4=-DHYDK_LANE_PIPE=1,-DHYDK_LANE_NC9_PROBE=4 pp2n7=-DHYDK_LANE_NC9_PROBE=7 pp2n4=-DHYDK_LANE_NC9_PROBE=4 \
-  w5=-DHYDK_K1_WAVES=5 w5i1=-DHYDK_K1_WAVES=5,-DHYDK_K1_ILP=1 i1=-DHYDK_K1_ILP=1
+  w5=-DHYDK_K1_WAVES=5 w5i1=-DHYDK_K1_WAVES=5,-DHYDK_K1_ILP=1 i1=-DHYDK_K1_ILP=1 \
+  cs=-DHYDK_K1_CHANSEQ=1 cs1=-DHYDK_K1_CHANSEQ=1,-DHYDK_LANE_PIPE=1

@@ -9,13 +9,13 @@
 #                                                                     r06 chain_probes pmc
 # One target per file under profiles/ (the name after the tag): bench_default, kernel_stats (single, single_form4, pipe, shard,
 # api + api_timeline), tile_mode, k1_content, pipeline_bounds, chain_probes, priorities, lane_step, lane_pipe, loop_stage_times,
-# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms, nc_probe, pg_presence, stream_priorities, k1_waves5.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
+# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms, nc_probe, pg_presence, stream_priorities, k1_waves5, chanseq.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
 # The probes that skip stages or run stand-in kernels load hydrium_amd/lib/libhydrium_probe.so (HYD_TEST_HOOKS flavour;
 # scripts/pipe_probe.py selects it) or a variant built by `python scripts/k1_variants.py --build ...` (chain_probes and
 # priorities build theirs HERE, before the gpurun call: hipcc cross-compiles, the .so files travel with the snapshot).
 set -u
 tag=$1; shift
-targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms nc_probe pg_presence stream_priorities k1_waves5} "
+targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms nc_probe pg_presence stream_priorities k1_waves5 chanseq} "
 want() { [[ "$targets" == *" $1 "* ]]; }
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -259,6 +259,22 @@ fi
 # the transform kernel compiled for five wavefronts per SIMD (python scripts/k1_variants.py --build base= w5=-DHYDK_K1_WAVES=5 w5i1=-DHYDK_K1_WAVES=5,-DHYDK_K1_ILP=1 i1=-DHYDK_K1_ILP=1)
 if want k1_waves5; then
 run k1_waves5 txt bash -c 'echo "# the transform kernel compiled for five wavefronts per SIMD (96 registers, 14 / 7 spilled) with two pixels / one pixel in lock step; alone, bytes, the bench loop; commit $(cat .commit 2>/dev/null)"; python scripts/k1_variants.py --run --rounds 2 --pipe base w5 w5i1 i1 | grep -v "^$"'
+fi
+
+# the transform kernel at 21 LDS granules instead of 25 (kernels.hip HYDK_K1_CHANSEQ): python scripts/k1_variants.py --build base= pp1=-DHYDK_LANE_PIPE=1 cs=-DHYDK_K1_CHANSEQ=1 cs1=-DHYDK_K1_CHANSEQ=1,-DHYDK_LANE_PIPE=1
+if want chanseq; then
+run chanseq txt bash -c '
+  eval "$PIPE_PROBE"
+  v() { HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$1.so; export HYDAMD_LIB; shift; "$@"; unset HYDAMD_LIB; }
+  t() { python scripts/pipe_probe.py --streams 16 --frames 512 --rans 5 --reps 2 --only-transform 2>&1 | grep -E "SUSTAINED|rror" | sed "s/.*: //" | tr "\n" " "; echo; }
+  echo "# HYDK_K1_CHANSEQ (cs: the channels take the row-pass buffer in turn, 16-bit quantised coefficients: 25.7 KB of LDS per transform workgroup instead of 31.9; cs1: with the chain at 128 registers, HYDK_LANE_PIPE 1, so that three transform workgroups fit beside a chain); alone, bytes, the bench loop; commit $(cat .commit 2>/dev/null)"
+  python scripts/k1_variants.py --run --rounds 2 --pipe base pp1 cs cs1 | grep -v "^$"
+  echo "# transform kernels only, back to back on 16 streams (capacity), and the loop without scan + emit"
+  for i in 1 2; do
+    for n in base cs; do echo -n "$n transform only: "; v $n t; done
+    for n in base pp1 cs cs1; do echo -n "$n (skip 4): "; HYDAMD_DEBUG_SKIP=4 v $n p; done
+  done
+'
 fi
 
 # the emit kernel as fewer, fatter workgroups (HYDAMD_EMIT_SHARE virtual blocks per workgroup): does a small kernel wait for its

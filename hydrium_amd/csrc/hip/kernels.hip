@@ -127,6 +127,9 @@ constexpr int kThreads = 256;
 #else
 #define HYDK_CHAIN_VGPR_ATTR
 #endif
+#ifndef HYDK_CHAIN_LDS_MIN
+#define HYDK_CHAIN_LDS_MIN 0
+#endif
 #ifndef HYDK_LANE_NC9_PROBE
 #define HYDK_LANE_NC9_PROBE 9
 #endif
@@ -1953,7 +1956,12 @@ __global__ __launch_bounds__(64) HYDK_CHAIN_VGPR_ATTR void k_rans_lanes(const Hy
      * (a 16384^2 frame has 3 clusters per preset: 26 KB, not 80). */
     constexpr int kOpsBytes = NC * kLaneTokens * (int)sizeof(uint4);
     constexpr int kTabBytes = HYDK_LANE_TAB_GLOBAL ? 0 : 2 * NC * HYDK_ANS_SLOTS;
-    constexpr int kLdsBytes = kOpsBytes + kTabBytes > (int)sizeof(LfHuffScratch) ? kOpsBytes + kTabBytes : (int)sizeof(LfHuffScratch);
+    constexpr int kNeedBytes = kOpsBytes + kTabBytes > (int)sizeof(LfHuffScratch) ? kOpsBytes + kTabBytes : (int)sizeof(LfHuffScratch);
+    /* HYDK_CHAIN_LDS_MIN (round 6): a nine-cluster chain workgroup asks for at least this many bytes.  79.5 KB is just UNDER half
+     * of a compute unit's 160 KB: two chain workgroups fit one compute unit and then no transform workgroup does (2 x 63 of 128
+     * granules) — that unit's vector pipelines idle for a chain's lifetime.  Above half (65 granules = 83 200 bytes) a compute unit
+     * holds one chain at most and always two transform workgroups beside it (65 + 2 x 25 = 115). */
+    constexpr int kLdsBytes = NC == 9 && kNeedBytes < HYDK_CHAIN_LDS_MIN ? HYDK_CHAIN_LDS_MIN : kNeedBytes;
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kLdsBytes];
     uint4 *const s_ops = (uint4 *)s_mem;
     unsigned char *const s_tab = s_mem + kOpsBytes; /* uint16_t[NC * 4096] */

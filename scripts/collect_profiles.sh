@@ -9,13 +9,13 @@
 #                                                                     r06 chain_probes pmc
 # One target per file under profiles/ (the name after the tag): bench_default, kernel_stats (single, single_form4, pipe, shard,
 # api + api_timeline), tile_mode, k1_content, pipeline_bounds, chain_probes, priorities, lane_step, lane_pipe, loop_stage_times,
-# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms, nc_probe, pg_presence, stream_priorities, k1_waves5, chanseq.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
+# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms, nc_probe, pg_presence, stream_priorities, k1_waves5, chanseq, chain_lds_min.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
 # The probes that skip stages or run stand-in kernels load hydrium_amd/lib/libhydrium_probe.so (HYD_TEST_HOOKS flavour;
 # scripts/pipe_probe.py selects it) or a variant built by `python scripts/k1_variants.py --build ...` (chain_probes and
 # priorities build theirs HERE, before the gpurun call: hipcc cross-compiles, the .so files travel with the snapshot).
 set -u
 tag=$1; shift
-targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms nc_probe pg_presence stream_priorities k1_waves5 chanseq} "
+targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms nc_probe pg_presence stream_priorities k1_waves5 chanseq chain_lds_min} "
 want() { [[ "$targets" == *" $1 "* ]]; }
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -275,6 +275,11 @@ run chanseq txt bash -c '
     for n in base pp1 cs cs1; do echo -n "$n (skip 4): "; HYDAMD_DEBUG_SKIP=4 v $n p; done
   done
 '
+fi
+
+# a chain workgroup that asks for more than half a compute unit's LDS (kernels.hip HYDK_CHAIN_LDS_MIN; python scripts/k1_variants.py --build base= pad65=-DHYDK_CHAIN_LDS_MIN=83200 pad70=-DHYDK_CHAIN_LDS_MIN=89600 pad78=-DHYDK_CHAIN_LDS_MIN=99840)
+if want chain_lds_min; then
+run chain_lds_min txt bash -c 'echo "# HYDK_CHAIN_LDS_MIN: a chain workgroup asks for 65 / 70 / 78 LDS granules instead of 63, so that a compute unit holds ONE chain at most (two chains of 63 leave no room for a transform workgroup); alone, bytes, the bench loop; commit $(cat .commit 2>/dev/null)"; python scripts/k1_variants.py --run --rounds 3 --pipe base pad65 pad70 pad78 | grep -v "^$"'
 fi
 
 # the emit kernel as fewer, fatter workgroups (HYDAMD_EMIT_SHARE virtual blocks per workgroup): does a small kernel wait for its

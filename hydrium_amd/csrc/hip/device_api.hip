@@ -940,12 +940,17 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
      * host reads the pinned LF total behind it. */
     static const unsigned order_only = [] {
         const char *v = getenv("HYDAMD_EVENT_SCOPE");
-        return v && !strcmp(v, "device") ? (unsigned)hipEventReleaseToDevice : 0u;
+        return v && (!strcmp(v, "device") || !strcmp(v, "device-all")) ? (unsigned)hipEventReleaseToDevice : 0u;
     }();
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->frame_fence, hipEventDisableTiming | order_only));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_fork, hipEventDisableTiming | order_only));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_join, hipEventDisableTiming | order_only));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_ready, hipEventDisableTiming));
+    {
+        /* (HYDAMD_EVENT_SCOPE=device-all, measurement only: lf_ready too — is its system-scope release what the LF coder costs the loop?) */
+        const char *v = getenv("HYDAMD_EVENT_SCOPE");
+        const unsigned all = v && !strcmp(v, "device-all") ? (unsigned)hipEventReleaseToDevice : 0u;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_ready, hipEventDisableTiming | all));
+    }
     for (int i = 0; i < 4; i++) {
         HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_jobs_ring[i], slots * sizeof(HydkLfJob), hipHostMallocDefault));
         memset(ctx->h_jobs_ring[i], 0, slots * sizeof(HydkLfJob));
@@ -1348,6 +1353,15 @@ static int transform_range(HydAmdContext *ctx, int first, int count) {
 /* The LF coder's token and code kernels for slots [first, first + count), whose transform kernels
  * are already enqueued.  It needs only the LF ints they write: forked onto its own stream so that it
  * overlaps the HF entropy stage; join_lf brings the streams back together. */
+#ifdef HYD_TEST_HOOKS
+/* HYDAMD_DEBUG_LF_DROP (timing only, wrong LF streams): 1 the token kernel, 2 the code passengers, 4 offsets + pack, 8 the gather */
+static int lf_drop() {
+    static const int v = getenv("HYDAMD_DEBUG_LF_DROP") ? atoi(getenv("HYDAMD_DEBUG_LF_DROP")) : 0;
+    return v;
+}
+#else
+static constexpr int lf_drop() { return 0; }
+#endif
 static int ensure_lf_stream(HydAmdContext *ctx) {
     if (!ctx->lf_stream)
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lf_stream, hipStreamNonBlocking));
@@ -1413,6 +1427,7 @@ static int join_lf(HydAmdContext *ctx, int num_slots, bool totals_follow = false
     }
     if (num_slots > 0 && ctx->lf_need_gather) {
         hipStream_t where = ctx->lf_pending ? ctx->lf_stream : ctx->stream;
+        if (!(lf_drop() & 8))
         HIP_TRY(ctx, hydk::launch_lf_gather(ctx->lf_streams, ctx->lf_bits, ctx->lf_packed, ctx->lf_total, num_slots, where));
         if (totals_follow && !ctx->lf_pending) /* the caller's own publishing launch follows on the same stream */
             ctx->lf_total_unpublished = true;
@@ -1981,6 +1996,8 @@ __global__ __launch_bounds__(64) void k_sleep_probe(unsigned long long ticks_100
             *sink = s;                                                                                        \
     }
 HYDK_SLEEP_PROBE_REGS(k_sleep_probe_regs104, 104)
+HYDK_SLEEP_PROBE_REGS(k_sleep_probe_regs124, 124) /* allocated as 128: three transform wavefronts (3 x 120) still fit beside it */
+HYDK_SLEEP_PROBE_REGS(k_sleep_probe_regs160, 160) /* as the lane-form chain with HYDK_LANE_PIPE 2 (164): two fit */
 HYDK_SLEEP_PROBE_REGS(k_sleep_probe_regs40, 40)
 #undef HYDK_SLEEP_PROBE_REGS
 
@@ -2098,7 +2115,15 @@ static void launch_chain_standins(HydAmdContext *ctx, int count) {
         HYDK_STANDIN(3, 64);
     else if (!strcmp(kind, "valu4"))
         HYDK_STANDIN(5, 256);
-    else if (regs >= 100) {
+    else if (regs >= 160) {
+        if (lds > 65536)
+            (void)hipFuncSetAttribute((const void *)k_sleep_probe_regs160, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(k_sleep_probe_regs160, grid, dim3(64), (size_t)lds, ctx->stream, ticks, (uint32_t *)nullptr);
+    } else if (regs >= 124) {
+        if (lds > 65536)
+            (void)hipFuncSetAttribute((const void *)k_sleep_probe_regs124, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(k_sleep_probe_regs124, grid, dim3(64), (size_t)lds, ctx->stream, ticks, (uint32_t *)nullptr);
+    } else if (regs >= 100) {
         if (lds > 65536)
             (void)hipFuncSetAttribute((const void *)k_sleep_probe_regs104, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(k_sleep_probe_regs104, grid, dim3(64), (size_t)lds, ctx->stream, ticks, (uint32_t *)nullptr);
@@ -2206,13 +2231,14 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
             lf_first = ctx->coded;
             lf_count = num_slots - ctx->coded;
             ScopedTimer timer(ctx, HYDAMD_K_LF);
+            if (!(lf_drop() & 1))
             HIP_TRY(ctx, hydk::launch_lf_front(ctx->d_jobs + lf_first, ctx->lf_recs + (size_t)lf_first * HYDK_LF_SYMBOLS,
                                                ctx->lf_hist + (size_t)lf_first * HYDK_LF_CODES,
                                                ctx->lf_work + (size_t)lf_first * hydk::lf_work_bytes(), lf_count, ctx->stream));
         }
     }
     if (num_slots > ctx->coded) {
-        const int st = entropy_range(ctx, ctx->coded, num_slots - ctx->coded, lf_count > 0);
+        const int st = entropy_range(ctx, ctx->coded, num_slots - ctx->coded, lf_count > 0 && !(lf_drop() & 2));
         if (st != ST_OK)
             return st;
         ctx->coded = num_slots;
@@ -2243,6 +2269,7 @@ int hydamd_run_entropy(HydAmdContext *ctx, int num_slots) {
     }
     if (lf_count > 0) {
         ScopedTimer timer(ctx, HYDAMD_K_LF);
+        if (!(lf_drop() & 4))
         HIP_TRY(ctx, hydk::launch_lf_back(ctx->d_jobs + lf_first, ctx->lf_recs + (size_t)lf_first * HYDK_LF_SYMBOLS,
                                           ctx->lf_streams + lf_first, ctx->lf_bits + (size_t)lf_first * HYDK_LF_BITWORDS,
                                           ctx->lf_work + (size_t)lf_first * hydk::lf_work_bytes(), lf_count, ctx->stream));

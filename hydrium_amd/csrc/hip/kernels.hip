@@ -26,6 +26,18 @@
 #include <stdint.h>
 
 #include "hydk_common.h"
+/* HYDK_SMALL_WAVES (round 6): a register budget for the frame's small kernels — 16 wavefronts per SIMD = 32 registers, what four
+ * transform wavefronts (4 x 120) leave of a SIMD's 512: a small kernel's wavefronts then start beside a full complement of
+ * transform wavefronts instead of waiting for one to retire (and keeping the next from starting).  0: the compiler's choice. */
+#ifndef HYDK_SMALL_WAVES
+#define HYDK_SMALL_WAVES 0
+#endif
+#if HYDK_SMALL_WAVES
+#define HYDK_SMALL_BOUNDS(threads) __launch_bounds__(threads) __attribute__((amdgpu_num_vgpr(512 / HYDK_SMALL_WAVES)))
+#else
+#define HYDK_SMALL_BOUNDS(threads) __launch_bounds__(threads)
+#endif
+#include <atomic>
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -122,8 +134,23 @@ constexpr int kThreads = 256;
 #ifndef HYDK_CHAIN_NUM_VGPR
 #define HYDK_CHAIN_NUM_VGPR 0
 #endif
+/*   HYDK_CHAIN_WAVES_PER_EU  round 6's find.  A kernel whose LDS lets only two of its workgroups onto a compute unit can never have more
+ *                      than one wavefront per SIMD, and the compiler, knowing that, PADS its register allocation to the
+ *                      smallest figure that guarantees it: .amdhsa_next_free_vgpr 257 for a chain kernel that uses 164 (128 with
+ *                      HYDK_LANE_PIPE 1).  Harmless for the kernel itself — and the reason no transform wavefront beyond two ever
+ *                      fitted beside a chain on its SIMD, whatever LDS either side gave up.  Declaring the occupancy range
+ *                      (amdgpu_waves_per_eu(1, N)) stops the padding: the chain is allocated what it uses.  0: leave it to the
+ *                      compiler (the state of rounds 3-6). */
+#ifndef HYDK_CHAIN_DYN_LDS
+#define HYDK_CHAIN_DYN_LDS 0
+#endif
+#ifndef HYDK_CHAIN_WAVES_PER_EU
+#define HYDK_CHAIN_WAVES_PER_EU 0
+#endif
 #if HYDK_CHAIN_NUM_VGPR
 #define HYDK_CHAIN_VGPR_ATTR __attribute__((amdgpu_num_vgpr(HYDK_CHAIN_NUM_VGPR)))
+#elif HYDK_CHAIN_WAVES_PER_EU
+#define HYDK_CHAIN_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(1, HYDK_CHAIN_WAVES_PER_EU)))
 #else
 #define HYDK_CHAIN_VGPR_ATTR
 #endif
@@ -1310,7 +1337,7 @@ __global__ __launch_bounds__(kThreads) void k_join_parts(const HydkLfJob *__rest
  * and not on this kernel's tables).  An A/B switch (HYDAMD_LF_CODES_RIDE=tables): by default the passengers ride in the
  * chain kernel's launch, which lasts 2.5 ms anyway.
  * ======================================================================================== */
-__global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_all, HydkTables *tabs,
+__global__ HYDK_SMALL_BOUNDS(kThreads) void k_build_tables(const uint32_t *hist_all, HydkTables *tabs,
                                                            const uint32_t *alpha_max_all, int nclusters,
                                                            uint32_t alpha_floor, const uint32_t *alpha_floor_dev,
                                                            int first_slot, int num_slots, const uint32_t *lf_hist,
@@ -1943,6 +1970,12 @@ struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs
     "v_addc_co_u32_e64 %[fl], %[junk], %[fl], %[fl], %[rfn]\n\t"                                                 \
     HYDK_LANE_WAIT
 
+/* LDS of a lane-form chain workgroup: operand rows + slot tables (or the LF code builder's scratch, whichever is larger) */
+constexpr int lanes_lds_bytes(int nc) {
+    const int ops = nc * kLaneTokens * (int)sizeof(uint4), tab = HYDK_LANE_TAB_GLOBAL ? 0 : 2 * nc * HYDK_ANS_SLOTS;
+    const int need = ops + tab > (int)sizeof(LfHuffScratch) ? ops + tab : (int)sizeof(LfHuffScratch);
+    return nc == 9 && need < HYDK_CHAIN_LDS_MIN ? HYDK_CHAIN_LDS_MIN : need;
+}
 template <int NC> /* NC: clusters per preset of the frame's clustering scheme (9 / 3 / 2 / 1): the tables' size in LDS */
 __global__ __launch_bounds__(64) HYDK_CHAIN_VGPR_ATTR void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
                                                    const HydkTables *tabs, uint16_t *aux_all, uint16_t *flags_all,
@@ -1962,7 +1995,15 @@ __global__ __launch_bounds__(64) HYDK_CHAIN_VGPR_ATTR void k_rans_lanes(const Hy
      * granules) — that unit's vector pipelines idle for a chain's lifetime.  Above half (65 granules = 83 200 bytes) a compute unit
      * holds one chain at most and always two transform workgroups beside it (65 + 2 x 25 = 115). */
     constexpr int kLdsBytes = NC == 9 && kNeedBytes < HYDK_CHAIN_LDS_MIN ? HYDK_CHAIN_LDS_MIN : kNeedBytes;
+    static_assert(kLdsBytes == lanes_lds_bytes(NC), "the launch asks for what the kernel lays out");
+#if HYDK_CHAIN_DYN_LDS
+    /* the SAME bytes, asked for at launch: a kernel whose STATIC LDS lets only two of its workgroups onto a compute unit has its
+     * register allocation padded by the compiler to the smallest figure that rules out a second wavefront per SIMD
+     * (.amdhsa_next_free_vgpr 257 for a kernel that uses 164) — registers no wavefront of ANOTHER kernel can then have */
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+#else
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[kLdsBytes];
+#endif
     uint4 *const s_ops = (uint4 *)s_mem;
     unsigned char *const s_tab = s_mem + kOpsBytes; /* uint16_t[NC * 4096] */
     __builtin_amdgcn_s_setprio(HYDK_CHAIN_PRIO);
@@ -2433,7 +2474,7 @@ constexpr int kEmitPer = 8;                  /* symbols per lane and batch */
 constexpr int kEmitBatch = 64 * kEmitPer;    /* 512 */
 constexpr int kEmitWin = kEmitBatch + 4;     /* 512 symbols x at most 32 bits = 512 words + alignment slack */
 
-__global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
+__global__ HYDK_SMALL_BOUNDS(kThreads) void k_rans_emit(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
                                                         const uint16_t *aux_all, const uint16_t *flags_all, uint32_t aux_pitch,
                                                         const uint32_t *final_state_all, const uint32_t *group_bits_all,
                                                         const uint64_t *offsets_all, uint8_t *payload, int preset_bits,
@@ -2621,7 +2662,7 @@ __global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restr
  *                  other blocks clear the frame's accumulator arena when the launch is the frame's first.
  *   k_publish:     the frame's totals and status, written by the device into pinned host memory.
  * ======================================================================================== */
-__global__ __launch_bounds__(kThreads) void k_frame_begin(const uint32_t *__restrict__ host_jobs, uint32_t *__restrict__ d_jobs,
+__global__ HYDK_SMALL_BOUNDS(kThreads) void k_frame_begin(const uint32_t *__restrict__ host_jobs, uint32_t *__restrict__ d_jobs,
                                                           uint32_t job_words, uint4 *__restrict__ accum, uint32_t quads) {
     HYDK_URGENT();
     if (blockIdx.x == 0) {
@@ -2633,7 +2674,7 @@ __global__ __launch_bounds__(kThreads) void k_frame_begin(const uint32_t *__rest
         accum[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-__global__ __launch_bounds__(64) void k_publish(const uint64_t *total, uint64_t *h_total, const unsigned long long *lf_total,
+__global__ HYDK_SMALL_BOUNDS(64) void k_publish(const uint64_t *total, uint64_t *h_total, const unsigned long long *lf_total,
                                                 unsigned long long *h_lf_total, const uint32_t *status, uint32_t *h_status) {
     HYDK_URGENT();
     if (threadIdx.x == 0 && total)
@@ -2644,7 +2685,7 @@ __global__ __launch_bounds__(64) void k_publish(const uint64_t *total, uint64_t 
         *h_status = *status;
 }
 
-__global__ __launch_bounds__(kThreads) void k_scan_sections(const uint32_t *group_bits, int count, uint64_t *offsets,
+__global__ HYDK_SMALL_BOUNDS(kThreads) void k_scan_sections(const uint32_t *group_bits, int count, uint64_t *offsets,
                                                             uint64_t *total, uint8_t *payload, uint64_t payload_cap,
                                                             int clear_shared_words, uint32_t *status) {
     __shared__ uint64_t s_wave[4];
@@ -2924,9 +2965,26 @@ hipError_t launch_rans_lanes(const HydkLfJob *d_jobs, const uint32_t *sym_count,
                              int nclusters, int num_slots, const uint32_t *status, const uint32_t *lf_hist,
                              HydkLfStream *lf_streams, void *lf_work, hipStream_t stream) {
     const dim3 grid(lf_hist ? 2 * num_slots : num_slots);
+#if HYDK_CHAIN_DYN_LDS
+#define HYDK_LAUNCH_LANES(NC)                                                                                                  \
+    do {                                                                                                                       \
+        /* more than 64 KB of dynamic LDS is opted into per function AND device (several devices in one process: multi.c) */ \
+        static std::atomic<uint32_t> opted{0};                                                                                 \
+        int dev = 0;                                                                                                           \
+        if (lanes_lds_bytes(NC) > 65536 && hipGetDevice(&dev) == hipSuccess && !((opted.load() >> (dev & 31)) & 1u)) {         \
+            const hipError_t e = hipFuncSetAttribute((const void *)k_rans_lanes<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, lanes_lds_bytes(NC)); \
+            if (e != hipSuccess)                                                                                               \
+                return e;                                                                                                      \
+            opted.fetch_or(1u << (dev & 31));                                                                                  \
+        }                                                                                                                      \
+        hipLaunchKernelGGL(k_rans_lanes<NC>, grid, dim3(64), (size_t)lanes_lds_bytes(NC), stream, d_jobs, sym_count, tabs, aux, flags, aux_pitch, \
+                           final_state, group_bits, preset_bits, status, num_slots, lf_hist, lf_streams, lf_work);             \
+    } while (0)
+#else
 #define HYDK_LAUNCH_LANES(NC)                                                                                                  \
     hipLaunchKernelGGL(k_rans_lanes<NC>, grid, dim3(64), 0, stream, d_jobs, sym_count, tabs, aux, flags, aux_pitch, final_state, \
                        group_bits, preset_bits, status, num_slots, lf_hist, lf_streams, lf_work)
+#endif
     /* the tables in LDS are sized by the clustering scheme (encoder.c:862-901: 9 / 3 / 2 / 1 clusters per preset) */
     if (nclusters == 9)
         HYDK_LAUNCH_LANES(HYDK_LANE_NC9_PROBE);

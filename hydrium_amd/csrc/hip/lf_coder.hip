@@ -44,6 +44,26 @@
 #include <stdint.h>
 
 #include "hydk_common.h"
+/* HYDK_SMALL_WAVES (round 6): a register budget for the frame's small kernels — 16 wavefronts per SIMD = 32 registers, what four
+ * transform wavefronts (4 x 120) leave of a SIMD's 512: a small kernel's wavefronts then start beside a full complement of
+ * transform wavefronts instead of waiting for one to retire (and keeping the next from starting).  0: the compiler's choice. */
+/* HYDK_LF_WPB: windows a workgroup of k_lf_tokens / k_lf_pack takes, one after another (1: 220 workgroups per LF group and kernel) */
+#ifndef HYDK_LF_WPB
+#define HYDK_LF_WPB 1
+#endif
+/* HYDK_LF_PROBE (timing only, wrong LF streams): 1 no s_setprio in the LF kernels; 2 k_lf_tokens leaves no histograms (no global
+ * atomics); 4 k_lf_tokens stores no records; 8 k_lf_tokens' workgroups return at once (what do 7 040 workgroups cost by existing?) */
+#ifndef HYDK_LF_PROBE
+#define HYDK_LF_PROBE 0
+#endif
+#ifndef HYDK_SMALL_WAVES
+#define HYDK_SMALL_WAVES 0
+#endif
+#if HYDK_SMALL_WAVES
+#define HYDK_SMALL_BOUNDS(threads) __launch_bounds__(threads) __attribute__((amdgpu_num_vgpr(512 / HYDK_SMALL_WAVES)))
+#else
+#define HYDK_SMALL_BOUNDS(threads) __launch_bounds__(threads)
+#endif
 
 namespace {
 
@@ -329,7 +349,7 @@ __device__ __forceinline__ uint32_t lf_tokens_window(const HydkLfJob &job, const
         if (r[j])
             atomicAdd(&s_hist[256u + r[j] - 3u], 1u);
     }
-    if (q0 < kEmitSpan && q0 <= last_q) { /* a thread's four records are 32 contiguous bytes; the tail of the stream is padded, never read */
+    if (!(HYDK_LF_PROBE & 4) && q0 < kEmitSpan && q0 <= last_q) { /* a thread's four records are 32 contiguous bytes; the tail of the stream is padded, never read */
         ulonglong2 *dst = (ulonglong2 *)(recs + tb + q0);
         dst[0] = make_ulonglong2(q0 + 0 <= last_q ? LF_REC(v[0], lit[0], r[0]) : 0ull, q0 + 1 <= last_q ? LF_REC(v[1], lit[1], r[1]) : 0ull);
         dst[1] = make_ulonglong2(q0 + 2 <= last_q ? LF_REC(v[2], lit[2], r[2]) : 0ull, q0 + 3 <= last_q ? LF_REC(v[3], lit[3], r[3]) : 0ull);
@@ -387,42 +407,51 @@ __device__ __forceinline__ uint32_t lf_window_strings(const LfShape &sh, const u
  * The kernels.  All workgroups are 256 threads and live for microseconds.
  * ======================================================================================== */
 /* grid = (windows of 896 values, LF groups); hist_all must be zero on entry */
-__global__ __launch_bounds__(kLfThreads) void k_lf_tokens(const HydkLfJob *__restrict__ jobs,
+__global__ HYDK_SMALL_BOUNDS(kLfThreads) void k_lf_tokens(const HydkLfJob *__restrict__ jobs,
                                                           unsigned long long *__restrict__ recs_all,
                                                           uint32_t *__restrict__ hist_all, LfWork *__restrict__ work) {
-    __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
+    if (!(HYDK_LF_PROBE & 1))
+        __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
     const int slot = blockIdx.y, tid = threadIdx.x;
     const HydkLfJob &job = jobs[slot];
     const LfShape sh = lf_shape(job);
-    const int tb = (int)blockIdx.x * kEmitSpan;
-    if (tb >= sh.n)
-        return;
     __shared__ __attribute__((aligned(16))) int s_rs[kScanSpan];
     __shared__ uint32_t s_hist[HYDK_LF_CODES];
     __shared__ LfTokenScratch s_tok;
     __shared__ uint32_t s_rbits;
-    if (tid == 0)
-        s_rbits = 0;
-    uint32_t rb = lf_tokens_window(job, sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, tb, s_rs, s_hist, s_tok);
-    rb = wave_incl_sum(rb);
-    if ((tid & 63) == 63 && rb)
-        atomicAdd(&s_rbits, rb);
-    __syncthreads();
-    LfWork &w = work[slot];
-    for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads) {
-        const uint32_t c = s_hist[i];
-        w.win_hist[blockIdx.x][i] = (uint16_t)c; /* at most 896 + 7 per window */
-        if (c)
-            atomicAdd(&hist_all[(size_t)slot * HYDK_LF_CODES + i], c);
+    if (HYDK_LF_PROBE & 8)
+        return;
+    /* HYDK_LF_WPB windows per workgroup, one after another (1: a workgroup per window) */
+    for (int win = (int)blockIdx.x * HYDK_LF_WPB; win < ((int)blockIdx.x + 1) * HYDK_LF_WPB && win < kMaxWindows; win++) {
+        const int tb = win * kEmitSpan;
+        if (tb >= sh.n)
+            return;
+        if (tid == 0)
+            s_rbits = 0;
+        uint32_t rb = lf_tokens_window(job, sh, recs_all + (size_t)slot * HYDK_LF_SYMBOLS, tb, s_rs, s_hist, s_tok);
+        rb = wave_incl_sum(rb);
+        if ((tid & 63) == 63 && rb)
+            atomicAdd(&s_rbits, rb);
+        __syncthreads();
+        LfWork &w = work[slot];
+        for (int i = tid; i < HYDK_LF_CODES && !(HYDK_LF_PROBE & 2); i += kLfThreads) {
+            const uint32_t c = s_hist[i];
+            w.win_hist[win][i] = (uint16_t)c; /* at most 896 + 7 per window */
+            if (c)
+                atomicAdd(&hist_all[(size_t)slot * HYDK_LF_CODES + i], c);
+        }
+        if (tid == 0)
+            w.win_residue_bits[win] = s_rbits;
+        if (HYDK_LF_WPB > 1)
+            __syncthreads(); /* the next window reuses the scratch */
     }
-    if (tid == 0)
-        w.win_residue_bits[blockIdx.x] = s_rbits;
 }
 
 /* grid = LF groups, block = 64: code lengths + canonical codes of each LF group's histogram */
 __global__ __launch_bounds__(64) void k_lf_codes(const uint32_t *__restrict__ hist_all, HydkLfStream *__restrict__ streams,
                                                  LfWork *__restrict__ work) {
-    __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
+    if (!(HYDK_LF_PROBE & 1))
+        __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
     __shared__ LfHuffScratch s_huff;
     const int slot = blockIdx.x;
     lf_huffman_wave(hist_all + (size_t)slot * HYDK_LF_CODES, work[slot].codes, streams + slot, s_huff, (int)threadIdx.x);
@@ -430,9 +459,10 @@ __global__ __launch_bounds__(64) void k_lf_codes(const uint32_t *__restrict__ hi
 
 /* grid = LF groups, block = 256: bits of each window = sum over tokens of (count x code length) + its
  * residue bits; where each window's bits start; the words two windows share are cleared */
-__global__ __launch_bounds__(kLfThreads) void k_lf_offsets(const HydkLfJob *__restrict__ jobs, LfWork *__restrict__ work,
+__global__ HYDK_SMALL_BOUNDS(kLfThreads) void k_lf_offsets(const HydkLfJob *__restrict__ jobs, LfWork *__restrict__ work,
                                                            HydkLfStream *__restrict__ streams, uint32_t *__restrict__ bits_all) {
-    __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
+    if (!(HYDK_LF_PROBE & 1))
+        __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
     const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LfShape sh = lf_shape(jobs[slot]);
     const int windows = (sh.n + kEmitSpan - 1) / kEmitSpan; /* <= 220 < 256 */
@@ -480,20 +510,26 @@ __global__ __launch_bounds__(kLfThreads) void k_lf_offsets(const HydkLfJob *__re
 }
 
 /* grid = (windows of 896 values, LF groups) */
-__global__ __launch_bounds__(kLfThreads) void k_lf_pack(const HydkLfJob *__restrict__ jobs,
+__global__ HYDK_SMALL_BOUNDS(kLfThreads) void k_lf_pack(const HydkLfJob *__restrict__ jobs,
                                                         const unsigned long long *__restrict__ recs_all,
                                                         const LfWork *__restrict__ work, uint32_t *__restrict__ bits_all) {
-    __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
+    if (!(HYDK_LF_PROBE & 1))
+        __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
     const int slot = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const LfShape sh = lf_shape(jobs[slot]);
-    const int tb = (int)blockIdx.x * kEmitSpan;
-    if (tb >= sh.n)
-        return;
     __shared__ uint32_t s_bits[kPackWords];
     __shared__ uint32_t s_code[HYDK_LF_CODES];
     __shared__ uint32_t s_wsum[kLfWaves];
+    if ((int)blockIdx.x * HYDK_LF_WPB * kEmitSpan >= sh.n)
+        return;
     for (int i = tid; i < HYDK_LF_CODES; i += kLfThreads)
         s_code[i] = work[slot].codes[i];
+  for (int win = (int)blockIdx.x * HYDK_LF_WPB; win < ((int)blockIdx.x + 1) * HYDK_LF_WPB && win < kMaxWindows; win++) {
+    const int tb = win * kEmitSpan;
+    if (tb >= sh.n)
+        return;
+    if (win != (int)blockIdx.x * HYDK_LF_WPB)
+        __syncthreads(); /* the window before has left s_bits and s_wsum */
     for (int w = tid; w < kPackWords; w += kLfThreads)
         s_bits[w] = 0;
     __syncthreads();
@@ -504,7 +540,7 @@ __global__ __launch_bounds__(kLfThreads) void k_lf_pack(const HydkLfJob *__restr
     if (lane == 63)
         s_wsum[wave] = inc;
     __syncthreads();
-    const uint32_t gbits = work[slot].win_off[blockIdx.x]; /* bits in front of this window */
+    const uint32_t gbits = work[slot].win_off[win]; /* bits in front of this window */
     uint32_t pos = (gbits & 31u) + inc - mine, total = 0;
     for (int w = 0; w < kLfWaves; w++) {
         const uint32_t t = s_wsum[w];
@@ -531,7 +567,7 @@ __global__ __launch_bounds__(kLfThreads) void k_lf_pack(const HydkLfJob *__restr
     /* whole words are stored; the first and the last word of the span may be shared with the neighbouring
      * windows (k_lf_offsets cleared them): those are ORed into memory */
     if (!total)
-        return;
+        continue;
     const uint32_t end = (gbits & 31u) + total, last = (end - 1u) >> 5;
     uint32_t *dst = bits_all + (size_t)slot * HYDK_LF_BITWORDS + (gbits >> 5);
     for (uint32_t w = tid; w <= last; w += kLfThreads) {
@@ -540,11 +576,12 @@ __global__ __launch_bounds__(kLfThreads) void k_lf_pack(const HydkLfJob *__restr
         else
             dst[w] = s_bits[w];
     }
+  }
 }
 
 /* The LF groups' symbol data, 4-byte aligned, back to back in slot order: one copy (or one
  * all-gather) moves a frame's LF streams.  grid = LF groups, block = 256. */
-__global__ __launch_bounds__(256) void k_lf_gather(HydkLfStream *__restrict__ streams, const uint32_t *__restrict__ bits_all,
+__global__ HYDK_SMALL_BOUNDS(256) void k_lf_gather(HydkLfStream *__restrict__ streams, const uint32_t *__restrict__ bits_all,
                                                    uint32_t *__restrict__ packed, unsigned long long *__restrict__ total,
                                                    int num_slots) {
     const int slot = blockIdx.x, tid = threadIdx.x;
@@ -591,7 +628,7 @@ size_t lf_work_bytes() { return sizeof(LfWork); }
 hipError_t launch_lf_front(const HydkLfJob *d_jobs, unsigned long long *recs, uint32_t *hist, void *work, int num_slots,
                            hipStream_t stream) {
     /* hist is zero on entry: it lives in the arena k_frame_begin clears once per frame */
-    hipLaunchKernelGGL(k_lf_tokens, dim3(kMaxWindows, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist, (LfWork *)work);
+    hipLaunchKernelGGL(k_lf_tokens, dim3((kMaxWindows + HYDK_LF_WPB - 1) / HYDK_LF_WPB, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, hist, (LfWork *)work);
     return hipGetLastError();
 }
 
@@ -604,7 +641,7 @@ hipError_t launch_lf_back(const HydkLfJob *d_jobs, const unsigned long long *rec
                           void *work, int num_slots, hipStream_t stream) {
     LfWork *w = (LfWork *)work;
     hipLaunchKernelGGL(k_lf_offsets, dim3(num_slots), dim3(kLfThreads), 0, stream, d_jobs, w, streams, bits);
-    hipLaunchKernelGGL(k_lf_pack, dim3(kMaxWindows, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, w, bits);
+    hipLaunchKernelGGL(k_lf_pack, dim3((kMaxWindows + HYDK_LF_WPB - 1) / HYDK_LF_WPB, num_slots), dim3(kLfThreads), 0, stream, d_jobs, recs, w, bits);
     return hipGetLastError();
 }
 

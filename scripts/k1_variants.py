@@ -38,17 +38,28 @@ def build(specs):
     for spec in specs:
         name, _, flags = spec.partition("=")
         flags = [f for f in flags.split(",") if f]
+        lf_only = [f[3:] for f in flags if f.startswith("LF:")]  # LF:<flag>: for lf_coder.hip alone (and that file is recompiled)
+        flags = [f for f in flags if not f.startswith("LF:")]
         obj = os.path.join(OUT, f"k1v_{name}.kernels.o")
         cmd = [hb.HIPCC] + hb.HIP_FLAGS + flags + ["-c", os.path.join(hb.CSRC, "hip", "kernels.hip"), "-o", obj]
-        procs.append((name, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for name, obj, pr in procs:
+        pr2, obj2 = None, None
+        if lf_only or any("HYDK_SMALL_WAVES" in f or "HYDK_LF_" in f for f in flags):  # a switch lf_coder.hip reads too: that file is recompiled as well
+            obj2 = os.path.join(OUT, f"k1v_{name}.lf_coder.o")
+            pr2 = subprocess.Popen([hb.HIPCC] + hb.HIP_FLAGS + flags + lf_only + ["-c", os.path.join(hb.CSRC, "hip", "lf_coder.hip"), "-o", obj2],
+                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        procs.append((name, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), obj2, pr2))
+    for name, obj, pr, obj2, pr2 in procs:
         out, _ = pr.communicate()
-        if pr.returncode:
-            print(f"{name}: COMPILE FAILED\n{out}")
+        out2 = pr2.communicate()[0] if pr2 else ""
+        if pr.returncode or (pr2 and pr2.returncode):
+            print(f"{name}: COMPILE FAILED\n{out}{out2}")
             continue
+        objs = [o for o in base_objs if not (obj2 and os.path.basename(o).startswith("lf_coder.hip"))] + [obj] + ([obj2] if obj2 else [])
         hb._run([hb.HIPCC, f"--offload-arch={hb.ARCH}", "-shared", "-fPIC", "-Wl,-soname,libhydrium.so.0", "-o", lib_of(name)]
-                + base_objs + [obj, "-lpthread"])
+                + objs + ["-lpthread"])
         os.remove(obj)
+        if obj2:
+            os.remove(obj2)
         print("built", lib_of(name))
 
 

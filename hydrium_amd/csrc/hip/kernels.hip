@@ -1970,6 +1970,12 @@ struct RansOps { /* per (cluster, token), staged in LDS: everything a step needs
     "v_addc_co_u32_e64 %[fl], %[junk], %[fl], %[fl], %[rfn]\n\t"                                                 \
     HYDK_LANE_WAIT
 
+/* sixteen bytes of LDS by absolute address */
+__device__ __forceinline__ uint4 lds_row_at(uint32_t addr) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *(__attribute__((address_space(3))) const u32x4 *)(uintptr_t)addr;
+    return uint4{v.x, v.y, v.z, v.w};
+}
 /* LDS of a lane-form chain workgroup: operand rows + slot tables (or the LF code builder's scratch, whichever is larger) */
 constexpr int lanes_lds_bytes(int nc) {
     const int ops = nc * kLaneTokens * (int)sizeof(uint4), tab = HYDK_LANE_TAB_GLOBAL ? 0 : 2 * nc * HYDK_ANS_SLOTS;
@@ -2007,6 +2013,10 @@ __global__ __launch_bounds__(64) HYDK_CHAIN_VGPR_ATTR void k_rans_lanes(const Hy
     uint4 *const s_ops = (uint4 *)s_mem;
     unsigned char *const s_tab = s_mem + kOpsBytes; /* uint16_t[NC * 4096] */
     __builtin_amdgcn_s_setprio(HYDK_CHAIN_PRIO);
+#if HYDK_CHAIN_DYN_LDS
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_mem != 0u)
+        __builtin_trap(); /* (HYDK_LANE_ROW addresses the rows absolutely) */
+#endif
 #if HYDK_CHAIN_PROBE & 32
     const uint32_t probe_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -2079,6 +2089,14 @@ __global__ __launch_bounds__(64) HYDK_CHAIN_VGPR_ATTR void k_rans_lanes(const Hy
 
 /* a position beyond the stream's end walks with row 0's operands, whose symbol may never have occurred (f = 0: the "remainder"
  * is the state itself): an LDS read past the end returns 0, a global one must not be made */
+/* an operand row by its byte offset (bits 4-14 of a record).  With the LDS asked for at launch the compiler adds the array's
+ * (link-time) base to every request — one more vector instruction per symbol; the kernel has no other LDS, the array sits at
+ * address 0 (checked at the kernel's start), and the offset IS the address */
+#if HYDK_CHAIN_DYN_LDS
+#define HYDK_LANE_ROW(row) lds_row_at((uint32_t)(row))
+#else
+#define HYDK_LANE_ROW(row) (*(const uint4 *)(s_mem + (row)))
+#endif
 #if HYDK_LANE_TAB_GLOBAL
 #define HYDK_LANE_COLD_SLOT(off, VALID) ((uint32_t) * HYDK_GLOBAL(const uint16_t, (const char *)(uintptr_t)gtab + ((VALID) ? (off) : 0u)))
 #else
@@ -2260,7 +2278,7 @@ __global__ __launch_bounds__(64) HYDK_CHAIN_VGPR_ATTR void k_rans_lanes(const Hy
                     row = 1920u;                                                                                 \
                     asm volatile("" : "+v"(row));                                                                \
                 }                                                                                                \
-                ov[pos] = *(const uint4 *)(s_mem + row);                                                         \
+                ov[pos] = HYDK_LANE_ROW(row);                                                         \
             }                                                                                                    \
             __builtin_amdgcn_sched_barrier(0); /* (the scheduler would sink the requests back into the steps) */ \
             uint32_t A = 0, B = 0, sm = 0, sl = 0, so = 0; /* the walk's state between two steps of a round */   \
@@ -2352,7 +2370,7 @@ __global__ __launch_bounds__(64) HYDK_CHAIN_VGPR_ATTR void k_rans_lanes(const Hy
                     row = 1920u;                                                                                 \
                     asm volatile("" : "+v"(row));                                                                \
                 }                                                                                                \
-                ov[pos] = *(const uint4 *)(s_mem + row);                                                         \
+                ov[pos] = HYDK_LANE_ROW(row);                                                         \
             }                                                                                                    \
             __builtin_amdgcn_sched_barrier(0); /* (the scheduler would sink the requests back into the steps) */ \
             /* memory operations go out HERE, behind the wait the row requests needed for this round's records (the \
@@ -2442,6 +2460,7 @@ __global__ __launch_bounds__(64) HYDK_CHAIN_VGPR_ATTR void k_rans_lanes(const Hy
 #undef HYDK_LANE_STEP_HEAD
 #undef HYDK_LANE_STEP_COLD
 #undef HYDK_LANE_COLD_SLOT
+#undef HYDK_LANE_ROW
     if (lane < ngroups) {
         final_state_all[G] = state;
         /* [preset id][final state][per symbol: refill word, residue bits] (encoder.c:945, entropy.c:1127-1147) */

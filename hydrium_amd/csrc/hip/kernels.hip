@@ -26,17 +26,6 @@
 #include <stdint.h>
 
 #include "hydk_common.h"
-/* HYDK_SMALL_WAVES (round 6): a register budget for the frame's small kernels — 16 wavefronts per SIMD = 32 registers, what four
- * transform wavefronts (4 x 120) leave of a SIMD's 512: a small kernel's wavefronts then start beside a full complement of
- * transform wavefronts instead of waiting for one to retire (and keeping the next from starting).  0: the compiler's choice. */
-#ifndef HYDK_SMALL_WAVES
-#define HYDK_SMALL_WAVES 0
-#endif
-#if HYDK_SMALL_WAVES
-#define HYDK_SMALL_BOUNDS(threads) __launch_bounds__(threads) __attribute__((amdgpu_num_vgpr(512 / HYDK_SMALL_WAVES)))
-#else
-#define HYDK_SMALL_BOUNDS(threads) __launch_bounds__(threads)
-#endif
 #include <atomic>
 #include <type_traits>
 
@@ -129,31 +118,10 @@ constexpr int kThreads = 256;
 /*   HYDK_LANE_NC9_PROBE  timing only (wrong bytes; run with the emit stage off): a nine-cluster frame's chains run the instance
  *                      that holds tables for this many clusters — 7: 61.8 KB, 6: 53 KB, 4: 35 KB instead of 79.5 — : what would a
  *                      chain be worth beside which THREE transform workgroups fit (160 KB - 3 x 31.25 = 66 KB)? */
-/*   HYDK_CHAIN_NUM_VGPR  a register budget for the lane-form chain (0: the compiler's choice, 164 with HYDK_LANE_PIPE 2): at <= 152 three
- *                      transform wavefronts (120 each) fit beside a chain on its SIMD */
-#ifndef HYDK_CHAIN_NUM_VGPR
-#define HYDK_CHAIN_NUM_VGPR 0
-#endif
-/*   HYDK_CHAIN_WAVES_PER_EU  round 6's find.  A kernel whose LDS lets only two of its workgroups onto a compute unit can never have more
- *                      than one wavefront per SIMD, and the compiler, knowing that, PADS its register allocation to the
- *                      smallest figure that guarantees it: .amdhsa_next_free_vgpr 257 for a chain kernel that uses 164 (128 with
- *                      HYDK_LANE_PIPE 1).  Harmless for the kernel itself — and the reason no transform wavefront beyond two ever
- *                      fitted beside a chain on its SIMD, whatever LDS either side gave up.  Declaring the occupancy range
- *                      (amdgpu_waves_per_eu(1, N)) stops the padding: the chain is allocated what it uses.  0: leave it to the
- *                      compiler (the state of rounds 3-6). */
-#ifndef HYDK_CHAIN_DYN_LDS
-#define HYDK_CHAIN_DYN_LDS 0
-#endif
-#ifndef HYDK_CHAIN_WAVES_PER_EU
-#define HYDK_CHAIN_WAVES_PER_EU 0
-#endif
-#if HYDK_CHAIN_NUM_VGPR
-#define HYDK_CHAIN_VGPR_ATTR __attribute__((amdgpu_num_vgpr(HYDK_CHAIN_NUM_VGPR)))
-#elif HYDK_CHAIN_WAVES_PER_EU
-#define HYDK_CHAIN_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(1, HYDK_CHAIN_WAVES_PER_EU)))
-#else
-#define HYDK_CHAIN_VGPR_ATTR
-#endif
+/*   (The compiler PADS the register allocation of a kernel whose STATIC LDS lets only two of its workgroups onto a compute unit —
+ *   such a kernel can never have more than one wavefront per SIMD — to the smallest figure that guarantees it:
+ *   .amdhsa_next_free_vgpr 257 for the chain kernel, which uses 164.  amdgpu_waves_per_eu(1, N) and amdgpu_num_vgpr(N) do not move
+ *   it; asking for the LDS at launch does: HYDK_CHAIN_DYN_LDS.) */
 #ifndef HYDK_CHAIN_LDS_MIN
 #define HYDK_CHAIN_LDS_MIN 0
 #endif
@@ -1337,7 +1305,7 @@ __global__ __launch_bounds__(kThreads) void k_join_parts(const HydkLfJob *__rest
  * and not on this kernel's tables).  An A/B switch (HYDAMD_LF_CODES_RIDE=tables): by default the passengers ride in the
  * chain kernel's launch, which lasts 2.5 ms anyway.
  * ======================================================================================== */
-__global__ HYDK_SMALL_BOUNDS(kThreads) void k_build_tables(const uint32_t *hist_all, HydkTables *tabs,
+__global__ __launch_bounds__(kThreads) void k_build_tables(const uint32_t *hist_all, HydkTables *tabs,
                                                            const uint32_t *alpha_max_all, int nclusters,
                                                            uint32_t alpha_floor, const uint32_t *alpha_floor_dev,
                                                            int first_slot, int num_slots, const uint32_t *lf_hist,
@@ -1983,7 +1951,7 @@ constexpr int lanes_lds_bytes(int nc) {
     return nc == 9 && need < HYDK_CHAIN_LDS_MIN ? HYDK_CHAIN_LDS_MIN : need;
 }
 template <int NC> /* NC: clusters per preset of the frame's clustering scheme (9 / 3 / 2 / 1): the tables' size in LDS */
-__global__ __launch_bounds__(64) HYDK_CHAIN_VGPR_ATTR void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
+__global__ __launch_bounds__(64) void k_rans_lanes(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
                                                    const HydkTables *tabs, uint16_t *aux_all, uint16_t *flags_all,
                                                    uint32_t aux_pitch /* symbols per group in aux / flags */,
                                                    uint32_t *final_state_all, uint32_t *group_bits_all,
@@ -2493,7 +2461,7 @@ constexpr int kEmitPer = 8;                  /* symbols per lane and batch */
 constexpr int kEmitBatch = 64 * kEmitPer;    /* 512 */
 constexpr int kEmitWin = kEmitBatch + 4;     /* 512 symbols x at most 32 bits = 512 words + alignment slack */
 
-__global__ HYDK_SMALL_BOUNDS(kThreads) void k_rans_emit(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
+__global__ __launch_bounds__(kThreads) void k_rans_emit(const HydkLfJob *__restrict__ jobs, const uint32_t *sym_count_all,
                                                         const uint16_t *aux_all, const uint16_t *flags_all, uint32_t aux_pitch,
                                                         const uint32_t *final_state_all, const uint32_t *group_bits_all,
                                                         const uint64_t *offsets_all, uint8_t *payload, int preset_bits,
@@ -2681,7 +2649,7 @@ __global__ HYDK_SMALL_BOUNDS(kThreads) void k_rans_emit(const HydkLfJob *__restr
  *                  other blocks clear the frame's accumulator arena when the launch is the frame's first.
  *   k_publish:     the frame's totals and status, written by the device into pinned host memory.
  * ======================================================================================== */
-__global__ HYDK_SMALL_BOUNDS(kThreads) void k_frame_begin(const uint32_t *__restrict__ host_jobs, uint32_t *__restrict__ d_jobs,
+__global__ __launch_bounds__(kThreads) void k_frame_begin(const uint32_t *__restrict__ host_jobs, uint32_t *__restrict__ d_jobs,
                                                           uint32_t job_words, uint4 *__restrict__ accum, uint32_t quads) {
     HYDK_URGENT();
     if (blockIdx.x == 0) {
@@ -2693,7 +2661,7 @@ __global__ HYDK_SMALL_BOUNDS(kThreads) void k_frame_begin(const uint32_t *__rest
         accum[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-__global__ HYDK_SMALL_BOUNDS(64) void k_publish(const uint64_t *total, uint64_t *h_total, const unsigned long long *lf_total,
+__global__ __launch_bounds__(64) void k_publish(const uint64_t *total, uint64_t *h_total, const unsigned long long *lf_total,
                                                 unsigned long long *h_lf_total, const uint32_t *status, uint32_t *h_status) {
     HYDK_URGENT();
     if (threadIdx.x == 0 && total)
@@ -2704,7 +2672,7 @@ __global__ HYDK_SMALL_BOUNDS(64) void k_publish(const uint64_t *total, uint64_t 
         *h_status = *status;
 }
 
-__global__ HYDK_SMALL_BOUNDS(kThreads) void k_scan_sections(const uint32_t *group_bits, int count, uint64_t *offsets,
+__global__ __launch_bounds__(kThreads) void k_scan_sections(const uint32_t *group_bits, int count, uint64_t *offsets,
                                                             uint64_t *total, uint8_t *payload, uint64_t payload_cap,
                                                             int clear_shared_words, uint32_t *status) {
     __shared__ uint64_t s_wave[4];

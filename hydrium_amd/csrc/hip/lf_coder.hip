@@ -44,9 +44,6 @@
 #include <stdint.h>
 
 #include "hydk_common.h"
-/* HYDK_SMALL_WAVES (round 6): a register budget for the frame's small kernels — 16 wavefronts per SIMD = 32 registers, what four
- * transform wavefronts (4 x 120) leave of a SIMD's 512: a small kernel's wavefronts then start beside a full complement of
- * transform wavefronts instead of waiting for one to retire (and keeping the next from starting).  0: the compiler's choice. */
 /* HYDK_LF_WPB: windows a workgroup of k_lf_tokens / k_lf_pack takes, one after another (1: 220 workgroups per LF group and kernel) */
 #ifndef HYDK_LF_WPB
 #define HYDK_LF_WPB 1
@@ -55,14 +52,6 @@
  * atomics); 4 k_lf_tokens stores no records; 8 k_lf_tokens' workgroups return at once (what do 7 040 workgroups cost by existing?) */
 #ifndef HYDK_LF_PROBE
 #define HYDK_LF_PROBE 0
-#endif
-#ifndef HYDK_SMALL_WAVES
-#define HYDK_SMALL_WAVES 0
-#endif
-#if HYDK_SMALL_WAVES
-#define HYDK_SMALL_BOUNDS(threads) __launch_bounds__(threads) __attribute__((amdgpu_num_vgpr(512 / HYDK_SMALL_WAVES)))
-#else
-#define HYDK_SMALL_BOUNDS(threads) __launch_bounds__(threads)
 #endif
 
 namespace {
@@ -407,7 +396,7 @@ __device__ __forceinline__ uint32_t lf_window_strings(const LfShape &sh, const u
  * The kernels.  All workgroups are 256 threads and live for microseconds.
  * ======================================================================================== */
 /* grid = (windows of 896 values, LF groups); hist_all must be zero on entry */
-__global__ HYDK_SMALL_BOUNDS(kLfThreads) void k_lf_tokens(const HydkLfJob *__restrict__ jobs,
+__global__ __launch_bounds__(kLfThreads) void k_lf_tokens(const HydkLfJob *__restrict__ jobs,
                                                           unsigned long long *__restrict__ recs_all,
                                                           uint32_t *__restrict__ hist_all, LfWork *__restrict__ work) {
     if (!(HYDK_LF_PROBE & 1))
@@ -459,7 +448,7 @@ __global__ __launch_bounds__(64) void k_lf_codes(const uint32_t *__restrict__ hi
 
 /* grid = LF groups, block = 256: bits of each window = sum over tokens of (count x code length) + its
  * residue bits; where each window's bits start; the words two windows share are cleared */
-__global__ HYDK_SMALL_BOUNDS(kLfThreads) void k_lf_offsets(const HydkLfJob *__restrict__ jobs, LfWork *__restrict__ work,
+__global__ __launch_bounds__(kLfThreads) void k_lf_offsets(const HydkLfJob *__restrict__ jobs, LfWork *__restrict__ work,
                                                            HydkLfStream *__restrict__ streams, uint32_t *__restrict__ bits_all) {
     if (!(HYDK_LF_PROBE & 1))
         __builtin_amdgcn_s_setprio(3); /* late work of a frame whose stream holds nothing else: see kernels.hip HYDK_URGENT */
@@ -510,7 +499,7 @@ __global__ HYDK_SMALL_BOUNDS(kLfThreads) void k_lf_offsets(const HydkLfJob *__re
 }
 
 /* grid = (windows of 896 values, LF groups) */
-__global__ HYDK_SMALL_BOUNDS(kLfThreads) void k_lf_pack(const HydkLfJob *__restrict__ jobs,
+__global__ __launch_bounds__(kLfThreads) void k_lf_pack(const HydkLfJob *__restrict__ jobs,
                                                         const unsigned long long *__restrict__ recs_all,
                                                         const LfWork *__restrict__ work, uint32_t *__restrict__ bits_all) {
     if (!(HYDK_LF_PROBE & 1))
@@ -581,7 +570,7 @@ __global__ HYDK_SMALL_BOUNDS(kLfThreads) void k_lf_pack(const HydkLfJob *__restr
 
 /* The LF groups' symbol data, 4-byte aligned, back to back in slot order: one copy (or one
  * all-gather) moves a frame's LF streams.  grid = LF groups, block = 256. */
-__global__ HYDK_SMALL_BOUNDS(256) void k_lf_gather(HydkLfStream *__restrict__ streams, const uint32_t *__restrict__ bits_all,
+__global__ __launch_bounds__(256) void k_lf_gather(HydkLfStream *__restrict__ streams, const uint32_t *__restrict__ bits_all,
                                                    uint32_t *__restrict__ packed, unsigned long long *__restrict__ total,
                                                    int num_slots) {
     const int slot = blockIdx.x, tid = threadIdx.x;

@@ -9,13 +9,13 @@
 #                                                                     r06 chain_probes pmc
 # One target per file under profiles/ (the name after the tag): bench_default, kernel_stats (single, single_form4, pipe, shard,
 # api + api_timeline), tile_mode, k1_content, pipeline_bounds, chain_probes, priorities, lane_step, lane_pipe, loop_stage_times,
-# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms, nc_probe, pg_presence, stream_priorities, k1_waves5, chanseq, chain_lds_min.  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
+# emit_share, icache, pmc_8k_photo, fuzz, split_loop, gt_chain, noise_forms, nc_probe, pg_presence, stream_priorities, k1_waves5, chanseq, chain_lds_min, sleeper_matrix, dyn_lds (the two as first collected are several runs' outputs joined: profiles/r06_sleeper_matrix.txt, r06_dyn_lds.txt).  The kernel variants the probe targets load: bash scripts/build_probe_variants.sh (here, before gpurun).
 # The probes that skip stages or run stand-in kernels load hydrium_amd/lib/libhydrium_probe.so (HYD_TEST_HOOKS flavour;
 # scripts/pipe_probe.py selects it) or a variant built by `python scripts/k1_variants.py --build ...` (chain_probes and
 # priorities build theirs HERE, before the gpurun call: hipcc cross-compiles, the .so files travel with the snapshot).
 set -u
 tag=$1; shift
-targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms nc_probe pg_presence stream_priorities k1_waves5 chanseq chain_lds_min} "
+targets=" ${*:-bench_default kernel_stats tile_mode k1_content pipeline_bounds chain_probes priorities lane_step lane_pipe loop_stage_times emit_share launch_boundaries icache pmc_8k_photo split_loop gt_chain noise_forms nc_probe pg_presence stream_priorities k1_waves5 chanseq chain_lds_min sleeper_matrix dyn_lds} "
 want() { [[ "$targets" == *" $1 "* ]]; }
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -280,6 +280,41 @@ fi
 # a chain workgroup that asks for more than half a compute unit's LDS (kernels.hip HYDK_CHAIN_LDS_MIN; python scripts/k1_variants.py --build base= pad65=-DHYDK_CHAIN_LDS_MIN=83200 pad70=-DHYDK_CHAIN_LDS_MIN=89600 pad78=-DHYDK_CHAIN_LDS_MIN=99840)
 if want chain_lds_min; then
 run chain_lds_min txt bash -c 'echo "# HYDK_CHAIN_LDS_MIN: a chain workgroup asks for 65 / 70 / 78 LDS granules instead of 63, so that a compute unit holds ONE chain at most (two chains of 63 leave no room for a transform workgroup); alone, bytes, the bench loop; commit $(cat .commit 2>/dev/null)"; python scripts/k1_variants.py --run --rounds 3 --pipe base pad65 pad70 pad78 | grep -v "^$"'
+fi
+
+# sleepers in the chains' place: LDS held x registers held x duration, beside the 25-granule transform kernel (base) and the 21-granule one (cs)
+if want sleeper_matrix; then
+run sleeper_matrix txt bash -c '
+  eval "$PIPE_PROBE"
+  v() { HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$1.so; export HYDAMD_LIB; shift; "$@"; unset HYDAMD_LIB; }
+  echo "# sleeping wavefronts in the chains place (HYDAMD_DEBUG_SKIP=20: no chains, no scan + emit): bytes of LDS x registers x microseconds; sustained Gpixel/s; commit $(cat .commit 2>/dev/null)"
+  for n in base cs; do
+    echo -n "$n real chain (skip 4): "; HYDAMD_DEBUG_SKIP=4 v $n p
+    echo -n "$n no chain (skip 6):   "; HYDAMD_DEBUG_SKIP=6 v $n p
+    for us in 1800 4000; do for lds in 0 32768 62720 65536 72960 80640 83200 99840; do
+      echo -n "$n $us us, 104 registers, $lds B: "; HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=$lds HYDAMD_DEBUG_SLEEP_VGPRS=104 HYDAMD_DEBUG_SLEEP_US=$us v $n p
+    done; done
+    for r in 104 124 160; do echo -n "$n 1800 us, $r registers, 65536 B: "; HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=65536 HYDAMD_DEBUG_SLEEP_VGPRS=$r HYDAMD_DEBUG_SLEEP_US=1800 v $n p; done
+    for r in 104 124 160; do echo -n "$n 1800 us, $r registers, 80640 B: "; HYDAMD_DEBUG_SKIP=20 HYDAMD_DEBUG_SLEEP_LDS=80640 HYDAMD_DEBUG_SLEEP_VGPRS=$r HYDAMD_DEBUG_SLEEP_US=1800 v $n p; done
+  done
+'
+fi
+
+# the chain at its true register allocation (HYDK_CHAIN_DYN_LDS) beside the 21-granule transform kernel, and what the LF coder costs there
+if want dyn_lds; then
+run dyn_lds txt bash -c '
+  eval "$PIPE_PROBE"
+  v() { HYDAMD_LIB=$PWD/scripts/probe_build/k1v_$1.so; export HYDAMD_LIB; shift; "$@"; unset HYDAMD_LIB; }
+  echo "# dyn: the chain s LDS asked for at launch (164 registers allocated instead of 264); csdynp1: + HYDK_K1_CHANSEQ + HYDK_LANE_PIPE 1 (128); commit $(cat .commit 2>/dev/null)"
+  K1V_NOISE=1 python scripts/k1_variants.py --run --rounds 2 --pipe base dyn csdynp1 | grep -v "^$"
+  echo "# loop without scan + emit (skip 4), with and without the LF coder; q5: the chain without global traffic and bank conflicts (timing only)"
+  for n in base csdynp1; do echo -n "$n (skip 4): "; HYDAMD_DEBUG_SKIP=4 v $n p; echo -n "$n (skip 4), LF coder off: "; HYDAMD_DEBUG_SKIP=4 v $n p --lf 0; done
+  echo -n "csdynp1q5 (skip 4), LF coder off: "; HYDAMD_DEBUG_SKIP=4 v csdynp1q5 p --lf 0
+  echo "# the full loop; LF kernels dropped (HYDAMD_DEBUG_LF_DROP: 1 tokens, 2 code passengers, 4 offsets + pack, 8 gather) and timing-only token kernels (HYDK_LF_PROBE: 2 no histograms, 4 no records, 8 workgroups return at once)"
+  for n in base csdynp1; do echo -n "$n: "; v $n p; echo -n "$n, LF coder off: "; v $n p --lf 0; done
+  for d in 1 2 4 8 15; do echo -n "csdynp1 drop $d: "; HYDAMD_DEBUG_LF_DROP=$d v csdynp1 p; done
+  for n in lp2 lp4 lp8; do echo -n "$n: "; v $n p; done
+'
 fi
 
 # the emit kernel as fewer, fatter workgroups (HYDAMD_EMIT_SHARE virtual blocks per workgroup): does a small kernel wait for its

@@ -43,7 +43,7 @@ def build(specs):
         obj = os.path.join(OUT, f"k1v_{name}.kernels.o")
         cmd = [hb.HIPCC] + hb.HIP_FLAGS + flags + ["-c", os.path.join(hb.CSRC, "hip", "kernels.hip"), "-o", obj]
         pr2, obj2 = None, None
-        if lf_only or any("HYDK_SMALL_WAVES" in f or "HYDK_LF_" in f for f in flags):  # a switch lf_coder.hip reads too: that file is recompiled as well
+        if lf_only or any("HYDK_LF_" in f for f in flags):  # a switch lf_coder.hip reads too: that file is recompiled as well
             obj2 = os.path.join(OUT, f"k1v_{name}.lf_coder.o")
             pr2 = subprocess.Popen([hb.HIPCC] + hb.HIP_FLAGS + flags + lf_only + ["-c", os.path.join(hb.CSRC, "hip", "lf_coder.hip"), "-o", obj2],
                                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -940,15 +940,24 @@ static int create_impl(HydAmdContext *ctx, int debug_planes) {
      * host reads the pinned LF total behind it. */
     static const unsigned order_only = [] {
         const char *v = getenv("HYDAMD_EVENT_SCOPE");
-        return v && (!strcmp(v, "device") || !strcmp(v, "device-all")) ? (unsigned)hipEventReleaseToDevice : 0u;
+#ifdef HYD_TEST_HOOKS
+        if (v && !strcmp(v, "device-all")) /* (see lf_ready) */
+            return (unsigned)hipEventReleaseToDevice;
+#endif
+        return v && !strcmp(v, "device") ? (unsigned)hipEventReleaseToDevice : 0u;
     }();
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->frame_fence, hipEventDisableTiming | order_only));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_fork, hipEventDisableTiming | order_only));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_join, hipEventDisableTiming | order_only));
     {
-        /* (HYDAMD_EVENT_SCOPE=device-all, measurement only: lf_ready too — is its system-scope release what the LF coder costs the loop?) */
+#ifdef HYD_TEST_HOOKS
+        /* (HYDAMD_EVENT_SCOPE=device-all, probe flavour only: lf_ready too — is its system-scope release what the LF coder costs
+         * the loop?  It is not: profiles/r06_dyn_lds.txt) */
         const char *v = getenv("HYDAMD_EVENT_SCOPE");
         const unsigned all = v && !strcmp(v, "device-all") ? (unsigned)hipEventReleaseToDevice : 0u;
+#else
+        const unsigned all = 0u;
+#endif
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lf_ready, hipEventDisableTiming | all));
     }
     for (int i = 0; i < 4; i++) {

@@ -18,7 +18,10 @@ ITSELF (re-executing under `python -m torch.distributed.run --nnodes=1 --nproc-p
 running inside a process group; launched by torch.distributed.run it checks that the world it finds is the `--gpus` it
 was given.  `n_gpus` is the process group's size and `rccl_ranks` the sum of an all-reduce of ones over it.
 `--mode shard` is the strong-scaling leg (ONE 16384x16384 frame per step, LF groups sharded over the ranks, one blob
-gather per frame to the assembling rank).
+gather per frame to the assembling rank).  The frame-mode line carries the other workloads as legs: on one GPU they run
+in-process behind the timed loop; at N > 1 the legs that need every rank (shard_16k, batch_4k) are started by rank 0 as jobs of
+their own once the frame loop's process group is gone (`child_job`: `bench.py --gpus N --mode ...`, 300 s, killed as a whole on
+overrun), so that a leg that fails or hangs cannot take the headline with it.
 
 Prints ONE JSON line on rank 0.  `value` is whole-job Mpixel/s over all GPUs.
 """
